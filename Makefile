@@ -1,0 +1,53 @@
+# malva-hip build.  Everything is built in-tree so the artefacts travel with the
+# repo snapshot to the GPU box; none of them is committed (.gitignore).
+#
+#   make lib      HIP kernels + C-ABI       -> malva_amd/lib/libmalva_hip.so   (hipcc, gfx950)
+#   make cli      C++17 host driver         -> bin/malva-geno
+#   make oracle   CPU restatement (checker) -> oracle/libmalva_oracle.so       (gcc)
+#   make ref      the reference's own vendored xxhash.c, compiled where it lies
+#                 under /root/reference     -> oracle/_ref/libxxhash_ref.so    (only when the reference is present)
+
+HIPCC      ?= /opt/rocm/bin/hipcc
+CC         ?= gcc
+CXX        ?= g++
+ARCH       ?= gfx950
+REFERENCE  ?= /root/reference
+
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Imalva_amd/csrc \
+              -Wall -Wno-unused-function -fvisibility=hidden
+CSRC       := $(wildcard malva_amd/csrc/*.hip)
+CHDR       := $(wildcard malva_amd/csrc/*.h) $(wildcard include/*.h)
+HOSTSRC    := $(wildcard malva_amd/host/*.cpp)
+HOSTHDR    := $(wildcard malva_amd/host/*.hpp)
+
+all: lib oracle ref cli
+
+lib: malva_amd/lib/libmalva_hip.so
+malva_amd/lib/libmalva_hip.so: $(CSRC) $(CHDR)
+	@mkdir -p malva_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)
+
+cli: bin/malva-geno
+bin/malva-geno: $(HOSTSRC) $(HOSTHDR) malva_amd/lib/libmalva_hip.so
+	@mkdir -p bin
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Imalva_amd/host -o $@ $(HOSTSRC) \
+	    -Lmalva_amd/lib -lmalva_hip -lz -Wl,-rpath,'$$ORIGIN/../malva_amd/lib'
+
+oracle: oracle/libmalva_oracle.so
+oracle/libmalva_oracle.so: oracle/malva_oracle.c
+	$(CC) -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Wall -o $@ $< -lm
+
+# The reference build: its own xxhash.c (which includes its own xxhash.h),
+# untouched, straight from the read-only checkout.  Skipped on machines that do
+# not have the reference (the GPU box); the prebuilt .so travels instead.
+ref:
+	@if [ -f $(REFERENCE)/xxhash.c ]; then \
+	    mkdir -p oracle/_ref && \
+	    $(CC) -O2 -fPIC -shared -o oracle/_ref/libxxhash_ref.so $(REFERENCE)/xxhash.c && \
+	    echo "built oracle/_ref/libxxhash_ref.so from $(REFERENCE)/xxhash.c"; \
+	else echo "reference not present: keeping prebuilt oracle/_ref (if any)"; fi
+
+clean:
+	rm -rf malva_amd/lib bin oracle/libmalva_oracle.so oracle/_ref
+
+.PHONY: all lib cli oracle ref clean

@@ -1,0 +1,166 @@
+"""Pins for the CPU oracle: it must agree with everything the reference holds
+for this path before any GPU parity claim leans on it.
+
+  * XXH3_64bits vs the reference's own vendored xxhash.c (oracle/_ref, built by
+    `make ref` from /root/reference/xxhash.c; skipped where it is absent)
+  * the known-answer vectors recorded from the compiled reference in
+    SURVEY.md Appendix B (hashes, canonical forms, counter wrap, raw likelihoods)
+  * the reference's example: example/haploid.tar.gz -> example/haploid.malva.vcf,
+    byte for byte (fixtures copied to tests/golden/)
+"""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import capi, kmc_standin, pipeline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_xxh3_known_answers():
+    kat = [
+        (b"ACGTACGTACGTACGTACGTACGTACGTACGTACG", 0x6AE639F026113AEA),
+        (b"A" * 35, 0x149BBDBDED0FB1DE),
+        (b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACG", 0x1E2873EC7681F59A),
+        (b"T" * 43, 0x2B162856A8F91172),
+        (b"GATTACA" * 9, 0x4ECBA423D91DEEAC),
+    ]
+    for s, h in kat:
+        assert capi.xxh3_64(s) == h
+    assert capi.xxh3_64(kat[0][0]) % (1 << 33) == 638663402
+
+
+def test_xxh3_matches_reference_build():
+    path = os.path.join(ROOT, "oracle", "_ref", "libxxhash_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    ref = ctypes.CDLL(path)
+    ref.XXH3_64bits.restype = ctypes.c_uint64
+    ref.XXH3_64bits.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    rng = random.Random(20261003)
+    for length in range(0, 241):
+        for _ in range(25):
+            b = bytes(rng.randrange(256) for _ in range(length))
+            assert capi.xxh3_64(b) == ref.XXH3_64bits(b, length), length
+    for length in (35, 43, 63):
+        for _ in range(2000):
+            b = bytes(rng.choice(b"ACGTN") for _ in range(length))
+            assert capi.xxh3_64(b) == ref.XXH3_64bits(b, length)
+
+
+def test_canonical_known_answers():
+    assert capi.canonical(b"TTTTGGGGCCCCAAAATTTTGGGGCCCCAAAATTT") == b"AAATTTTGGGGCCCCAAAATTTTGGGGCCCCAAAA"
+    assert capi.canonical(b"ACGTNACGT") == b"ACGTNACGT"
+    # non-ACGTN byte: complement is NUL; BF hashes all k bytes, KMAP keeps the prefix
+    assert capi.canonical(b"ACGWACGTT") == b"AACGT\x00CGT"
+    m = capi.KMAP()
+    m.add_key(b"ACGWACGTT")
+    assert [k for k, _ in m.items()] == [b"AACGT"]
+    # lower-case table quirk: g -> G (bloom_filter.hpp:47)
+    assert capi.canonical(b"tg") == b"GA"
+
+
+def test_bf_counter_wraps_mod_65536():
+    bf = capi.BF(1 << 20)
+    km = b"ACGTACGTACGTACGTACGTACGTACGTACGTACG"
+    bf.add_key(km)
+    assert bf.increment(km, 1) is False      # write mode: no-op, returns false
+    bf.switch_mode()
+    for _ in range(300):
+        assert bf.increment(km, 255)
+    assert bf.get_count(km) == 10964          # 76500 mod 65536
+    assert bf.get_count(b"A" * 35) == 0
+
+
+def test_kmap_semantics():
+    m = capi.KMAP()
+    m.add_key(b"ACGTT")
+    m.increment(b"AACGT", 7)                  # reverse complement: same canonical key
+    assert m.get_count(b"ACGTT") == 7
+    m.increment(b"CCCCC", 5)                  # absent: no insertion
+    assert len(m) == 1 and m.get_count(b"CCCCC") == 0
+    m.increment(b"ACGTT", 0x7FFFFFFF)         # u32 add stored in int: reads back negative
+    assert m.get_count(b"ACGTT") == -(1 << 31) + 6
+    m.add_key(b"ACGTT")                       # add_key resets to 0
+    assert m.get_count(b"ACGTT") == 0
+
+
+EPS = 0.001
+
+
+def _vals(cov, freq, haploid=False, max_cov=200):
+    return capi.genotype(cov, np.array(freq, dtype=np.float32), EPS, max_cov, haploid)
+
+
+def test_genotype_known_answers_bit_exact():
+    h = float.fromhex
+    g = _vals([12, 9], [0.7, 0.3])
+    assert [(a, b) for a, b, _ in g] == [(0, 0), (0, 1), (1, 1)]
+    assert [v for _, _, v in g] == [h("0x1.eefdfc72b71fp-71"), h("0x1.53a893960afbp-2"), h("0x1.87a8a1020adbap-103")]
+    bi, gq, _ = capi.select_gt([v for _, _, v in g])
+    assert (bi, gq) == (1, 100)
+
+    g = _vals([30, 0], [0.95, 0.05])
+    assert [v for _, _, v in g] == [h("0x1.c06aba32050f9p-1"), h("0x1.799d610673c97p-34"), h("0x1.4dbed28693617p-308")]
+    assert capi.select_gt([v for _, _, v in g])[:2] == (0, 100)
+
+    g = _vals([0, 25], [0.95, 0.05])
+    assert [v for _, _, v in g] == [h("0x1.a202d247fcc3ap-250"), h("0x1.7b821659c0058p-29"), h("0x1.3f95ec31d007bp-9")]
+    bi, gq, norm = capi.select_gt([v for _, _, v in g])
+    assert (bi, gq) == (2, 100)
+    assert "%f" % norm[1] == "0.000001" and "%f" % norm[2] == "0.999999"
+
+    g = _vals([10, 7, 3], [0.6, 0.3, 0.1])
+    assert [(a, b) for a, b, _ in g] == [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    assert [v for _, _, v in g] == [h("0x1.cea77e9c3f6f7p-92"), h("0x1.55d18bbf2d9f5p-20"), h("0x1.f71f122480c9cp-58"),
+                                    h("0x1.8f850f1f1c406p-128"), h("0x1.0eec434e4beacp-85"), h("0x1.18317effd1e18p-181")]
+    assert capi.select_gt([v for _, _, v in g])[:2] == (1, 100)
+
+    g = _vals([10, 7, 3], [0.6, 0.3, 0.1], haploid=True)
+    assert [(a, b) for a, b, _ in g] == [(0, -1), (1, -1), (2, -1)]
+    assert [v for _, _, v in g] == [h("0x1.cea77e9c3f6f7p-92"), h("0x1.8f850f1f1c406p-128"), h("0x1.18317effd1e18p-181")]
+    assert capi.select_gt([v for _, _, v in g])[:2] == (0, 100)
+
+    g = _vals([201, 3], [0.5, 0.5])
+    assert g == [(0, 0, 0.0)]
+    bi, gq, norm = capi.select_gt([0.0])
+    assert bi == -1 and gq == 0 and np.isnan(norm[0])
+
+    g = _vals([5, 5], [1.0, 0.0])
+    assert [v for _, _, v in g] == [h("0x1.1ecac877b546ap-40"), 0.0, 0.0]
+    assert capi.select_gt([v for _, _, v in g])[:2] == (0, 100)
+
+    g = _vals([15, 14, 0, 1], [0.25] * 4)
+    d = {(a, b): v for a, b, v in g}
+    assert d[(0, 1)] == h("0x1.3997be27a6e4cp-8") and d[(0, 0)] == h("0x1.a4d89870a38cp-148")
+    assert d[(2, 2)] == h("0x1.6475f7ce79147p-351")
+    assert max(d, key=d.get) == (0, 1)
+
+
+def test_genotype_early_outs():
+    # two over-covered alleles: one entry each (var_block.hpp:237-246)
+    assert _vals([300, 250, 1], [0.5, 0.3, 0.2]) == [(0, 0, 0.0), (0, 0, 0.0)]
+    assert _vals([0, 0], [0.5, 0.5]) == [(0, 0, 0.0)]
+    assert _vals([0, 0], [0.5, 0.5], haploid=True) == [(0, -1, 0.0)]
+
+
+@pytest.fixture(scope="module")
+def haploid_run(golden_dir):
+    opt = pipeline.Options(haploid=True, bf_size=1 << 33, freq_key="AF")
+    fa = os.path.join(golden_dir, "haploid.fa")
+    vcf = os.path.join(golden_dir, "haploid.vcf.gz")
+    idx = pipeline.index(fa, vcf, opt)
+    return opt, fa, vcf, idx
+
+
+def test_haploid_example_byte_identical(golden_dir, haploid_run):
+    """README.md:131-140: `MALVA -1 -k 35 -r 43 -b 1 -f AF haploid.fa haploid.vcf haploid.fq`"""
+    opt, fa, vcf, idx = haploid_run
+    kmers = kmc_standin.count_fastq(os.path.join(golden_dir, "haploid.fq"), opt.ref_k)
+    out = pipeline.call(fa, vcf, idx, kmers, opt)
+    gold = open(os.path.join(golden_dir, "haploid.malva.vcf")).read()
+    assert out == gold
+    assert out.count("\t0:100\n") == 54 and out.count("\t0:0\n") == 364
