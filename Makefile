@@ -14,7 +14,7 @@ ARCH       ?= gfx950
 REFERENCE  ?= /root/reference
 
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Imalva_amd/csrc \
-              -Wall -Wno-unused-function -fvisibility=hidden
+              -Wall -Wno-unused-function -Wno-unused-value -fvisibility=hidden
 CSRC       := $(wildcard malva_amd/csrc/*.hip)
 CHDR       := $(wildcard malva_amd/csrc/*.h) $(wildcard include/*.h)
 HOSTSRC    := $(wildcard malva_amd/host/*.cpp)

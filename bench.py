@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- the malva-geno `call` hot path on N MI355X GPUs of one node.
+
+One step = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM (BASELINE.json config C3 per GPU):
+
+    1. KMC scan (main.cpp:482-500) of this rank's shard of the k-mer table
+    2. exchange: one sum all-reduce of the counter vector over RCCL (N > 1 only)
+    3. per-variant path (main.cpp:556-559) on this rank's slice of the variants
+
+Weak scaling: every rank scans `--kmers` rows and genotypes `--variants`
+variants; the index (both filters + exact map) covers all N * variants and is
+replicated on every GPU, as SURVEY 8(e) prescribes.
+
+Launch:  python bench.py --gpus 1            (default, single process)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCAN_BYTES_PER_KMER = 44      # 20 B streamed + 3 probes x 8 B
+GENO_BYTES_PER_SNP = 128
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--kmers", type=float, default=1e8, help="k-mer table rows per GPU")
+    ap.add_argument("--variants", type=float, default=1e6, help="isolated biallelic SNPs per GPU")
+    ap.add_argument("--b", type=int, default=4, help="filter size in units of 2^33 bits (malva-geno -b)")
+    ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
+    ap.add_argument("--cpu-variants", type=float, default=2e5)
+    ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident summary bitmaps")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from malva_amd import BF_ALT, BF_CTX, Context, synth
+    from malva_amd.dist import allreduce_counters_, rank_world
+
+    rank, world = rank_world()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, R = 35, 43
+    n_rows = int(args.kmers)
+    n_vars = int(args.variants)
+    n_vars_total = n_vars * world
+    bf_bits = args.b << 33
+
+    # ---- setup (untimed): synthetic panel, index build on the device ------------------
+    t0 = time.time()
+    panel = synth.snp_panel(n_vars_total, seed=20261003)
+    log(rank, "panel: %d SNPs on a %.3g-base genome (%.1fs)" % (n_vars_total, panel.genome.size, time.time() - t0))
+    ctx = Context(K, R, bf_bits, device=local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.no_summary:
+        ctx.set_option("use_summary", 0)
+    t0 = time.time()
+    sig, _ = synth.snp_signature_rows(panel, K)
+    stride = 40
+    batch = 1 << 20
+    for a in range(0, sig.shape[0], 2 * batch):
+        chunk = sig[a:a + 2 * batch]
+        rows = np.zeros((chunk.shape[0], stride), dtype=np.uint8)
+        rows[:, :K] = chunk
+        ctx.map_insert(rows[0::2])          # allele 0 -> ref_bf (main.cpp:137)
+        ctx.bf_insert(BF_ALT, rows[1::2])   # others   -> bf     (main.cpp:139)
+    del sig
+    ctx.bf_finalize(BF_ALT)
+    ctx.ref_scan(panel.genome.tobytes())
+    ctx.bf_finalize(BF_CTX)
+    _, n_alt, _ = ctx.bf_info(BF_ALT)
+    _, n_ctx, _ = ctx.bf_info(BF_CTX)
+    log(rank, "index: %d bf bits set, %d context bits set, %d map keys (%.1fs)" % (n_alt, n_ctx, ctx.map_size(), time.time() - t0))
+
+    # this rank's shard of the table and of the variants
+    t0 = time.time()
+    v0, v1 = rank * n_vars, (rank + 1) * n_vars
+    sub = synth.Panel(genome=panel.genome, pos=panel.pos[v0:v1], var_allele_off=(panel.var_allele_off[v0:v1 + 1] - panel.var_allele_off[v0]),
+                      allele_off=panel.allele_off[2 * v0:2 * v1 + 1] - panel.allele_off[2 * v0], pool=panel.pool[2 * v0:2 * v1],
+                      freq=panel.freq[2 * v0:2 * v1], present_mask=panel.present_mask[v0:v1], flags=panel.flags[v0:v1],
+                      donor_gt=panel.donor_gt[v0:v1])
+    hi, lo, cnt = synth.kmer_table(sub, n_rows, K, R, seed=777 + rank)
+    log(rank, "table: %d rows per GPU (%.1fs)" % (n_rows, time.time() - t0))
+
+    def dev_i64(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+
+    d_hi, d_lo = dev_i64(hi), dev_i64(lo)
+    d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+    ctx.reference_upload(panel.genome)
+    d_pos = dev_i64(sub.pos.astype(np.uint64))
+    d_vo = torch.from_numpy(sub.var_allele_off.astype(np.uint32).view(np.int32)).to(dev)
+    d_ao = torch.from_numpy(sub.allele_off.astype(np.uint32).view(np.int32)).to(dev)
+    d_pool = torch.from_numpy(np.ascontiguousarray(sub.pool)).to(dev)
+    d_freq = torch.from_numpy(np.ascontiguousarray(sub.freq)).to(dev)
+    d_pm = dev_i64(sub.present_mask)
+    d_fl = torch.from_numpy(np.ascontiguousarray(sub.flags)).to(dev)
+    na = int(sub.var_allele_off[-1])
+    d_cov = torch.zeros(na, dtype=torch.int32, device=dev)
+    d_g1 = torch.zeros(n_vars, dtype=torch.int32, device=dev)
+    d_g2 = torch.zeros(n_vars, dtype=torch.int32, device=dev)
+    d_gq = torch.zeros(n_vars, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n_vars, dtype=torch.uint8, device=dev)
+    n_bf, n_map = ctx.counters_size()
+    d_counters = torch.zeros(n_bf + n_map, dtype=torch.int32, device=dev)
+
+    scan_ms = []
+
+    def step(record=False):
+        ctx.counters_reset()
+        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
+        if world > 1:
+            ctx.counters_export_device(d_counters.data_ptr())
+            allreduce_counters_(d_counters)
+            ctx.counters_import_device(d_counters.data_ptr())
+        ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
+                                 d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
+                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+        if record:
+            scan_ms.append(ctx.scan_stats())     # waits on the scan's own events only
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t_start = time.perf_counter()
+    for s in range(args.steps):
+        step(record=False)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing for the roofline (outside the timed region, same launches) --
+    geno_ms = []
+    for _ in range(max(3, args.steps)):
+        ctx.counters_reset()
+        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
+        scan_ms.append(ctx.scan_stats())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
+                                 d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
+                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+        e1.record()
+        e1.synchronize()
+        geno_ms.append(e0.elapsed_time(e1))
+    filt_ms = float(np.mean([m[0] for m in scan_ms]))
+    hits_ms = float(np.mean([m[1] for m in scan_ms]))
+    n_hits = int(scan_ms[-1][2])
+    geno_ms_avg = float(np.mean(geno_ms))
+
+    # ---- size-independent check of the full-size run: GT histogram is sane and the counters are consistent --
+    g1 = d_g1.cpu().numpy(); g2 = d_g2.cpu().numpy(); gq = d_gq.cpu().numpy()
+    called = {"0/0": int(np.sum((g1 == 0) & (g2 == 0))), "0/1": int(np.sum((g1 == 0) & (g2 == 1))), "1/1": int(np.sum((g1 == 1) & (g2 == 1)))}
+
+    cpu_baseline = None
+    parity_sample = None
+    if rank == 0 and args.cpu_sample > 0:
+        from oracle import capi as ocapi
+        ns = int(min(args.cpu_sample, n_rows))
+        log(rank, "cpu baseline: importing the device-built filters into the oracle ...")
+        obf, octx, omap = ocapi.BF(bf_bits), ocapi.BF(bf_bits), ocapi.KMAP()
+        _, _, words, _ = ctx.bf_export(BF_ALT)
+        obf.load_words(words)
+        _, _, words, _ = ctx.bf_export(BF_CTX)
+        octx.load_words(words)
+        del words
+        obf.switch_mode(); octx.switch_mode()
+        sigs, _ = synth.snp_signature_rows(panel, K)
+        refrows = np.zeros((n_vars_total, stride), dtype=np.uint8)
+        refrows[:, :K] = sigs[0::2]
+        ocapi.add_kmers(obf, omap, refrows, np.ones(n_vars_total, dtype=np.uint8))
+        del sigs, refrows
+        t0 = time.perf_counter()
+        ocapi.kmc_scan_packed(octx, obf, omap, hi[:ns], lo[:ns], cnt[:ns], K, R)
+        cpu_scan_s = time.perf_counter() - t0
+        # parity of the same sample through the device path
+        ctx.counters_reset()
+        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), ns)
+        ctx.synchronize()
+        _, _, _, counts = ctx.bf_export(BF_ALT)
+        keys, vals = ctx.map_export()
+        ok_bf = bool(np.array_equal(counts, obf.counts()))
+        ok_map = dict(zip(keys, (int(v) for v in vals))) == dict(omap.items())
+        nv = int(min(args.cpu_variants, n_vars))
+        t0 = time.perf_counter()
+        ocov, og1, og2, ogq = ocapi.call_isolated(obf, omap, panel.genome, sub.pos[:nv], sub.allele_off[:2 * nv + 1], sub.var_allele_off[:nv + 1],
+                                                  sub.pool[:2 * nv], sub.freq[:2 * nv], sub.present_mask[:nv], sub.flags[:nv], K, 0.001, 200, False)
+        cpu_geno_s = time.perf_counter() - t0
+        ctx.call_isolated_device(nv, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(), d_pm.data_ptr(),
+                                 d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(), d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize()
+        ok_gt = bool(np.array_equal(d_g1[:nv].cpu().numpy(), og1) and np.array_equal(d_g2[:nv].cpu().numpy(), og2)
+                     and np.array_equal(d_gq[:nv].cpu().numpy(), ogq) and np.array_equal(d_cov[:2 * nv].cpu().numpy().view(np.uint32), ocov))
+        parity_sample = {"bf_counters_equal": ok_bf, "map_values_equal": ok_map, "gt_gq_cov_equal": ok_gt, "rows": ns, "variants": nv}
+        cpu_baseline = {"value": ns / cpu_scan_s, "unit": "kmers/s", "cores": 1, "kind": "port",
+                        "sample": "first %d rows of rank 0's table through oracle/malva_oracle.c (single thread, as the reference); "
+                                  "%d variants through its loop-B restatement" % (ns, nv),
+                        "variants_per_s": nv / cpu_geno_s}
+
+    if rank == 0:
+        total_kmers = n_rows * world * args.steps
+        total_vars = n_vars * world * args.steps
+        achieved = SCAN_BYTES_PER_KMER * n_rows / (filt_ms * 1e-3) / 1e9
+        out = {
+            "metric": "KMC k-mers scanned/sec (whole call step: scan + counter all-reduce + genotyping), k=35 r=43",
+            "value": total_kmers / elapsed,
+            "unit": "kmers/s",
+            "variants_per_s": total_vars / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "C3 per GPU: %.3g KMC k-mers + %.3g isolated biallelic SNPs, k=35 r=43 b=%d, table resident in HBM"
+                                   % (n_rows, n_vars, args.b),
+                       "kmers_per_gpu": n_rows, "variants_per_gpu": n_vars, "bf_bits": bf_bits, "parallelism": "table rows x%d, variants x%d" % (world, world),
+                       "summary_bitmaps": not args.no_summary},
+            "roofline": {"kernel": "scan_filter_kernel<35,43>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_unit": SCAN_BYTES_PER_KMER,
+                         "units_per_launch": n_rows, "avg_launch_ms": filt_ms},
+            "kernels_ms": {"scan_filter": filt_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg, "scan_hit_rows": n_hits},
+            "genotype_roofline": {"achieved": GENO_BYTES_PER_SNP * n_vars / (geno_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "bytes_per_unit": GENO_BYTES_PER_SNP},
+            "calls": called,
+            "cpu_baseline": cpu_baseline,
+            "parity_sample": parity_sample,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+/*
+ * malva_hip.h -- C ABI of the MI355X-native malva-geno hot path.
+ *
+ * The reference (AlgoLab/malva v1.3.1) has no plugin/FFI seam: its hot path is
+ * the header-only classes BF (bloom_filter.hpp:52-157), KMAP (kmap.hpp:46-132)
+ * and VB (var_block.hpp:61-798), driven one k-mer / one block at a time from
+ * main.cpp.  This header is that seam, cut at exactly the calls index_main and
+ * call_main make, with every per-k-mer call turned into a batch call.  Each
+ * entry point cites the reference interface it replaces; INTEGRATION.md shows
+ * the thin BF/KMAP/VB wrappers a maintainer would put in front of it.
+ *
+ * Conventions
+ *   - every function returns 0 (MG_OK) or a negative MG_ERR_*; the message for
+ *     the last failure on a context is mg_last_error(ctx).  Nothing throws.
+ *   - all device memory is owned by the opaque mg_ctx (one context = one GPU).
+ *     Calls on one context must be serialised by the caller, exactly like the
+ *     single-threaded reference.
+ *   - "rows" arguments are host buffers of n fixed-stride ASCII k-mers, each
+ *     NUL-terminated inside its stride (the reference passes `const char*`
+ *     and measures with strlen, bloom_filter.hpp:69); 1 <= strlen <= 128.
+ *     They may be reused as soon as the call returns.
+ *   - the *_device variants take device pointers valid on the context's GPU
+ *     and are asynchronous on the context's stream (mg_set_stream); everything
+ *     else synchronises before returning.
+ *   - packed k-mer tables (the KMC stream) are SoA {hi[], lo[], cnt[]}: the
+ *     ref_k-mer as a 2-bit string (A=0 C=1 G=2 T=3), MSB-first and right
+ *     aligned in the 128-bit value hi:lo, so integer order == strcmp order.
+ *   - there is no CPU fallback anywhere behind this interface: without a
+ *     usable HIP device mg_create fails.
+ */
+#ifndef MALVA_HIP_H
+#define MALVA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_ERR_ARG (-1)    /* bad argument */
+#define MG_ERR_HIP (-2)    /* HIP runtime / launch failure */
+#define MG_ERR_STATE (-3)  /* call not valid in the filter's current mode */
+#define MG_ERR_NOMEM (-4)  /* allocation failed */
+#define MG_ERR_LIMIT (-5)  /* size beyond what the implementation addresses */
+
+#define MG_BF_ALT 0 /* `bf`         main.cpp:300 -- ALT-allele signature k-mers        */
+#define MG_BF_CTX 1 /* `context_bf` main.cpp:302 -- reference contexts (ref_k-mers)    */
+
+#define MG_MAX_KMER 128 /* longest ASCII k-mer a row may hold                            */
+#define MG_MAX_PACKED_K 64 /* longest k / ref_k of the packed (2-bit) paths              */
+
+typedef struct mg_ctx mg_ctx;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* BF bf(opt::bf_size); KMAP ref_bf; BF context_bf(opt::bf_size)  (main.cpp:300-302)
+ * plus VB vb(opt::k, opt::error_rate) (main.cpp:305,520).  bf_bits is the size
+ * of EACH filter in bits (-b N => N * 2^33, argument_parser.hpp:119-123). */
+int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, uint64_t bf_bits);
+int mg_destroy(mg_ctx *ctx);
+const char *mg_last_error(const mg_ctx *ctx);
+/* Launch everything on `hip_stream` (a hipStream_t; NULL = the context's own
+ * stream).  Lets a caller time the kernels with events on its own stream. */
+int mg_set_stream(mg_ctx *ctx, void *hip_stream);
+int mg_synchronize(mg_ctx *ctx);
+
+/* ---- BF  (bloom_filter.hpp:52-157) -------------------------------------- */
+
+/* void BF::add_key(const char*)                        bloom_filter.hpp:81   */
+int mg_bf_insert(mg_ctx *ctx, int which, const char *rows, size_t stride, size_t n);
+/* bool BF::test_key(const char*) const                 bloom_filter.hpp:87   */
+int mg_bf_test(mg_ctx *ctx, int which, const char *rows, size_t stride, size_t n, uint8_t *out);
+/* void BF::switch_mode()                               bloom_filter.hpp:93
+ * builds the rank directory and one zeroed counter per set bit */
+int mg_bf_finalize(mg_ctx *ctx, int which);
+/* bool BF::increment(const char*, uint32)              bloom_filter.hpp:100
+ * returns MG_ERR_STATE where the reference returns false (write mode) */
+int mg_bf_increment(mg_ctx *ctx, int which, const char *rows, size_t stride, size_t n, const uint32_t *counters);
+/* uint16_t BF::get_count(const char*) const            bloom_filter.hpp:115
+ * (0 for every row while the filter is still in write mode) */
+int mg_bf_get_count(mg_ctx *ctx, int which, const char *rows, size_t stride, size_t n, uint16_t *out);
+/* _size, popcount (== _counts.size() once finalised), _mode */
+int mg_bf_info(mg_ctx *ctx, int which, uint64_t *size_bits, uint64_t *n_set, int *mode);
+
+/* ---- KMAP  (kmap.hpp:46-132) -------------------------------------------- */
+
+/* void KMAP::add_key(const char*)                      kmap.hpp:108          */
+int mg_map_insert(mg_ctx *ctx, const char *rows, size_t stride, size_t n);
+/* bool KMAP::test_key(const char*)                     kmap.hpp:99           */
+int mg_map_test(mg_ctx *ctx, const char *rows, size_t stride, size_t n, uint8_t *out);
+/* void KMAP::increment(const char*, int)               kmap.hpp:114          */
+int mg_map_increment(mg_ctx *ctx, const char *rows, size_t stride, size_t n, const int32_t *counters);
+/* int KMAP::get_count(const char*)                     kmap.hpp:124          */
+int mg_map_get_count(mg_ctx *ctx, const char *rows, size_t stride, size_t n, int32_t *out);
+/* kmers.size() */
+int mg_map_size(mg_ctx *ctx, uint64_t *n_keys);
+
+/* ---- index-time reference scan  (main.cpp:383-401) ----------------------- */
+
+/* One used contig, upper-cased ASCII: for every position, if the centre k-mer
+ * of the ref_k window hits `bf`, add the window to `context_bf`. */
+int mg_ref_scan(mg_ctx *ctx, const char *contig, size_t len);
+
+/* ---- call-time KMC scan  (main.cpp:482-500) ------------------------------ */
+
+/* for each (ref_k-mer, count): ref_bf.increment(centre, count);
+ * if (!context_bf.test_key(ref_k-mer)) bf.increment(centre, count).
+ * Both filters must be finalised.  ref_k <= MG_MAX_PACKED_K. */
+int mg_kmc_scan(mg_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n);
+int mg_kmc_scan_device(mg_ctx *ctx, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n);
+
+/* ---- multi-GPU exchange step --------------------------------------------- */
+
+/* The scan's only state is two commutative wrapping-u32 sums:
+ * [ bf counters (n_bf u32, in rank order) | map counters (n_map u32, in key
+ * insertion order) ].  Ranks that built the same index agree on this layout,
+ * so one sum all-reduce of this vector combines shard scans. */
+int mg_counters_size(mg_ctx *ctx, uint64_t *n_bf, uint64_t *n_map);
+int mg_counters_export_device(mg_ctx *ctx, void *d_u32_out);
+int mg_counters_import_device(mg_ctx *ctx, const void *d_u32_in);
+int mg_counters_reset(mg_ctx *ctx);
+
+/* ---- per-variant path ----------------------------------------------------- */
+
+/* set_coverages (main.cpp:151-184) over flat signature descriptors of any
+ * number of blocks: allele slot a owns signatures [allele_sig_off[a],
+ * allele_sig_off[a+1]); signature s owns rows [sig_kmer_off[s], sig_kmer_off[s+1]);
+ * is_ref[row] != 0 -> KMAP::get_count, else BF(bf)::get_count.
+ * cov_out[a] = max over signatures of the truncating running mean. */
+int mg_lookup_cover(mg_ctx *ctx, const char *rows, size_t stride, size_t n_rows, const uint8_t *is_ref,
+                    const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
+                    uint32_t *cov_out);
+
+/* Result codes of mg_genotype / mg_call_isolated per variant */
+#define MG_GT_NORMAL 0   /* likelihood list computed                              */
+#define MG_GT_OVERCOV 1  /* some allele > max_cov: (best_geno,0) per such allele  */
+#define MG_GT_SINGLE 2   /* one allele only: (best_geno,1)                        */
+#define MG_GT_NOCOV 3    /* all coverages 0: (best_geno,0)                        */
+
+/* VB::genotype (var_block.hpp:224-330) + the normalise / first-strict-max / GQ
+ * part of VB::output_variants (:366-394).  Variant v owns allele slots
+ * [var_allele_off[v], var_allele_off[v+1]).  gt2 = -1 in haploid mode.
+ * probs (optional, may be NULL): normalised list in the reference's order,
+ * variant v at var_gt_off[v] (caller-provided offsets, A or A(A+1)/2 each). */
+int mg_genotype(mg_ctx *ctx, const uint32_t *cov, const float *freq, const uint32_t *var_allele_off, size_t n_vars,
+                float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq,
+                uint8_t *status, double *probs, const uint64_t *var_gt_off);
+
+/* Fused device path for blocks that hold ONE variant whose alleles are all
+ * shorter than k (the isolated-SNP/indel case): signature enumeration
+ * (var_block.hpp:95-219 with comb = {v}), lookup + coverage, likelihoods and
+ * GT/GQ in one launch.  `reference` is the concatenation of the upper-cased
+ * contigs already uploaded with mg_reference_upload; pos[v] is the variant's
+ * offset in that buffer.  flags bit0: eligible (is_present and not within k of
+ * a contig end, var_block.hpp:104).  present_mask bit a: some panel haplotype
+ * carries allele a (build_alleles_combs, var_block.hpp:734-786). */
+int mg_reference_upload(mg_ctx *ctx, const char *ascii, size_t len);
+int mg_call_isolated(mg_ctx *ctx, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off,
+                     const uint32_t *allele_off, const char *allele_pool, size_t pool_len, const float *freq,
+                     const uint64_t *present_mask, const uint8_t *flags, float error_rate, int max_cov, int haploid,
+                     uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status);
+/* same, every array already resident on the device (asynchronous) */
+int mg_call_isolated_device(mg_ctx *ctx, size_t n_vars, const void *d_pos, const void *d_var_allele_off,
+                            const void *d_allele_off, const void *d_allele_pool, const void *d_freq,
+                            const void *d_present_mask, const void *d_flags, float error_rate, int max_cov,
+                            int haploid, void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status);
+
+/* ---- index payloads  (bloom_filter.hpp:127-146, kmap.hpp:52-82) ----------- */
+
+/* BF: _mode, _size, bit words (ceil(size/64) u64), counters (n_set u16).
+ * Call with NULL buffers to query sizes first. */
+int mg_bf_export(mg_ctx *ctx, int which, uint64_t *words_out, uint16_t *counts_out);
+int mg_bf_import(mg_ctx *ctx, int which, int mode, uint64_t size_bits, const uint64_t *words,
+                 const uint16_t *counts, uint64_t n_counts);
+/* KMAP: n keys as NUL-terminated rows of `stride` bytes + values */
+int mg_map_export(mg_ctx *ctx, char *rows_out, size_t stride, int32_t *vals_out);
+int mg_map_import(mg_ctx *ctx, const char *rows, size_t stride, size_t n, const int32_t *vals);
+
+/* ---- introspection for tests / profiling ---------------------------------- */
+
+/* hash % size of BF::_get_hash for each row (bloom_filter.hpp:67-74,84) */
+int mg_debug_bf_index(mg_ctx *ctx, int which, const char *rows, size_t stride, size_t n, uint64_t *idx_out);
+/* same from packed k-mers of length klen (1..64), MSB-first right-aligned */
+int mg_debug_packed_index(mg_ctx *ctx, int which, const uint64_t *hi, const uint64_t *lo, size_t n, uint32_t klen,
+                          uint64_t *idx_out);
+/* timing of the most recent mg_kmc_scan* in milliseconds (HIP events on the
+ * context's stream): [0] filter kernel, [1] hit kernel; n_hits = rows that
+ * reached the hit kernel */
+int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *n_hits);
+/* 0 disables the cache-resident summary bitmaps (A/B switch; results identical) */
+int mg_set_option(mg_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MALVA_HIP_H */

@@ -1,0 +1,350 @@
+"""ctypes binding of include/malva_hip.h.  No fallback: a missing or unloadable
+libmalva_hip.so is an error."""
+import ctypes as C
+import os
+
+import numpy as np
+
+BF_ALT, BF_CTX = 0, 1
+GT_NORMAL, GT_OVERCOV, GT_SINGLE, GT_NOCOV = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MalvaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("malva_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libmalva_hip.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise MalvaError(-100, "%s not built: run `make lib` (hipcc --offload-arch=gfx950)" % path)
+    L = C.CDLL(path)
+    vp, cp, sz, u64, u32, i32, i64 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int32, C.c_int64
+    fl, it = C.c_float, C.c_int
+    sig = {
+        "mg_create": [C.POINTER(vp), it, u32, u32, u64],
+        "mg_destroy": [vp],
+        "mg_set_stream": [vp, vp],
+        "mg_synchronize": [vp],
+        "mg_bf_insert": [vp, it, vp, sz, sz],
+        "mg_bf_test": [vp, it, vp, sz, sz, vp],
+        "mg_bf_finalize": [vp, it],
+        "mg_bf_increment": [vp, it, vp, sz, sz, vp],
+        "mg_bf_get_count": [vp, it, vp, sz, sz, vp],
+        "mg_bf_info": [vp, it, vp, vp, vp],
+        "mg_map_insert": [vp, vp, sz, sz],
+        "mg_map_test": [vp, vp, sz, sz, vp],
+        "mg_map_increment": [vp, vp, sz, sz, vp],
+        "mg_map_get_count": [vp, vp, sz, sz, vp],
+        "mg_map_size": [vp, vp],
+        "mg_ref_scan": [vp, vp, sz],
+        "mg_kmc_scan": [vp, vp, vp, vp, sz],
+        "mg_kmc_scan_device": [vp, vp, vp, vp, sz],
+        "mg_counters_size": [vp, vp, vp],
+        "mg_counters_export_device": [vp, vp],
+        "mg_counters_import_device": [vp, vp],
+        "mg_counters_reset": [vp],
+        "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
+        "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
+        "mg_reference_upload": [vp, vp, sz],
+        "mg_call_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp],
+        "mg_call_isolated_device": [vp, sz, vp, vp, vp, vp, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp],
+        "mg_bf_export": [vp, it, vp, vp],
+        "mg_bf_import": [vp, it, it, u64, vp, vp, u64],
+        "mg_map_export": [vp, vp, sz, vp],
+        "mg_map_import": [vp, vp, sz, sz, vp],
+        "mg_debug_bf_index": [vp, it, vp, sz, sz, vp],
+        "mg_debug_packed_index": [vp, it, vp, vp, sz, u32, vp],
+        "mg_scan_stats": [vp, vp, vp],
+        "mg_set_option": [vp, cp, i64],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+        f.argtypes = args
+        f.restype = C.c_int
+    L.mg_last_error.argtypes = [vp]
+    L.mg_last_error.restype = cp
+    _LIB = L
+    return L
+
+
+EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_synchronize", "mg_bf_insert", "mg_bf_test",
+            "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
+            "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
+            "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset",
+            "mg_lookup_cover", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
+            "mg_bf_export", "mg_bf_import", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
+            "mg_debug_packed_index", "mg_scan_stats", "mg_set_option"]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def rows_of(kmers, stride=None):
+    """list of bytes -> contiguous uint8 [n, stride], NUL padded"""
+    n = len(kmers)
+    if stride is None:
+        stride = (max((len(k) for k in kmers), default=1) + 1 + 7) // 8 * 8
+    arr = np.zeros((n, stride), dtype=np.uint8)
+    for i, k in enumerate(kmers):
+        if len(k) >= stride:
+            raise ValueError("k-mer longer than the row stride")
+        arr[i, : len(k)] = np.frombuffer(k, dtype=np.uint8)
+    return arr
+
+
+def _rows(rows):
+    if isinstance(rows, (list, tuple)):
+        rows = rows_of(rows)
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    assert rows.ndim == 2
+    return rows
+
+
+class Context:
+    """One GPU's filters, exact map and kernels (mg_ctx)."""
+
+    def __init__(self, k=35, ref_k=43, bf_bits=1 << 33, device=0):
+        self._L = lib()
+        self.h = C.c_void_p()
+        rc = self._L.mg_create(C.byref(self.h), device, k, ref_k, bf_bits)
+        if rc != 0:
+            self.h = None
+            raise MalvaError(rc, "mg_create failed (no usable HIP device, bad sizes or out of memory)")
+        self.k, self.ref_k, self.bf_bits = k, ref_k, bf_bits
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.mg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MalvaError(rc, self._L.mg_last_error(self.h).decode())
+
+    # lifetime / options
+    def set_stream(self, stream_handle):
+        self._ck(self._L.mg_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._ck(self._L.mg_synchronize(self.h))
+
+    def set_option(self, name, value):
+        self._ck(self._L.mg_set_option(self.h, name.encode(), int(value)))
+
+    # BF
+    def bf_insert(self, which, rows):
+        rows = _rows(rows)
+        self._ck(self._L.mg_bf_insert(self.h, which, _p(rows), rows.shape[1], rows.shape[0]))
+
+    def bf_test(self, which, rows):
+        rows = _rows(rows)
+        out = np.zeros(rows.shape[0], dtype=np.uint8)
+        self._ck(self._L.mg_bf_test(self.h, which, _p(rows), rows.shape[1], rows.shape[0], _p(out)))
+        return out.astype(bool)
+
+    def bf_finalize(self, which):
+        self._ck(self._L.mg_bf_finalize(self.h, which))
+
+    def bf_increment(self, which, rows, counters):
+        rows = _rows(rows)
+        counters = np.ascontiguousarray(counters, dtype=np.uint32)
+        assert counters.shape[0] == rows.shape[0]
+        self._ck(self._L.mg_bf_increment(self.h, which, _p(rows), rows.shape[1], rows.shape[0], _p(counters)))
+
+    def bf_get_count(self, which, rows):
+        rows = _rows(rows)
+        out = np.zeros(rows.shape[0], dtype=np.uint16)
+        self._ck(self._L.mg_bf_get_count(self.h, which, _p(rows), rows.shape[1], rows.shape[0], _p(out)))
+        return out
+
+    def bf_info(self, which):
+        size, nset, mode = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._ck(self._L.mg_bf_info(self.h, which, C.byref(size), C.byref(nset), C.byref(mode)))
+        return size.value, nset.value, mode.value
+
+    def bf_index(self, which, rows):
+        rows = _rows(rows)
+        out = np.zeros(rows.shape[0], dtype=np.uint64)
+        self._ck(self._L.mg_debug_bf_index(self.h, which, _p(rows), rows.shape[1], rows.shape[0], _p(out)))
+        return out
+
+    def packed_index(self, which, hi, lo, klen):
+        hi = np.ascontiguousarray(hi, dtype=np.uint64)
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        out = np.zeros(hi.shape[0], dtype=np.uint64)
+        self._ck(self._L.mg_debug_packed_index(self.h, which, _p(hi), _p(lo), hi.shape[0], klen, _p(out)))
+        return out
+
+    def bf_export(self, which):
+        size, nset, mode = self.bf_info(which)
+        words = np.zeros((size + 63) // 64, dtype=np.uint64)
+        counts = np.zeros(nset if mode else 0, dtype=np.uint16)
+        self._ck(self._L.mg_bf_export(self.h, which, _p(words), _p(counts) if counts.size else None))
+        return mode, size, words, counts
+
+    def bf_import(self, which, mode, size, words, counts):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        self._ck(self._L.mg_bf_import(self.h, which, int(mode), size, _p(words), _p(counts) if counts.size else None,
+                                      counts.size))
+
+    # KMAP
+    def map_insert(self, rows):
+        rows = _rows(rows)
+        self._ck(self._L.mg_map_insert(self.h, _p(rows), rows.shape[1], rows.shape[0]))
+
+    def map_test(self, rows):
+        rows = _rows(rows)
+        out = np.zeros(rows.shape[0], dtype=np.uint8)
+        self._ck(self._L.mg_map_test(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(out)))
+        return out.astype(bool)
+
+    def map_increment(self, rows, counters):
+        rows = _rows(rows)
+        counters = np.ascontiguousarray(counters, dtype=np.int32)
+        self._ck(self._L.mg_map_increment(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(counters)))
+
+    def map_get_count(self, rows):
+        rows = _rows(rows)
+        out = np.zeros(rows.shape[0], dtype=np.int32)
+        self._ck(self._L.mg_map_get_count(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(out)))
+        return out
+
+    def map_size(self):
+        n = C.c_uint64()
+        self._ck(self._L.mg_map_size(self.h, C.byref(n)))
+        return n.value
+
+    def map_export(self):
+        n = self.map_size()
+        stride = (self.k + 1 + 7) // 8 * 8
+        rows = np.zeros((n, stride), dtype=np.uint8)
+        vals = np.zeros(n, dtype=np.int32)
+        if n:
+            self._ck(self._L.mg_map_export(self.h, _p(rows), stride, _p(vals)))
+        keys = [bytes(r).split(b"\0", 1)[0] for r in rows]
+        return keys, vals
+
+    def map_import(self, keys, vals):
+        rows = _rows(keys)
+        vals = np.ascontiguousarray(vals, dtype=np.int32)
+        self._ck(self._L.mg_map_import(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(vals)))
+
+    # scans
+    def ref_scan(self, contig: bytes):
+        buf = np.frombuffer(contig, dtype=np.uint8)
+        self._ck(self._L.mg_ref_scan(self.h, _p(buf), buf.size))
+
+    def kmc_scan(self, hi, lo, cnt):
+        hi = np.ascontiguousarray(hi, dtype=np.uint64)
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        cnt = np.ascontiguousarray(cnt, dtype=np.uint32)
+        assert hi.shape == lo.shape == cnt.shape
+        self._ck(self._L.mg_kmc_scan(self.h, _p(hi), _p(lo), _p(cnt), hi.shape[0]))
+
+    def kmc_scan_device(self, d_hi, d_lo, d_cnt, n):
+        self._ck(self._L.mg_kmc_scan_device(self.h, C.c_void_p(d_hi), C.c_void_p(d_lo), C.c_void_p(d_cnt), n))
+
+    def scan_stats(self):
+        ms = (C.c_float * 2)()
+        nh = C.c_uint64()
+        self._ck(self._L.mg_scan_stats(self.h, ms, C.byref(nh)))
+        return float(ms[0]), float(ms[1]), nh.value
+
+    # counters exchange
+    def counters_size(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.mg_counters_size(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def counters_export_device(self, d_ptr):
+        self._ck(self._L.mg_counters_export_device(self.h, C.c_void_p(d_ptr)))
+
+    def counters_import_device(self, d_ptr):
+        self._ck(self._L.mg_counters_import_device(self.h, C.c_void_p(d_ptr)))
+
+    def counters_reset(self):
+        self._ck(self._L.mg_counters_reset(self.h))
+
+    # per-variant path
+    def lookup_cover(self, rows, is_ref, sig_kmer_off, allele_sig_off):
+        so = np.ascontiguousarray(sig_kmer_off, dtype=np.uint64)
+        ao = np.ascontiguousarray(allele_sig_off, dtype=np.uint64)
+        n_alleles, n_sigs = len(ao) - 1, len(so) - 1
+        cov = np.zeros(n_alleles, dtype=np.uint32)
+        if isinstance(rows, (list, tuple)) and len(rows) == 0:
+            rows = np.zeros((0, 8), dtype=np.uint8)
+        rows = _rows(rows)
+        is_ref = np.ascontiguousarray(is_ref, dtype=np.uint8)
+        self._ck(self._L.mg_lookup_cover(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(is_ref), _p(so), n_sigs,
+                                         _p(ao), n_alleles, _p(cov)))
+        return cov
+
+    def genotype(self, cov, freq, var_allele_off, error_rate, max_cov, haploid, want_probs=False):
+        cov = np.ascontiguousarray(cov, dtype=np.uint32)
+        freq = np.ascontiguousarray(freq, dtype=np.float32)
+        vo = np.ascontiguousarray(var_allele_off, dtype=np.uint32)
+        n = len(vo) - 1
+        g1 = np.zeros(n, dtype=np.int32)
+        g2 = np.zeros(n, dtype=np.int32)
+        gq = np.zeros(n, dtype=np.int32)
+        st = np.zeros(n, dtype=np.uint8)
+        probs = goff = None
+        if want_probs:
+            A = np.diff(vo.astype(np.int64))
+            ng = A if haploid else A * (A + 1) // 2
+            goff = np.zeros(n + 1, dtype=np.uint64)
+            goff[1:] = np.cumsum(ng)
+            probs = np.zeros(int(goff[-1]), dtype=np.float64)
+        self._ck(self._L.mg_genotype(self.h, _p(cov), _p(freq), _p(vo), n, C.c_float(error_rate), max_cov, int(haploid),
+                                     _p(g1), _p(g2), _p(gq), _p(st), _p(probs), _p(goff)))
+        return g1, g2, gq, st, probs, goff
+
+    def reference_upload(self, ascii_bytes):
+        buf = np.frombuffer(ascii_bytes, dtype=np.uint8) if isinstance(ascii_bytes, (bytes, bytearray)) else ascii_bytes
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._ck(self._L.mg_reference_upload(self.h, _p(buf), buf.size))
+
+    def call_isolated(self, pos, var_allele_off, allele_off, allele_pool, freq, present_mask, flags, error_rate,
+                      max_cov, haploid):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        vo = np.ascontiguousarray(var_allele_off, dtype=np.uint32)
+        ao = np.ascontiguousarray(allele_off, dtype=np.uint32)
+        pool = np.frombuffer(allele_pool, dtype=np.uint8) if isinstance(allele_pool, (bytes, bytearray)) else allele_pool
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        freq = np.ascontiguousarray(freq, dtype=np.float32)
+        pm = np.ascontiguousarray(present_mask, dtype=np.uint64)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        n, na = len(pos), int(vo[-1])
+        cov = np.zeros(na, dtype=np.uint32)
+        g1 = np.zeros(n, dtype=np.int32)
+        g2 = np.zeros(n, dtype=np.int32)
+        gq = np.zeros(n, dtype=np.int32)
+        st = np.zeros(n, dtype=np.uint8)
+        self._ck(self._L.mg_call_isolated(self.h, n, _p(pos), _p(vo), _p(ao), _p(pool), pool.size, _p(freq), _p(pm),
+                                          _p(fl), C.c_float(error_rate), max_cov, int(haploid), _p(cov), _p(g1), _p(g2),
+                                          _p(gq), _p(st)))
+        return cov, g1, g2, gq, st
+
+    def call_isolated_device(self, n, d_pos, d_vo, d_ao, d_pool, d_freq, d_pm, d_flags, error_rate, max_cov, haploid,
+                             d_cov, d_g1, d_g2, d_gq, d_st):
+        v = C.c_void_p
+        self._ck(self._L.mg_call_isolated_device(self.h, n, v(d_pos), v(d_vo), v(d_ao), v(d_pool), v(d_freq), v(d_pm),
+                                                 v(d_flags), C.c_float(error_rate), max_cov, int(haploid), v(d_cov),
+                                                 v(d_g1), v(d_g2), v(d_gq), v(d_st)))

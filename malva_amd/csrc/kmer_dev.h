@@ -1,0 +1,215 @@
+// Device-side k-mer primitives: the RCN complement table and canonical form of
+// the reference (bloom_filter.hpp:36-65, kmap.hpp:86-97) for ASCII text, the same
+// on 2-bit packed ACGT strings, hash -> slot reduction, and read-only views of
+// the two stores (Bloom filter + rank directory, exact map).
+#pragma once
+#include "xxh3_dev.h"
+
+namespace mg {
+
+typedef int32_t i32;
+
+// ---- ASCII ------------------------------------------------------------------
+
+// RCN[128] of bloom_filter.hpp:36-50; every byte not listed (and every byte
+// >= 128, which the reference would index out of bounds) complements to 0.
+__device__ __forceinline__ u32 rcn(u32 c)
+{
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'N': return 'N';
+    case 'a': return 'T';
+    case 'c': return 'G';
+    case 'g': return 'G'; // sic (table index 103)
+    case 't': return 'A';
+    case 'n': return 'N';
+    default: return 0;
+    }
+}
+
+// A k-mer seen through a byte accessor IN(i), i in [0,k), oriented as
+// BF::_canonical leaves it: strcmp(kmer, rc) < 0 ? kmer : rc.  A NUL in rc ends
+// strcmp's walk with kmer's byte greater, so rc is kept.
+template <class IN> struct CanonBytes {
+    IN in;
+    int k;
+    bool fwd;
+    __device__ __forceinline__ CanonBytes(IN in_, int k_) : in(in_), k(k_), fwd(false)
+    {
+        for (int i = 0; i < k; ++i) {
+            const u32 a = in(i), b = rcn(in(k - 1 - i));
+            if (a != b) {
+                fwd = a < b;
+                break;
+            }
+        }
+    }
+    __device__ __forceinline__ u32 operator()(int i) const { return fwd ? in(i) : rcn(in(k - 1 - i)); }
+};
+
+// 2-bit code of an upper-case base, 4 for anything else
+__device__ __forceinline__ u32 code_of(u32 c)
+{
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+// ---- packed -----------------------------------------------------------------
+// Two layouts of a string of n <= 64 bases in a 128-bit value (hi:lo):
+//   M-form: base i at bits 2(n-1-i)   (MSB-first, right aligned: the ABI's table format)
+//   L-form: base i at bits 2i         (LSB-first: byte order of the ASCII rendering)
+// For a k-mer x with reverse complement rc:  L(rc) = ~M(x) & mask, and
+// strcmp(x, rc) < 0  <=>  L(x) < L(rc) as integers, so the canonical string is the
+// integer minimum of the two L-forms.
+
+struct U128 {
+    u64 lo, hi;
+};
+
+__device__ __forceinline__ u64 pairrev64(u64 x)
+{
+    const u64 r = __brevll(x);
+    return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+}
+__device__ __forceinline__ U128 shr128(U128 v, int s) // 0 <= s < 128
+{
+    U128 r;
+    if (s == 0) return v;
+    if (s < 64) {
+        r.lo = (v.lo >> s) | (v.hi << (64 - s));
+        r.hi = v.hi >> s;
+    } else {
+        r.lo = v.hi >> (s - 64);
+        r.hi = 0;
+    }
+    return r;
+}
+__device__ __forceinline__ U128 mask128(int bits) // 0 < bits <= 128
+{
+    U128 m;
+    m.lo = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1);
+    m.hi = bits >= 128 ? ~0ULL : (bits > 64 ? ((1ULL << (bits - 64)) - 1) : 0);
+    return m;
+}
+__device__ __forceinline__ bool lt128(U128 a, U128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+// L-form of the forward string from its M-form (n bases)
+__device__ __forceinline__ U128 mform_to_lform(U128 m, int n)
+{
+    U128 r;
+    r.lo = pairrev64(m.hi);
+    r.hi = pairrev64(m.lo);
+    return shr128(r, 2 * (64 - n));
+}
+// canonical L-form of the sub-string [off, off+k) of an n-base string given both forms
+__device__ __forceinline__ U128 canon_sub(U128 mform, U128 lform, int n, int off, int k)
+{
+    const U128 mk = mask128(2 * k);
+    U128 f = shr128(lform, 2 * off);
+    f.lo &= mk.lo;
+    f.hi &= mk.hi;
+    U128 m = shr128(mform, 2 * (n - k - off));
+    U128 r;
+    r.lo = ~m.lo & mk.lo;
+    r.hi = ~m.hi & mk.hi;
+    return lt128(f, r) ? f : r;
+}
+__device__ __forceinline__ u64 xxh3_packed(U128 c, int len)
+{
+    return len > 32 ? xxh3_packed_33to64(c.lo, c.hi, len) : xxh3_packed_17to32(c.lo, c.hi, len);
+}
+
+// ---- hash -> bit index (hash % _size, bloom_filter.hpp:84) --------------------
+// size = odd * 2^shift.  x mod size = ((x >> shift) mod odd) << shift | (x & (2^shift - 1)).
+struct ModDesc {
+    u64 size;
+    u64 odd;
+    u32 shift;
+    u32 kind; // 0: power of two, 1: (x >> shift) and odd fit 32 bits, 2: generic
+};
+__device__ __forceinline__ u64 mod_size(u64 h, const ModDesc &m)
+{
+    if (m.kind == 0) return h & (m.size - 1);
+    if (m.kind == 1) {
+        const u32 q = (u32)(h >> m.shift) % (u32)m.odd;
+        return ((u64)q << m.shift) | (h & ((1ULL << m.shift) - 1));
+    }
+    return h % m.size;
+}
+
+// ---- Bloom filter view ---------------------------------------------------------
+struct BFView {
+    u64 *words;        // size bits
+    const u32 *blk;    // ones before each 512-bit block (valid once finalised)
+    u32 *counts;       // one wrapping u32 per set bit; the u16 cell of the reference is its low half
+    const u64 *summary; // bit j = any bit set in [j << sum_shift, (j+1) << sum_shift)
+    ModDesc mod;
+    u32 sum_shift;
+    u32 use_summary;
+};
+__device__ __forceinline__ bool bf_bit(const BFView &b, u64 idx) { return (b.words[idx >> 6] >> (idx & 63)) & 1; }
+__device__ __forceinline__ bool bf_maybe(const BFView &b, u64 idx)
+{
+    if (!b.use_summary) return true;
+    const u64 j = idx >> b.sum_shift;
+    return (b.summary[j >> 6] >> (j & 63)) & 1;
+}
+// rank(idx) = ones in [0, idx)   (rank_support_v<1>, bloom_filter.hpp:108)
+__device__ __forceinline__ u32 bf_rank(const BFView &b, u64 idx)
+{
+    const u64 blk = idx >> 9, we = idx >> 6;
+    u32 r = b.blk[blk];
+    for (u64 w = blk * 8; w < we; ++w) r += (u32)__popcll(b.words[w]);
+    if (idx & 63) r += (u32)__popcll(b.words[we] & ((1ULL << (idx & 63)) - 1));
+    return r;
+}
+
+// ---- exact map view --------------------------------------------------------------
+// Open addressing, linear probing, power-of-two capacity.  tags: 0 empty, 1 being
+// written, >= 2 fingerprint of a published key.  Keys are canonical L-forms.
+// ids[slot] = smallest insertion row that carried the key; vals[id] is its counter,
+// so the counter vector has the same layout on every GPU that replays the inserts.
+struct MapView {
+    u32 *tags;
+    u64 *klo;
+    u64 *khi;
+    u32 *ids;
+    u32 *vals;
+    const u64 *summary; // bit (h >> (64 - sum_log2)) set for every stored key
+    u32 cap_log2;
+    u32 sum_log2;
+    u32 use_summary;
+};
+__device__ __forceinline__ u64 map_hash(U128 key)
+{
+    u64 h = key.lo ^ (key.hi * 0x9E3779B97F4A7C15ULL);
+    h *= 0xD6E8FEB86659FD93ULL;
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ULL;
+    h ^= h >> 32;
+    return h;
+}
+__device__ __forceinline__ u32 map_tag(u64 h) { return (u32)h | 0x80000000u; }
+__device__ __forceinline__ bool map_maybe(const MapView &m, u64 h)
+{
+    if (!m.use_summary) return true;
+    const u64 j = h >> (64 - m.sum_log2);
+    return (m.summary[j >> 6] >> (j & 63)) & 1;
+}
+// slot of a published key, or -1
+__device__ __forceinline__ long long map_find(const MapView &m, U128 key, u64 h)
+{
+    const u64 mask = (1ULL << m.cap_log2) - 1;
+    u64 s = h >> (64 - m.cap_log2);
+    const u32 tag = map_tag(h);
+    for (;;) {
+        const u32 t = m.tags[s];
+        if (t == 0) return -1;
+        if (t == tag && m.klo[s] == key.lo && m.khi[s] == key.hi) return (long long)s;
+        s = (s + 1) & mask;
+    }
+}
+
+} // namespace mg

@@ -1,0 +1,1499 @@
+// malva_hip.hip -- kernels and C ABI of the MI355X-native malva-geno hot path.
+// See include/malva_hip.h for the interface and the reference lines each entry
+// point replaces; DESIGN.md for the data layout and the roofline of each kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "geno_dev.h"
+#include "malva_hip.h"
+
+using namespace mg;
+
+#define MG_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ---- ASCII rows -------------------------------------------------------------
+
+struct RowIn {
+    const u8 *p;
+    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
+};
+__device__ __forceinline__ int row_len(const u8 *row, int stride)
+{
+    const int lim = stride < MG_MAX_KMER + 1 ? stride : MG_MAX_KMER + 1;
+    int n = 0;
+    while (n < lim && row[n]) ++n;
+    return n;
+}
+
+// canonical form of an ASCII k-mer as the exact map keys it: regular (pure
+// upper-case ACGT, no NUL => never truncated) keys pack to an L-form;
+// anything else is "irregular" and is kept by the host-side overflow list.
+template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, int k, U128 *out)
+{
+    U128 v{0, 0};
+    if (k > MG_MAX_PACKED_K) return false;
+    for (int i = 0; i < k; ++i) {
+        const u32 code = code_of(c(i));
+        if (code > 3) return false;
+        if (i < 32) v.lo |= (u64)code << (2 * i);
+        else v.hi |= (u64)code << (2 * (i - 32));
+    }
+    *out = v;
+    return true;
+}
+
+enum RowOp { OP_BF_INSERT, OP_BF_TEST, OP_BF_INC, OP_BF_GET, OP_BF_INDEX, OP_MAP_TEST, OP_MAP_INC, OP_MAP_GET, OP_WEIGHT };
+
+// One thread per row.  H4/H5/H7/H8 (bloom_filter.hpp:81-125) and H9
+// (kmap.hpp:99-131) in batch form, plus the mixed lookup of set_coverages
+// (main.cpp:166-170).  out type depends on the op.
+template <int OP>
+__global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride, size_t n, BFView bf, MapView map,
+                                                   const u32 *counters, const u8 *is_ref, void *out, u8 *irregular)
+{
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u8 *row = rows + i * stride;
+    const int k = row_len(row, (int)stride);
+    CanonBytes<RowIn> can(RowIn{row}, k);
+    bool want_map = OP == OP_MAP_TEST || OP == OP_MAP_INC || OP == OP_MAP_GET;
+    if (OP == OP_WEIGHT) want_map = is_ref[i] != 0;
+    if (want_map) {
+        U128 key;
+        long long s = -1;
+        const bool regular = pack_regular(can, k, &key);
+        if (regular) s = map_find(map, key, map_hash(key));
+        if (irregular) irregular[i] = regular ? 0 : 1;
+        if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
+        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.ids[s]], counters[i]);
+        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.ids[s]] : 0;
+        return;
+    }
+    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
+    if (OP == OP_BF_INDEX) ((u64 *)out)[i] = idx;
+    if (OP == OP_BF_INSERT) atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
+    if (OP == OP_BF_TEST) ((u8 *)out)[i] = bf_bit(bf, idx);
+    if (OP == OP_BF_INC) {
+        if (bf_bit(bf, idx)) atomicAdd(&bf.counts[bf_rank(bf, idx)], counters[i]);
+    }
+    if (OP == OP_BF_GET) ((uint16_t *)out)[i] = bf.counts && bf_bit(bf, idx) ? (uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+    if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts && bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+}
+
+// KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows
+// inserted by earlier calls (ids are global insertion rows).
+__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, u32 row0,
+                                                         u8 *irregular)
+{
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u8 *row = rows + i * stride;
+    const int k = row_len(row, (int)stride);
+    CanonBytes<RowIn> can(RowIn{row}, k);
+    U128 key;
+    const bool regular = pack_regular(can, k, &key);
+    irregular[i] = regular ? 0 : 1;
+    if (!regular) return;
+    const u64 h = map_hash(key);
+    const u32 tag = map_tag(h);
+    const u64 mask = (1ULL << map.cap_log2) - 1;
+    u64 s = h >> (64 - map.cap_log2);
+    const u32 my_id = row0 + (u32)i;
+    bool done = false;
+    // every lane retries inside one common loop, so a lane that owns a slot in
+    // the "being written" state always finishes its publish before anyone spins on it
+    for (int guard = 0; !done && guard < (1 << 30); ++guard) {
+        u32 t = __hip_atomic_load(&map.tags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            t = atomicCAS(&map.tags[s], 0u, 1u);
+            if (t == 0) {
+                map.klo[s] = key.lo;
+                map.khi[s] = key.hi;
+                atomicMin(&map.ids[s], my_id);
+                __threadfence();
+                __hip_atomic_store(&map.tags[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 j = h >> (64 - map.sum_log2);
+                atomicOr((unsigned long long *)&map.summary[j >> 6], 1ULL << (j & 63));
+                done = true;
+                continue;
+            }
+        }
+        if (t == 1) continue; // owner is publishing: look again
+        if (t == tag) {
+            __threadfence();
+            const u64 a = __hip_atomic_load(&map.klo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 b = __hip_atomic_load(&map.khi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a == key.lo && b == key.hi) {
+                const u32 old = atomicMin(&map.ids[s], my_id);
+                if (old < row0) map.vals[old] = 0; // kmers[ckmer] = 0 on a key from an earlier call
+                done = true;
+                continue;
+            }
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+// move every published entry of an old table into a new (larger, empty) one
+__global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm)
+{
+    const u64 s0 = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s0 >= (1ULL << oldm.cap_log2)) return;
+    if (oldm.tags[s0] < 2) return;
+    U128 key{oldm.klo[s0], oldm.khi[s0]};
+    const u64 h = map_hash(key);
+    const u64 mask = (1ULL << newm.cap_log2) - 1;
+    u64 s = h >> (64 - newm.cap_log2);
+    while (atomicCAS(&newm.tags[s], 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
+    newm.klo[s] = key.lo;
+    newm.khi[s] = key.hi;
+    newm.ids[s] = oldm.ids[s0];
+    const u64 j = h >> (64 - newm.sum_log2);
+    atomicOr((unsigned long long *)&newm.summary[j >> 6], 1ULL << (j & 63));
+}
+
+// list of published (key, id) for export
+__global__ void __launch_bounds__(TPB) map_dump_kernel(MapView m, u64 *klo, u64 *khi, u32 *ids, unsigned long long *count)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s >= (1ULL << m.cap_log2) || m.tags[s] < 2) return;
+    const unsigned long long j = atomicAdd(count, 1ULL);
+    klo[j] = m.klo[s];
+    khi[j] = m.khi[s];
+    ids[j] = m.ids[s];
+}
+
+// ---- finalize: rank directory, counters, summary ---------------------------
+
+// per 512-bit block popcount, exclusive scan inside a tile of TPB blocks
+__global__ void __launch_bounds__(TPB) blk_pop_kernel(const u64 *words, u64 nwords, u64 n_blk, u32 *blk, u32 *tile_sums)
+{
+    __shared__ u32 sh[TPB];
+    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
+    u32 pop = 0;
+    if (b < n_blk) {
+        const u64 w0 = b * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w0 + j < nwords) pop += (u32)__popcll(words[w0 + j]);
+    }
+    sh[threadIdx.x] = pop;
+    __syncthreads();
+    for (int d = 1; d < TPB; d <<= 1) {
+        const u32 v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (b < n_blk) blk[b] = sh[threadIdx.x] - pop;
+    if (threadIdx.x == TPB - 1) tile_sums[blockIdx.x] = sh[TPB - 1];
+}
+// single workgroup: exclusive scan of tile sums in place; total to *total (u64)
+__global__ void __launch_bounds__(1024) tile_scan_kernel(u32 *tile_sums, u64 n_tiles, unsigned long long *total)
+{
+    __shared__ unsigned long long sh[1024];
+    const u64 per = (n_tiles + 1023) / 1024;
+    const u64 lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    unsigned long long s = 0;
+    for (u64 i = lo; i < hi; ++i) s += tile_sums[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = sh[threadIdx.x] - s;
+    for (u64 i = lo; i < hi; ++i) {
+        const u32 v = tile_sums[i];
+        tile_sums[i] = (u32)run; // valid while the grand total fits 32 bits (checked by the host)
+        run += v;
+    }
+    if (threadIdx.x == 1023) *total = sh[1023];
+}
+__global__ void __launch_bounds__(TPB) blk_add_kernel(u32 *blk, u64 n_blk, const u32 *tile_sums, u32 total)
+{
+    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (b < n_blk) blk[b] += tile_sums[blockIdx.x];
+    if (b == n_blk) blk[b] = total; // rank(size) (bloom_filter.hpp:97)
+}
+// summary bit j = any bit in words [j << (S-6), (j+1) << (S-6)); one wave builds one u64
+__global__ void __launch_bounds__(TPB) summary_kernel(const u64 *words, u64 nwords, u64 *summary, u64 n_sum_bits, u32 sum_shift)
+{
+    const u64 j = (u64)blockIdx.x * TPB + threadIdx.x;
+    bool any = false;
+    if (j < n_sum_bits) {
+        const u64 per = 1ULL << (sum_shift - 6);
+        const u64 w0 = j * per;
+        for (u64 w = w0; w < w0 + per && w < nwords; ++w) any |= words[w] != 0;
+    }
+    const u64 m = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && (j >> 6) < ((n_sum_bits + 63) >> 6)) summary[j >> 6] = m;
+}
+__global__ void __launch_bounds__(TPB) mask_u16_kernel(const u32 *in, uint16_t *out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = (uint16_t)in[i];
+}
+__global__ void __launch_bounds__(TPB) widen_u16_kernel(const uint16_t *in, u32 *out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// ---- H11: reference-context scan (main.cpp:383-401) --------------------------
+// One thread per window start p; the workgroup stages its TPB + ref_k - 1 bytes
+// of the contig through LDS once.  Windows are full length (contigs shorter
+// than ref_k are handled by the host wrapper with the row kernels).
+struct LdsIn {
+    const u8 *p;
+    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
+};
+__global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 n_windows, int k, int ref_k, BFView bf,
+                                                       BFView ctx)
+{
+    __shared__ u8 sh[TPB + MG_MAX_KMER];
+    const u64 p0 = (u64)blockIdx.x * TPB;
+    const u64 avail = n_windows - p0 < TPB ? n_windows - p0 : TPB;
+    const int nbytes = (int)avail + ref_k - 1;
+    for (int i = threadIdx.x; i < nbytes; i += TPB) sh[i] = contig[p0 + i];
+    __syncthreads();
+    if (threadIdx.x >= avail) return;
+    const int off = (ref_k - k) / 2;
+    CanonBytes<LdsIn> ck(LdsIn{sh + threadIdx.x + off}, k);
+    const u64 idx = mod_size(xxh3_bytes(ck, k), bf.mod);
+    if (!bf_maybe(bf, idx) || !bf_bit(bf, idx)) return;
+    CanonBytes<LdsIn> cc(LdsIn{sh + threadIdx.x}, ref_k);
+    const u64 cidx = mod_size(xxh3_bytes(cc, ref_k), ctx.mod);
+    atomicOr((unsigned long long *)&ctx.words[cidx >> 6], 1ULL << (cidx & 63));
+}
+
+// ---- H10: KMC scan (main.cpp:482-500) -----------------------------------------
+// Filter kernel: one thread per table row.  Canonicalise the centre k-mer once,
+// probe the exact map (ref_bf.increment), hash it and test `bf`.  Rows whose bf
+// bit is set are rare; they are compacted into a hit list and finished by
+// scan_hits_kernel, so the ref_k-mer hash and the rank walk run at full lane
+// occupancy instead of dragging every wave through them.
+// Order of operations vs the reference: `bf.increment` is a no-op unless the bf
+// bit is set, so testing bf first and context_bf second gives identical counters.
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
+                                                          const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt,
+                                                          BFView bf, MapView map, u32 *hit_row, u64 *hit_idx,
+                                                          unsigned long long *hit_count)
+{
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const u64 stride = (u64)gridDim.x * TPB;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n + ((0 - n) & 63); i += stride) {
+        bool hit = false;
+        u64 idx = 0;
+        if (i < n) {
+            const U128 m{lo[i], hi[i]};
+            const U128 l = mform_to_lform(m, r);
+            const U128 c = canon_sub(m, l, r, off, k);
+            const u64 hm = map_hash(c);
+            if (map_maybe(map, hm)) {
+                const long long s = map_find(map, c, hm);
+                if (s >= 0) atomicAdd(&map.vals[map.ids[s]], cnt[i]);
+            }
+            idx = mod_size(xxh3_packed(c, k), bf.mod);
+            hit = bf_maybe(bf, idx) && bf_bit(bf, idx);
+        }
+        const u64 mask = __ballot(hit);
+        if (mask) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == __ffsll((unsigned long long)mask) - 1) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
+            base = __shfl(base, __ffsll((unsigned long long)mask) - 1, 64);
+            if (hit) {
+                const u64 j = base + __popcll(mask & ((1ULL << lane) - 1));
+                hit_row[j] = (u32)i;
+                hit_idx[j] = idx;
+            }
+        }
+    }
+}
+// Hit kernel: dense over the compacted rows.  context_bf.test_key on the ref_k-mer,
+// then bf.increment's rank + counter add.
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_hits_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
+                                                        const u32 *__restrict__ cnt, int r_rt, BFView bf, BFView ctx,
+                                                        const u32 *hit_row, const u64 *hit_idx,
+                                                        unsigned long long *hit_count)
+{
+    const int r = RC > 0 ? RC : r_rt;
+    const u64 nh = hit_count[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) hit_count[1] += nh; // running total of the whole scan call
+    for (u64 j = (u64)blockIdx.x * TPB + threadIdx.x; j < nh; j += (u64)gridDim.x * TPB) {
+        const u32 row = hit_row[j];
+        const U128 m{lo[row], hi[row]};
+        const U128 l = mform_to_lform(m, r);
+        const U128 c = canon_sub(m, l, r, 0, r);
+        const u64 cidx = mod_size(xxh3_packed(c, r), ctx.mod);
+        if (bf_bit(ctx, cidx)) continue;
+        atomicAdd(&bf.counts[bf_rank(bf, hit_idx[j])], cnt[row]);
+    }
+}
+
+// debug: hash % size of packed k-mers (M-form, klen bases)
+__global__ void __launch_bounds__(TPB) packed_index_kernel(const u64 *hi, const u64 *lo, u64 n, int klen, ModDesc mod,
+                                                           u64 *out)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const U128 m{lo[i], hi[i]};
+    const U128 l = mform_to_lform(m, klen);
+    const U128 c = canon_sub(m, l, klen, 0, klen);
+    out[i] = mod_size(xxh3_packed(c, klen), mod);
+}
+
+// ---- V1: coverage reduction (main.cpp:159-181) -----------------------------------
+__global__ void __launch_bounds__(TPB) cover_kernel(const i32 *w, const u64 *sig_kmer_off, const u64 *allele_sig_off,
+                                                    u64 n_alleles, u32 *cov)
+{
+    const u64 a = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (a >= n_alleles) return;
+    u32 allele_cov = 0;
+    for (u64 s = allele_sig_off[a]; s < allele_sig_off[a + 1]; ++s) {
+        u32 curr = 0;
+        i32 n = 0;
+        for (u64 j = sig_kmer_off[s]; j < sig_kmer_off[s + 1]; ++j) {
+            const i32 wt = w[j];
+            if (wt > 0) {
+                curr = (curr * (u32)n + (u32)wt) / (u32)(n + 1);
+                ++n;
+            }
+        }
+        if (curr > allele_cov) allele_cov = curr;
+    }
+    cov[a] = (u32)(float)allele_cov; // through the float parameter of set_variant_coverage (var_block.hpp:84)
+}
+
+// ---- G1-G3 ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) genotype_kernel(const u32 *cov, const float *freq, const u32 *var_allele_off,
+                                                       u64 n_vars, GenoParams p, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
+                                                       double *probs, const u64 *var_gt_off)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    genotype_one(cov + a0, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v,
+                 probs ? probs + var_gt_off[v] : nullptr);
+}
+
+// ---- fused isolated-variant path ---------------------------------------------------
+// The signature k-mer of allele a of a lone variant (var_block.hpp:145-200 with
+// comb = {v}):  ref[pos-mp, pos) + allele + ref[pos+ref_size, +ms),
+// mp = k/2 - len/2,  ms = ceil(k/2) - (len - len/2).
+struct SigIn {
+    const u8 *ref_left;  // reference + pos - mp
+    const u8 *allele;
+    const u8 *ref_right; // reference + pos + ref_size
+    int mp, alen;
+    __device__ __forceinline__ u32 operator()(int i) const
+    {
+        return i < mp ? ref_left[i] : (i < mp + alen ? allele[i - mp] : ref_right[i - mp - alen]);
+    }
+};
+__global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference, u64 n_vars, const u64 *pos,
+                                                            const u32 *var_allele_off, const u32 *allele_off,
+                                                            const u8 *pool, const float *freq, const u64 *present_mask,
+                                                            const u8 *flags, int k, BFView bf, MapView map, GenoParams p,
+                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
+    u32 *cov = cov_out + a0;
+    for (u32 a = 0; a < A; ++a) cov[a] = 0;
+    if (flags[v] & 1) {
+        const u64 pm = present_mask[v];
+        for (u32 a = 0; a < A && a < 64; ++a) {
+            if (!((pm >> a) & 1)) continue;
+            const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
+            const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
+            if (mp < 0 || ms < 0) continue; // alleles >= k take the general path (host contract)
+            SigIn in{reference + pos[v] - mp, pool + allele_off[a0 + a], reference + pos[v] + ref_size, mp, alen};
+            CanonBytes<SigIn> can(in, k);
+            i32 w = 0;
+            if (a == 0) {
+                U128 key;
+                if (pack_regular(can, k, &key)) {
+                    const long long s = map_find(map, key, map_hash(key));
+                    if (s >= 0) w = (i32)map.vals[map.ids[s]];
+                }
+            } else {
+                const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
+                if (bf_bit(bf, idx)) w = (i32)(uint16_t)bf.counts[bf_rank(bf, idx)];
+            }
+            if (w > 0) cov[a] = (u32)(float)(u32)w;
+        }
+    }
+    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, nullptr);
+}
+
+} // namespace
+
+// ===========================================================================
+// Host side: context, memory, launches
+// ===========================================================================
+
+struct BFState {
+    u64 size = 0, nwords = 0, n_blk = 0, nset = 0;
+    u64 *words = nullptr;
+    u32 *blk = nullptr;
+    u32 *counts = nullptr;
+    u64 *summary = nullptr;
+    u64 n_sum_bits = 0;
+    u32 sum_shift = 6;
+    int mode = 0;
+    ModDesc mod{};
+};
+struct MapState {
+    u32 cap_log2 = 0, sum_log2 = 0;
+    u32 *tags = nullptr;
+    u64 *klo = nullptr, *khi = nullptr;
+    u32 *ids = nullptr;
+    u32 *vals = nullptr;
+    u64 *summary = nullptr;
+    u64 rows_total = 0; // insertion rows so far (upper bound on distinct keys; ids index space)
+    u64 vals_cap = 0;
+    std::unordered_map<std::string, int32_t> irregular; // keys the packed table cannot hold (N / NUL-truncated)
+};
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct mg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    u32 k = 0, ref_k = 0;
+    BFState bf[2];
+    MapState map;
+    Scratch s_rows, s_aux, s_out, s_irr, s_hitrow, s_hitidx, s_misc[8];
+    unsigned long long *d_hit_count = nullptr;
+    double *d_ln = nullptr;
+    float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
+    float eps_for = -1.f;
+    u8 *d_ref = nullptr;
+    size_t ref_len = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool stats_valid = false;
+    int use_summary = 1;
+    int bf_sum_log2 = 23, map_sum_log2 = 23;
+    std::string err;
+};
+
+namespace {
+
+int fail(mg_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                                             \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess)                                                                                        \
+            return fail(c, e_ == hipErrorOutOfMemory ? MG_ERR_NOMEM : MG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != MG_OK) return rc_; \
+    } while (0)
+
+inline unsigned nblocks(u64 n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+int scratch(mg_ctx *c, Scratch &s, size_t bytes, void **out)
+{
+    if (bytes > s.cap) {
+        if (s.p) HIP_TRY(c, hipFree(s.p));
+        s.p = nullptr;
+        s.cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIP_TRY(c, hipMalloc(&s.p, want));
+        s.cap = want;
+    }
+    *out = s.p;
+    return MG_OK;
+}
+int upload(mg_ctx *c, Scratch &s, const void *host, size_t bytes, void **dev)
+{
+    TRY(scratch(c, s, bytes ? bytes : 1, dev));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return MG_OK;
+}
+
+ModDesc make_mod(u64 size)
+{
+    ModDesc m{};
+    m.size = size;
+    u32 sh = 0;
+    u64 odd = size;
+    while (odd && !(odd & 1)) {
+        odd >>= 1;
+        ++sh;
+    }
+    m.shift = sh;
+    m.odd = odd;
+    if (odd == 1) m.kind = 0;
+    else if (odd < (1ULL << 32) && sh >= 32) m.kind = 1;
+    else m.kind = 2;
+    return m;
+}
+
+BFView view(const mg_ctx *c, int which)
+{
+    const BFState &b = c->bf[which];
+    BFView v{};
+    v.words = b.words;
+    v.blk = b.blk;
+    v.counts = b.counts;
+    v.summary = b.summary;
+    v.mod = b.mod;
+    v.sum_shift = b.sum_shift;
+    v.use_summary = (c->use_summary && b.summary && b.mode) ? 1 : 0;
+    return v;
+}
+MapView view(const mg_ctx *c)
+{
+    const MapState &m = c->map;
+    MapView v{};
+    v.tags = m.tags;
+    v.klo = m.klo;
+    v.khi = m.khi;
+    v.ids = m.ids;
+    v.vals = m.vals;
+    v.summary = m.summary;
+    v.cap_log2 = m.cap_log2;
+    v.sum_log2 = m.sum_log2;
+    v.use_summary = c->use_summary ? 1 : 0;
+    return v;
+}
+
+int map_alloc(mg_ctx *c, MapState &m, u32 cap_log2)
+{
+    const u64 cap = 1ULL << cap_log2;
+    m.cap_log2 = cap_log2;
+    u32 sl = cap_log2 + 2;
+    if (sl > (u32)c->map_sum_log2) sl = (u32)c->map_sum_log2;
+    if (sl < 6) sl = 6;
+    m.sum_log2 = sl;
+    HIP_TRY(c, hipMalloc(&m.tags, cap * 4));
+    HIP_TRY(c, hipMalloc(&m.klo, cap * 8));
+    HIP_TRY(c, hipMalloc(&m.khi, cap * 8));
+    HIP_TRY(c, hipMalloc(&m.ids, cap * 4));
+    HIP_TRY(c, hipMalloc(&m.summary, (1ULL << sl) / 8));
+    HIP_TRY(c, hipMemsetAsync(m.tags, 0, cap * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(m.ids, 0xFF, cap * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(m.summary, 0, (1ULL << sl) / 8, c->stream));
+    return MG_OK;
+}
+void map_free_table(MapState &m)
+{
+    hipFree(m.tags);
+    hipFree(m.klo);
+    hipFree(m.khi);
+    hipFree(m.ids);
+    hipFree(m.summary);
+    m.tags = nullptr;
+    m.klo = m.khi = nullptr;
+    m.ids = nullptr;
+    m.summary = nullptr;
+}
+// make room for `extra` more insertion rows: table load <= 1/4, vals indexable by row
+int map_reserve(mg_ctx *c, u64 extra)
+{
+    MapState &m = c->map;
+    const u64 need_rows = m.rows_total + extra;
+    if (need_rows >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "exact map: more than 2^32-1 insertion rows");
+    if (need_rows > m.vals_cap) {
+        u64 ncap = need_rows + need_rows / 2 + 1024;
+        u32 *nv = nullptr;
+        HIP_TRY(c, hipMalloc(&nv, ncap * 4));
+        HIP_TRY(c, hipMemsetAsync(nv, 0, ncap * 4, c->stream));
+        if (m.vals && m.rows_total)
+            HIP_TRY(c, hipMemcpyAsync(nv, m.vals, m.rows_total * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (m.vals) hipFree(m.vals);
+        m.vals = nv;
+        m.vals_cap = ncap;
+    }
+    u32 want = 10;
+    while ((1ULL << want) < need_rows * 4) ++want;
+    if (!m.tags) return map_alloc(c, m, want);
+    if (want > m.cap_log2) {
+        MapState old = m; // shallow copy of pointers
+        m.tags = nullptr;
+        TRY(map_alloc(c, m, want));
+        MapView ov{};
+        ov.tags = old.tags; ov.klo = old.klo; ov.khi = old.khi; ov.ids = old.ids; ov.cap_log2 = old.cap_log2;
+        ov.sum_log2 = old.sum_log2;
+        MapView nv = view(c);
+        hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << old.cap_log2)), dim3(TPB), 0, c->stream, ov, nv);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(old.tags);
+        hipFree(old.klo);
+        hipFree(old.khi);
+        hipFree(old.ids);
+        hipFree(old.summary);
+    }
+    return MG_OK;
+}
+
+int check_rows(mg_ctx *c, const void *rows, size_t stride, size_t n)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n && !rows) return fail(c, MG_ERR_ARG, "rows is NULL");
+    if (stride < 2) return fail(c, MG_ERR_ARG, "row stride %zu too small", stride);
+    return MG_OK;
+}
+int check_which(mg_ctx *c, int which)
+{
+    if (!c) return MG_ERR_ARG;
+    if (which != MG_BF_ALT && which != MG_BF_CTX) return fail(c, MG_ERR_ARG, "which must be MG_BF_ALT or MG_BF_CTX");
+    return MG_OK;
+}
+
+template <int OP>
+int run_rows(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, const void *counters, const u8 *is_ref,
+             void *host_out, size_t out_elem, u8 *host_irregular)
+{
+    if (n == 0) return MG_OK;
+    void *d_rows, *d_cnt = nullptr, *d_isref = nullptr, *d_out = nullptr, *d_irr = nullptr;
+    TRY(upload(c, c->s_rows, rows, stride * n, &d_rows));
+    if (counters) TRY(upload(c, c->s_aux, counters, 4 * n, &d_cnt));
+    if (is_ref) TRY(upload(c, c->s_misc[0], is_ref, n, &d_isref));
+    if (host_out) TRY(scratch(c, c->s_out, out_elem * n, &d_out));
+    if (host_irregular) TRY(scratch(c, c->s_irr, n, &d_irr));
+    hipLaunchKernelGGL(rows_kernel<OP>, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u8 *)d_rows, stride, n,
+                       view(c, which), view(c), (const u32 *)d_cnt, (const u8 *)d_isref, d_out, (u8 *)d_irr);
+    HIP_TRY(c, hipGetLastError());
+    if (host_out) HIP_TRY(c, hipMemcpyAsync(host_out, d_out, out_elem * n, hipMemcpyDeviceToHost, c->stream));
+    if (host_irregular) HIP_TRY(c, hipMemcpyAsync(host_irregular, d_irr, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+// canonical key of an irregular row as KMAP::canonical returns it (kmap.hpp:86-97):
+// bookkeeping for keys the device table cannot represent; the scan never sees them.
+std::string host_irregular_key(const char *row, size_t stride)
+{
+    size_t k = strnlen(row, stride);
+    std::string rc(k, '\0');
+    auto comp = [](unsigned char ch) -> char {
+        switch (ch) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
+        case 'a': return 'T'; case 'c': return 'G'; case 'g': return 'G'; case 't': return 'A'; case 'n': return 'N';
+        default: return 0;
+        }
+    };
+    for (size_t i = 0; i < k; ++i) rc[i] = comp((unsigned char)row[k - 1 - i]);
+    std::string fw(row, k);
+    bool fwd = false;
+    for (size_t i = 0; i < k; ++i)
+        if ((unsigned char)fw[i] != (unsigned char)rc[i]) {
+            fwd = (unsigned char)fw[i] < (unsigned char)rc[i];
+            break;
+        }
+    std::string can = fwd ? fw : rc;
+    return std::string(can.c_str()); // cut at the first NUL
+}
+
+int fill_geno_params(mg_ctx *c, float error_rate, int max_cov, int haploid, GenoParams *p)
+{
+    if (!c->d_ln) {
+        std::vector<double> t(MG_LN_TABLE);
+        t[0] = 0.0;
+        for (int n = 1; n < MG_LN_TABLE; ++n) t[n] = std::log((double)n);
+        HIP_TRY(c, hipMalloc(&c->d_ln, sizeof(double) * MG_LN_TABLE));
+        HIP_TRY(c, hipMemcpy(c->d_ln, t.data(), sizeof(double) * MG_LN_TABLE, hipMemcpyHostToDevice));
+    }
+    if (!c->d_eps) HIP_TRY(c, hipMalloc(&c->d_eps, sizeof(float) * 2 * MG_EPS_TABLE));
+    if (!(c->eps_for == error_rate)) {
+        std::vector<float> t(2 * MG_EPS_TABLE, 0.f);
+        for (int A = 0; A < MG_EPS_TABLE; ++A) {
+            t[A] = std::log(error_rate / (float)(unsigned long)(A - 1));                // float overload
+            t[MG_EPS_TABLE + A] = std::log(error_rate / (float)(unsigned long)(A - 2)); // float overload
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_eps, t.data(), sizeof(float) * 2 * MG_EPS_TABLE, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->eps_for = error_rate;
+    }
+    p->ln_tab = c->d_ln;
+    p->c_err1 = c->d_eps;
+    p->c_err2 = c->d_eps + MG_EPS_TABLE;
+    p->c_hom = std::log(1 - error_rate);
+    p->c_het = std::log((1 - error_rate) / 2);
+    p->error_rate = error_rate;
+    p->max_cov = max_cov;
+    p->haploid = haploid;
+    return MG_OK;
+}
+
+} // namespace
+
+// ---- lifetime -------------------------------------------------------------------
+
+MG_EXPORT int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, uint64_t bf_bits)
+{
+    if (!out) return MG_ERR_ARG;
+    *out = nullptr;
+    if (k == 0 || k > MG_MAX_KMER || ref_k < k || ref_k > MG_MAX_KMER || bf_bits == 0) return MG_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MG_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return MG_ERR_HIP;
+    mg_ctx *c = new mg_ctx();
+    c->device = device;
+    c->k = k;
+    c->ref_k = ref_k;
+    if (hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return MG_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return MG_ERR_HIP;
+        }
+    for (int w = 0; w < 2; ++w) {
+        BFState &b = c->bf[w];
+        b.size = bf_bits;
+        b.nwords = (bf_bits + 63) / 64;
+        b.n_blk = (b.nwords + 7) / 8;
+        b.mod = make_mod(bf_bits);
+        if (hipMalloc(&b.words, b.nwords * 8) != hipSuccess || hipMemsetAsync(b.words, 0, b.nwords * 8, c->stream) != hipSuccess) {
+            mg_destroy(c);
+            return MG_ERR_NOMEM;
+        }
+    }
+    if (hipMalloc(&c->d_hit_count, 16) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        mg_destroy(c);
+        return MG_ERR_HIP;
+    }
+    *out = c;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_destroy(mg_ctx *c)
+{
+    if (!c) return MG_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto &b : c->bf) {
+        hipFree(b.words);
+        hipFree(b.blk);
+        hipFree(b.counts);
+        hipFree(b.summary);
+    }
+    map_free_table(c->map);
+    hipFree(c->map.vals);
+    for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr, &c->s_hitrow, &c->s_hitidx}) hipFree(s->p);
+    for (auto &s : c->s_misc) hipFree(s.p);
+    hipFree(c->d_hit_count);
+    hipFree(c->d_ln);
+    hipFree(c->d_eps);
+    hipFree(c->d_ref);
+    for (auto &e : c->ev)
+        if (e) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return MG_OK;
+}
+
+MG_EXPORT const char *mg_last_error(const mg_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
+{
+    if (!c) return MG_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MG_OK;
+}
+MG_EXPORT int mg_synchronize(mg_ctx *c)
+{
+    if (!c) return MG_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return MG_ERR_ARG;
+    if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
+    else if (!strcmp(name, "bf_summary_log2")) c->bf_sum_log2 = (int)value;
+    else if (!strcmp(name, "map_summary_log2")) c->map_sum_log2 = (int)value;
+    else return fail(c, MG_ERR_ARG, "unknown option %s", name);
+    return MG_OK;
+}
+
+// ---- BF ---------------------------------------------------------------------------
+
+MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride, size_t n)
+{
+    TRY(check_which(c, which));
+    TRY(check_rows(c, rows, stride, n));
+    // the reference lets add_key run in read mode too (the bit is set, the rank goes stale); refuse that
+    if (c->bf[which].mode) return fail(c, MG_ERR_STATE, "mg_bf_insert after mg_bf_finalize");
+    return run_rows<OP_BF_INSERT>(c, which, rows, stride, n, nullptr, nullptr, nullptr, 0, nullptr);
+}
+MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint8_t *out)
+{
+    TRY(check_which(c, which));
+    TRY(check_rows(c, rows, stride, n));
+    if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
+    return run_rows<OP_BF_TEST>(c, which, rows, stride, n, nullptr, nullptr, out, 1, nullptr);
+}
+MG_EXPORT int mg_debug_bf_index(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint64_t *out)
+{
+    TRY(check_which(c, which));
+    TRY(check_rows(c, rows, stride, n));
+    if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
+    return run_rows<OP_BF_INDEX>(c, which, rows, stride, n, nullptr, nullptr, out, 8, nullptr);
+}
+
+MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
+{
+    TRY(check_which(c, which));
+    BFState &b = c->bf[which];
+    if (b.blk) {
+        hipFree(b.blk);
+        b.blk = nullptr;
+    }
+    HIP_TRY(c, hipMalloc(&b.blk, (b.n_blk + 1) * 4));
+    const u64 n_tiles = nblocks(b.n_blk + 1);
+    void *d_tiles;
+    TRY(scratch(c, c->s_misc[1], (n_tiles + 1) * 4, &d_tiles));
+    unsigned long long *d_total = c->d_hit_count;
+    hipLaunchKernelGGL(blk_pop_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, b.words, b.nwords, b.n_blk, b.blk,
+                       (u32 *)d_tiles);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (u32 *)d_tiles, n_tiles, d_total);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (total >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "filter holds %llu set bits (>= 2^32-1)", total);
+    hipLaunchKernelGGL(blk_add_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, b.blk, b.n_blk, (const u32 *)d_tiles,
+                       (u32)total);
+    HIP_TRY(c, hipGetLastError());
+    b.nset = total;
+    if (b.counts) hipFree(b.counts);
+    b.counts = nullptr;
+    HIP_TRY(c, hipMalloc(&b.counts, (total ? total : 1) * 4));
+    HIP_TRY(c, hipMemsetAsync(b.counts, 0, (total ? total : 1) * 4, c->stream));
+    // summary bitmap: one bit per 2^sum_shift filter bits, sized to stay cache resident
+    u32 S = 6;
+    while (((b.size + (1ULL << S) - 1) >> S) > (1ULL << c->bf_sum_log2)) ++S;
+    b.sum_shift = S;
+    b.n_sum_bits = (b.size + (1ULL << S) - 1) >> S;
+    if (b.summary) hipFree(b.summary);
+    b.summary = nullptr;
+    HIP_TRY(c, hipMalloc(&b.summary, ((b.n_sum_bits + 63) / 64) * 8));
+    hipLaunchKernelGGL(summary_kernel, dim3(nblocks(((b.n_sum_bits + 63) / 64) * 64)), dim3(TPB), 0, c->stream, b.words,
+                       b.nwords, b.summary, b.n_sum_bits, S);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    b.mode = 1;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_bf_increment(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, const uint32_t *counters)
+{
+    TRY(check_which(c, which));
+    TRY(check_rows(c, rows, stride, n));
+    if (!c->bf[which].mode) return fail(c, MG_ERR_STATE, "BF::increment in write mode returns false");
+    if (n && !counters) return fail(c, MG_ERR_ARG, "counters is NULL");
+    return run_rows<OP_BF_INC>(c, which, rows, stride, n, counters, nullptr, nullptr, 0, nullptr);
+}
+MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint16_t *out)
+{
+    TRY(check_which(c, which));
+    TRY(check_rows(c, rows, stride, n));
+    if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
+    if (!c->bf[which].mode) { // bloom_filter.hpp:117: write mode -> 0
+        memset(out, 0, 2 * n);
+        return MG_OK;
+    }
+    return run_rows<OP_BF_GET>(c, which, rows, stride, n, nullptr, nullptr, out, 2, nullptr);
+}
+MG_EXPORT int mg_bf_info(mg_ctx *c, int which, uint64_t *size_bits, uint64_t *n_set, int *mode)
+{
+    TRY(check_which(c, which));
+    if (size_bits) *size_bits = c->bf[which].size;
+    if (n_set) *n_set = c->bf[which].nset;
+    if (mode) *mode = c->bf[which].mode;
+    return MG_OK;
+}
+
+// ---- KMAP ---------------------------------------------------------------------------
+
+MG_EXPORT int mg_map_insert(mg_ctx *c, const char *rows, size_t stride, size_t n)
+{
+    TRY(check_rows(c, rows, stride, n));
+    if (n == 0) return MG_OK;
+    TRY(map_reserve(c, n));
+    void *d_rows, *d_irr;
+    TRY(upload(c, c->s_rows, rows, stride * n, &d_rows));
+    TRY(scratch(c, c->s_irr, n, &d_irr));
+    hipLaunchKernelGGL(map_insert_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u8 *)d_rows, stride, n, view(c),
+                       (u32)c->map.rows_total, (u8 *)d_irr);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<u8> irr(n);
+    HIP_TRY(c, hipMemcpyAsync(irr.data(), d_irr, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->map.rows_total += n;
+    for (size_t i = 0; i < n; ++i)
+        if (irr[i]) c->map.irregular[host_irregular_key(rows + i * stride, stride)] = 0;
+    return MG_OK;
+}
+MG_EXPORT int mg_map_test(mg_ctx *c, const char *rows, size_t stride, size_t n, uint8_t *out)
+{
+    TRY(check_rows(c, rows, stride, n));
+    if (n == 0) return MG_OK;
+    if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    std::vector<u8> irr(n);
+    TRY(run_rows<OP_MAP_TEST>(c, 0, rows, stride, n, nullptr, nullptr, out, 1, irr.data()));
+    for (size_t i = 0; i < n; ++i)
+        if (irr[i]) out[i] = c->map.irregular.count(host_irregular_key(rows + i * stride, stride)) ? 1 : 0;
+    return MG_OK;
+}
+MG_EXPORT int mg_map_increment(mg_ctx *c, const char *rows, size_t stride, size_t n, const int32_t *counters)
+{
+    TRY(check_rows(c, rows, stride, n));
+    if (n == 0) return MG_OK;
+    if (!counters) return fail(c, MG_ERR_ARG, "counters is NULL");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    std::vector<u8> irr(n);
+    TRY(run_rows<OP_MAP_INC>(c, 0, rows, stride, n, counters, nullptr, nullptr, 0, irr.data()));
+    for (size_t i = 0; i < n; ++i)
+        if (irr[i]) {
+            auto it = c->map.irregular.find(host_irregular_key(rows + i * stride, stride));
+            if (it != c->map.irregular.end()) it->second = (int32_t)((uint32_t)it->second + (uint32_t)counters[i]);
+        }
+    return MG_OK;
+}
+MG_EXPORT int mg_map_get_count(mg_ctx *c, const char *rows, size_t stride, size_t n, int32_t *out)
+{
+    TRY(check_rows(c, rows, stride, n));
+    if (n == 0) return MG_OK;
+    if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    std::vector<u8> irr(n);
+    TRY(run_rows<OP_MAP_GET>(c, 0, rows, stride, n, nullptr, nullptr, out, 4, irr.data()));
+    for (size_t i = 0; i < n; ++i)
+        if (irr[i]) {
+            auto it = c->map.irregular.find(host_irregular_key(rows + i * stride, stride));
+            out[i] = it != c->map.irregular.end() ? it->second : 0;
+        }
+    return MG_OK;
+}
+
+namespace {
+// distinct regular keys on the device table
+int map_dump(mg_ctx *c, std::vector<u64> *klo, std::vector<u64> *khi, std::vector<u32> *ids)
+{
+    MapState &m = c->map;
+    klo->clear();
+    khi->clear();
+    ids->clear();
+    if (!m.tags) return MG_OK;
+    const u64 cap = 1ULL << m.cap_log2;
+    const u64 maxn = m.rows_total < cap ? m.rows_total : cap;
+    if (maxn == 0) return MG_OK;
+    void *d_lo, *d_hi, *d_id;
+    TRY(scratch(c, c->s_misc[2], maxn * 8, &d_lo));
+    TRY(scratch(c, c->s_misc[3], maxn * 8, &d_hi));
+    TRY(scratch(c, c->s_misc[4], maxn * 4, &d_id));
+    HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 8, c->stream));
+    hipLaunchKernelGGL(map_dump_kernel, dim3(nblocks(cap)), dim3(TPB), 0, c->stream, view(c), (u64 *)d_lo, (u64 *)d_hi,
+                       (u32 *)d_id, c->d_hit_count);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_hit_count, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    klo->resize(cnt);
+    khi->resize(cnt);
+    ids->resize(cnt);
+    if (cnt) {
+        HIP_TRY(c, hipMemcpy(klo->data(), d_lo, cnt * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(khi->data(), d_hi, cnt * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(ids->data(), d_id, cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
+{
+    if (!c || !n_keys) return MG_ERR_ARG;
+    std::vector<u64> a, b;
+    std::vector<u32> ids;
+    TRY(map_dump(c, &a, &b, &ids));
+    *n_keys = a.size() + c->map.irregular.size();
+    return MG_OK;
+}
+
+// ---- reference scan --------------------------------------------------------------------
+
+MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
+{
+    if (!c) return MG_ERR_ARG;
+    if (len && !contig) return fail(c, MG_ERR_ARG, "contig is NULL");
+    if (!c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_ref_scan needs `bf` finalised (main.cpp:378 precedes :383)");
+    if (c->bf[MG_BF_CTX].mode) return fail(c, MG_ERR_STATE, "context filter already finalised");
+    const size_t off = (c->ref_k - c->k) / 2;
+    if (off > len) return fail(c, MG_ERR_ARG, "contig shorter than (ref_k-k)/2: the reference throws std::out_of_range here");
+    if (len < c->ref_k) {
+        // main.cpp:386-389 with both strings clipped by std::string(reference, pos, n): one test, no loop
+        const size_t kn = len - off < c->k ? len - off : c->k;
+        if (kn == 0) return fail(c, MG_ERR_ARG, "contig of %zu bases has no centre k-mer", len);
+        std::vector<char> r1(MG_MAX_KMER + 8, 0), r2(MG_MAX_KMER + 8, 0);
+        memcpy(r1.data(), contig + off, kn);
+        memcpy(r2.data(), contig, len);
+        uint8_t hit = 0;
+        TRY(mg_bf_test(c, MG_BF_ALT, r1.data(), r1.size(), 1, &hit));
+        if (hit) TRY(mg_bf_insert(c, MG_BF_CTX, r2.data(), r2.size(), 1));
+        return MG_OK;
+    }
+    const u64 n_windows = len - c->ref_k + 1;
+    // stream the contig through the device in slices (a human chromosome is a few hundred MB)
+    const size_t slice = 256u << 20;
+    for (u64 w0 = 0; w0 < n_windows; w0 += slice) {
+        const u64 nw = n_windows - w0 < slice ? n_windows - w0 : slice;
+        void *d;
+        TRY(upload(c, c->s_rows, contig + w0, nw + c->ref_k - 1, &d));
+        hipLaunchKernelGGL(ref_scan_kernel, dim3(nblocks(nw)), dim3(TPB), 0, c->stream, (const u8 *)d, nw, (int)c->k,
+                           (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return MG_OK;
+}
+
+// ---- KMC scan ----------------------------------------------------------------------------
+
+namespace {
+template <int KC, int RC>
+int launch_scan(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, u32 *hit_row, u64 *hit_idx)
+{
+    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 256u * 16u);
+    hipLaunchKernelGGL((scan_filter_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, n, (int)c->k,
+                       (int)c->ref_k, view(c, MG_BF_ALT), view(c), hit_row, hit_idx, c->d_hit_count);
+    return MG_OK;
+}
+template <int KC, int RC>
+int launch_hits(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n_rows, const u32 *hit_row, const u64 *hit_idx)
+{
+    // the hit count lives on the device; a fixed grid walks it with a stride, so no host round trip
+    const unsigned grid = (unsigned)std::min<u64>(nblocks(n_rows), 1024u);
+    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, (int)c->ref_k,
+                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), hit_row, hit_idx, c->d_hit_count);
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n)
+{
+    if (!c) return MG_ERR_ARG;
+    if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
+    if (c->k < 17 || c->ref_k > MG_MAX_PACKED_K)
+        return fail(c, MG_ERR_LIMIT, "packed scan supports 17 <= k <= ref_k <= 64 (k=%u ref_k=%u)", c->k, c->ref_k);
+    if (n == 0) return MG_OK;
+    if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    const u64 chunk = 1ULL << 28; // rows per launch pair; hit rows are u32 offsets inside a chunk
+    void *hr, *hx;
+    const u64 cap = n < chunk ? n : chunk;
+    TRY(scratch(c, c->s_hitrow, cap * 4, &hr));
+    TRY(scratch(c, c->s_hitidx, cap * 8, &hx));
+    const bool d35_43 = c->k == 35 && c->ref_k == 43;
+    c->stats_valid = false;
+    HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
+    for (u64 r0 = 0; r0 < n; r0 += chunk) {
+        const u64 nr = n - r0 < chunk ? n - r0 : chunk;
+        const u64 *ph = (const u64 *)d_hi + r0, *pl = (const u64 *)d_lo + r0;
+        const u32 *pc = (const u32 *)d_cnt + r0;
+        if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 8, c->stream));
+        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+        if (d35_43) launch_scan<35, 43>(c, ph, pl, pc, nr, (u32 *)hr, (u64 *)hx);
+        else launch_scan<0, 0>(c, ph, pl, pc, nr, (u32 *)hr, (u64 *)hx);
+        HIP_TRY(c, hipGetLastError());
+        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+        if (d35_43) launch_hits<35, 43>(c, ph, pl, pc, nr, (const u32 *)hr, (const u64 *)hx);
+        else launch_hits<0, 0>(c, ph, pl, pc, nr, (const u32 *)hr, (const u64 *)hx);
+        HIP_TRY(c, hipGetLastError());
+        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    }
+    c->stats_valid = true;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n == 0) return MG_OK;
+    if (!hi || !lo || !cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
+    const size_t piece = 1u << 26; // host table streamed through the device in 64M-row pieces
+    for (size_t r0 = 0; r0 < n; r0 += piece) {
+        const size_t nr = n - r0 < piece ? n - r0 : piece;
+        void *dh, *dl, *dc;
+        TRY(upload(c, c->s_misc[5], hi + r0, nr * 8, &dh));
+        TRY(upload(c, c->s_misc[6], lo + r0, nr * 8, &dl));
+        TRY(upload(c, c->s_misc[7], cnt + r0, nr * 4, &dc));
+        TRY(mg_kmc_scan_device(c, dh, dl, dc, nr));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return MG_OK;
+}
+
+MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
+{
+    if (!c) return MG_ERR_ARG;
+    if (!c->stats_valid) return fail(c, MG_ERR_STATE, "no scan has run");
+    HIP_TRY(c, hipEventSynchronize(c->ev[2]));
+    if (ms_out) {
+        HIP_TRY(c, hipEventElapsedTime(&ms_out[0], c->ev[0], c->ev[1]));
+        HIP_TRY(c, hipEventElapsedTime(&ms_out[1], c->ev[1], c->ev[2]));
+    }
+    if (n_hits) {
+        unsigned long long t[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(t, c->d_hit_count, 16, hipMemcpyDeviceToHost));
+        *n_hits = t[1];
+    }
+    return MG_OK;
+}
+
+MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, const uint64_t *lo, size_t n, uint32_t klen,
+                                    uint64_t *out)
+{
+    TRY(check_which(c, which));
+    if (klen < 17 || klen > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed k-mers: 17 <= k <= 64");
+    if (n == 0) return MG_OK;
+    void *dh, *dl, *dout;
+    TRY(upload(c, c->s_misc[5], hi, n * 8, &dh));
+    TRY(upload(c, c->s_misc[6], lo, n * 8, &dl));
+    TRY(scratch(c, c->s_out, n * 8, &dout));
+    hipLaunchKernelGGL(packed_index_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u64 *)dh, (const u64 *)dl,
+                       (u64)n, (int)klen, c->bf[which].mod, (u64 *)dout);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+// ---- counters exchange --------------------------------------------------------------------
+
+MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
+{
+    if (!c) return MG_ERR_ARG;
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (n_bf) *n_bf = c->bf[0].nset;
+    if (n_map) *n_map = c->map.rows_total;
+    return MG_OK;
+}
+MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
+{
+    if (!c || !d_out) return MG_ERR_ARG;
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    const u64 nb = c->bf[0].nset, nm = c->map.rows_total;
+    if (nb) HIP_TRY(c, hipMemcpyAsync(d_out, c->bf[0].counts, nb * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (nm) HIP_TRY(c, hipMemcpyAsync((u32 *)d_out + nb, c->map.vals, nm * 4, hipMemcpyDeviceToDevice, c->stream));
+    return MG_OK;
+}
+MG_EXPORT int mg_counters_import_device(mg_ctx *c, const void *d_in)
+{
+    if (!c || !d_in) return MG_ERR_ARG;
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    const u64 nb = c->bf[0].nset, nm = c->map.rows_total;
+    if (nb) HIP_TRY(c, hipMemcpyAsync(c->bf[0].counts, d_in, nb * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (nm) HIP_TRY(c, hipMemcpyAsync(c->map.vals, (const u32 *)d_in + nb, nm * 4, hipMemcpyDeviceToDevice, c->stream));
+    return MG_OK;
+}
+MG_EXPORT int mg_counters_reset(mg_ctx *c)
+{
+    if (!c) return MG_ERR_ARG;
+    if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
+    if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
+    for (auto &kv : c->map.irregular) kv.second = 0;
+    return MG_OK;
+}
+
+// ---- per-variant path -----------------------------------------------------------------------
+
+MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t n_rows, const uint8_t *is_ref,
+                              const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
+                              uint32_t *cov_out)
+{
+    TRY(check_rows(c, rows, stride, n_rows));
+    if (n_alleles == 0) return MG_OK;
+    if (!sig_kmer_off || !allele_sig_off || !cov_out || (n_rows && !is_ref)) return fail(c, MG_ERR_ARG, "NULL descriptor");
+    if (allele_sig_off[n_alleles] != n_sigs || sig_kmer_off[n_sigs] != n_rows)
+        return fail(c, MG_ERR_ARG, "descriptor offsets do not close (sigs %zu rows %zu)", n_sigs, n_rows);
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    void *d_rows, *d_isref, *d_w, *d_so, *d_ao, *d_cov;
+    TRY(upload(c, c->s_rows, rows, stride * n_rows, &d_rows));
+    TRY(upload(c, c->s_misc[0], is_ref, n_rows, &d_isref));
+    TRY(scratch(c, c->s_out, 4 * (n_rows ? n_rows : 1), &d_w));
+    TRY(upload(c, c->s_misc[2], sig_kmer_off, 8 * (n_sigs + 1), &d_so));
+    TRY(upload(c, c->s_misc[3], allele_sig_off, 8 * (n_alleles + 1), &d_ao));
+    TRY(scratch(c, c->s_misc[4], 4 * n_alleles, &d_cov));
+    if (n_rows) {
+        hipLaunchKernelGGL(rows_kernel<OP_WEIGHT>, dim3(nblocks(n_rows)), dim3(TPB), 0, c->stream, (const u8 *)d_rows, stride,
+                           n_rows, view(c, MG_BF_ALT), view(c), (const u32 *)nullptr, (const u8 *)d_isref, d_w,
+                           (u8 *)nullptr);
+        HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(cover_kernel, dim3(nblocks(n_alleles)), dim3(TPB), 0, c->stream, (const i32 *)d_w, (const u64 *)d_so,
+                       (const u64 *)d_ao, (u64)n_alleles, (u32 *)d_cov);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * n_alleles, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, const uint32_t *var_allele_off, size_t n_vars,
+                          float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status,
+                          double *probs, const uint64_t *var_gt_off)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!cov || !freq || !var_allele_off || !gt1 || !gt2 || !gq || !status) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (probs && !var_gt_off) return fail(c, MG_ERR_ARG, "probs needs var_gt_off");
+    GenoParams p;
+    TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
+    const size_t na = var_allele_off[n_vars];
+    const size_t ng = probs ? var_gt_off[n_vars] : 0;
+    void *d_cov, *d_freq, *d_off, *d_g1, *d_g2, *d_gq, *d_st, *d_pr = nullptr, *d_go = nullptr;
+    TRY(upload(c, c->s_rows, cov, 4 * na, &d_cov));
+    TRY(upload(c, c->s_aux, freq, 4 * na, &d_freq));
+    TRY(upload(c, c->s_misc[0], var_allele_off, 4 * (n_vars + 1), &d_off));
+    TRY(scratch(c, c->s_misc[1], 4 * n_vars, &d_g1));
+    TRY(scratch(c, c->s_misc[2], 4 * n_vars, &d_g2));
+    TRY(scratch(c, c->s_misc[3], 4 * n_vars, &d_gq));
+    TRY(scratch(c, c->s_misc[4], n_vars, &d_st));
+    if (probs) {
+        TRY(scratch(c, c->s_out, 8 * (ng ? ng : 1), &d_pr));
+        TRY(upload(c, c->s_misc[5], var_gt_off, 8 * (n_vars + 1), &d_go));
+    }
+    hipLaunchKernelGGL(genotype_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u32 *)d_cov, (const float *)d_freq,
+                       (const u32 *)d_off, (u64)n_vars, p, (i32 *)d_g1, (i32 *)d_g2, (i32 *)d_gq, (u8 *)d_st, (double *)d_pr,
+                       (const u64 *)d_go);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(gt1, d_g1, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(gt2, d_g2, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(gq, d_gq, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status, d_st, n_vars, hipMemcpyDeviceToHost, c->stream));
+    if (probs && ng) HIP_TRY(c, hipMemcpyAsync(probs, d_pr, 8 * ng, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
+{
+    if (!c || (len && !ascii)) return MG_ERR_ARG;
+    if (c->d_ref) hipFree(c->d_ref);
+    c->d_ref = nullptr;
+    c->ref_len = 0;
+    HIP_TRY(c, hipMalloc(&c->d_ref, len ? len : 1));
+    if (len) HIP_TRY(c, hipMemcpy(c->d_ref, ascii, len, hipMemcpyHostToDevice));
+    c->ref_len = len;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_pos, const void *d_var_allele_off,
+                                      const void *d_allele_off, const void *d_allele_pool, const void *d_freq,
+                                      const void *d_present_mask, const void *d_flags, float error_rate, int max_cov, int haploid,
+                                      void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (!c->map.tags) TRY(map_reserve(c, 0));
+    GenoParams p;
+    TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
+    hipLaunchKernelGGL(call_isolated_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
+                       (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
+                       (const float *)d_freq, (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT),
+                       view(c), p, (u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+
+MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off,
+                               const uint32_t *allele_off, const char *allele_pool, size_t pool_len, const float *freq,
+                               const uint64_t *present_mask, const uint8_t *flags, float error_rate, int max_cov, int haploid,
+                               uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!pos || !var_allele_off || !allele_off || !allele_pool || !freq || !present_mask || !flags || !cov_out || !gt1 || !gt2 ||
+        !gq || !status)
+        return fail(c, MG_ERR_ARG, "NULL argument");
+    const size_t na = var_allele_off[n_vars];
+    // host-side contract checks: every window the kernel will read lies inside the uploaded reference
+    for (size_t v = 0; v < n_vars; ++v)
+        if (flags[v] & 1) {
+            const u32 a0 = var_allele_off[v];
+            const u64 rs = allele_off[a0 + 1] - allele_off[a0];
+            if (pos[v] < c->k || pos[v] + rs + c->k > c->ref_len)
+                return fail(c, MG_ERR_ARG, "variant %zu flagged eligible but within k of the reference buffer end", v);
+        }
+    if (allele_off[na] > pool_len) return fail(c, MG_ERR_ARG, "allele offsets exceed the pool");
+    void *d_pos, *d_vo, *d_ao, *d_pool, *d_fr, *d_pm, *d_fl, *d_cov, *d_g1, *d_g2, *d_gq, *d_st;
+    TRY(upload(c, c->s_rows, pos, 8 * n_vars, &d_pos));
+    TRY(upload(c, c->s_aux, var_allele_off, 4 * (n_vars + 1), &d_vo));
+    TRY(upload(c, c->s_misc[0], allele_off, 4 * (na + 1), &d_ao));
+    TRY(upload(c, c->s_misc[1], allele_pool, pool_len, &d_pool));
+    TRY(upload(c, c->s_misc[2], freq, 4 * na, &d_fr));
+    TRY(upload(c, c->s_misc[3], present_mask, 8 * n_vars, &d_pm));
+    TRY(upload(c, c->s_misc[4], flags, n_vars, &d_fl));
+    TRY(scratch(c, c->s_out, 4 * na, &d_cov));
+    TRY(scratch(c, c->s_misc[5], 4 * n_vars, &d_g1));
+    TRY(scratch(c, c->s_misc[6], 4 * n_vars, &d_g2));
+    TRY(scratch(c, c->s_misc[7], 4 * n_vars, &d_gq));
+    TRY(scratch(c, c->s_irr, n_vars, &d_st));
+    TRY(mg_call_isolated_device(c, n_vars, d_pos, d_vo, d_ao, d_pool, d_fr, d_pm, d_fl, error_rate, max_cov, haploid, d_cov, d_g1,
+                                d_g2, d_gq, d_st));
+    HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * na, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(gt1, d_g1, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(gt2, d_g2, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(gq, d_gq, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status, d_st, n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+// ---- index payloads ---------------------------------------------------------------------------
+
+MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *counts_out)
+{
+    TRY(check_which(c, which));
+    BFState &b = c->bf[which];
+    if (words_out) HIP_TRY(c, hipMemcpy(words_out, b.words, b.nwords * 8, hipMemcpyDeviceToHost));
+    if (counts_out && b.mode && b.nset) {
+        void *d16;
+        TRY(scratch(c, c->s_out, b.nset * 2, &d16));
+        hipLaunchKernelGGL(mask_u16_kernel, dim3(nblocks(b.nset)), dim3(TPB), 0, c->stream, (const u32 *)b.counts, (uint16_t *)d16,
+                           b.nset);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(counts_out, d16, b.nset * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return MG_OK;
+}
+MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *words, const uint16_t *counts,
+                           uint64_t n_counts)
+{
+    TRY(check_which(c, which));
+    BFState &b = c->bf[which];
+    if (size_bits != b.size) return fail(c, MG_ERR_ARG, "filter size %llu does not match the context (%llu)",
+                                         (unsigned long long)size_bits, (unsigned long long)b.size);
+    if (!words) return fail(c, MG_ERR_ARG, "words is NULL");
+    HIP_TRY(c, hipMemcpy(b.words, words, b.nwords * 8, hipMemcpyHostToDevice));
+    b.mode = 0;
+    if (mode) {
+        TRY(mg_bf_finalize(c, which)); // rank is rebuilt on load, as bloom_filter.hpp:143 does
+        if (n_counts != b.nset) return fail(c, MG_ERR_ARG, "counter count %llu != popcount %llu", (unsigned long long)n_counts,
+                                            (unsigned long long)b.nset);
+        if (n_counts) {
+            void *d16;
+            TRY(upload(c, c->s_out, counts, n_counts * 2, &d16));
+            hipLaunchKernelGGL(widen_u16_kernel, dim3(nblocks(n_counts)), dim3(TPB), 0, c->stream, (const uint16_t *)d16, b.counts,
+                               n_counts);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return MG_OK;
+}
+
+namespace {
+void unpack_lform(u64 lo, u64 hi, u32 k, char *out)
+{
+    static const char L[4] = {'A', 'C', 'G', 'T'};
+    for (u32 i = 0; i < k; ++i) out[i] = L[(i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3];
+    out[k] = 0;
+}
+} // namespace
+
+// Regular keys all have length k (a shorter or longer pure-ACGT key cannot be
+// told apart once packed, so mg_map_insert of a row whose length != k is irregular
+// from the table's point of view only if it holds a non-ACGT byte; rows are
+// expected to be k long, as every signature k-mer of the reference is).
+MG_EXPORT int mg_map_export(mg_ctx *c, char *rows_out, size_t stride, int32_t *vals_out)
+{
+    if (!c) return MG_ERR_ARG;
+    std::vector<u64> lo, hi;
+    std::vector<u32> ids;
+    TRY(map_dump(c, &lo, &hi, &ids));
+    if (!rows_out && !vals_out) return MG_OK;
+    if (stride < c->k + 1) return fail(c, MG_ERR_ARG, "stride %zu < k+1", stride);
+    std::vector<u32> vals(c->map.rows_total);
+    if (c->map.rows_total) HIP_TRY(c, hipMemcpy(vals.data(), c->map.vals, c->map.rows_total * 4, hipMemcpyDeviceToHost));
+    size_t j = 0;
+    for (; j < lo.size(); ++j) {
+        if (rows_out) {
+            memset(rows_out + j * stride, 0, stride);
+            unpack_lform(lo[j], hi[j], c->k, rows_out + j * stride);
+        }
+        if (vals_out) vals_out[j] = (int32_t)vals[ids[j]];
+    }
+    for (auto &kv : c->map.irregular) {
+        if (rows_out) {
+            memset(rows_out + j * stride, 0, stride);
+            memcpy(rows_out + j * stride, kv.first.data(), kv.first.size() < stride - 1 ? kv.first.size() : stride - 1);
+        }
+        if (vals_out) vals_out[j] = kv.second;
+        ++j;
+    }
+    return MG_OK;
+}
+MG_EXPORT int mg_map_import(mg_ctx *c, const char *rows, size_t stride, size_t n, const int32_t *vals)
+{
+    TRY(check_rows(c, rows, stride, n));
+    if (n == 0) return MG_OK;
+    const u64 row0 = c->map.rows_total;
+    TRY(mg_map_insert(c, rows, stride, n));
+    if (vals) {
+        // imported keys are distinct, so row i keeps id row0 + i; irregular rows go to the overflow list
+        HIP_TRY(c, hipMemcpy(c->map.vals + row0, vals, n * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < n; ++i) {
+            std::string key(rows + i * stride, strnlen(rows + i * stride, stride));
+            auto it = c->map.irregular.find(key);
+            if (it != c->map.irregular.end()) it->second = vals[i];
+        }
+    }
+    return MG_OK;
+}

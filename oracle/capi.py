@@ -38,6 +38,7 @@ def lib():
             "mo_bf_counts": (vp, [vp]),
             "mo_bf_popcount": (u64, [vp]),
             "mo_bf_set_positions": (u64, [vp, vp, u64]),
+            "mo_bf_load_words": (None, [vp, vp]),
             "mo_kmap_new": (vp, []),
             "mo_kmap_free": (None, [vp]),
             "mo_kmap_add_key": (None, [vp, cp]),
@@ -140,6 +141,11 @@ class BF:
         if n == 0:
             return np.zeros(0, dtype=np.uint16)
         return np.ctypeslib.as_array(C.cast(lib().mo_bf_counts(self.h), C.POINTER(C.c_uint16)), shape=(n,))
+
+    def load_words(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.shape[0] == lib().mo_bf_nwords(self.h)
+        lib().mo_bf_load_words(self.h, _p(words))
 
     def set_positions(self):
         n = self.popcount()

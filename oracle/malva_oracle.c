@@ -691,3 +691,10 @@ MO_API void mo_call_isolated(const mo_bf *bf, const mo_kmap *ref_bf, const char 
         }
     }
 }
+
+/* Load a bit array built elsewhere (e.g. exported from the device index, whose
+ * own parity is tested separately) so a timing run does not have to rebuild it. */
+MO_API void mo_bf_load_words(mo_bf *b, const uint64_t *words)
+{
+    memcpy(b->words, words, b->nwords * 8);
+}

@@ -1,0 +1,87 @@
+"""H10/H11: reference-context scan and KMC scan on the device vs the oracle.
+Full counter state is compared: every bf counter (rank order) and every exact-map
+value, for tiny filters (collisions, context hits) and full-size ones, with the
+cache-resident summaries on and off, specialised (35,43) and generic (k, ref_k)."""
+import numpy as np
+import pytest
+
+from gpu_util import build_index_pair, map_values_by_key
+from malva_amd import BF_ALT, BF_CTX, Context, synth
+from oracle import capi as ocapi
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan_case(k, ref_k, bf_bits, n_vars, n_rows, seed, use_summary=1, genome_edit=None):
+    panel = synth.snp_panel(n_vars, seed)
+    if genome_edit:
+        genome_edit(panel.genome)
+    ctx = Context(k, ref_k, bf_bits)
+    ctx.set_option("use_summary", use_summary)
+    obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bf_bits)
+    # index parity first: same bits in both filters
+    _, _, words, _ = ctx.bf_export(BF_ALT)
+    assert np.array_equal(words, obf.words())
+    _, _, cwords, _ = ctx.bf_export(BF_CTX)
+    assert np.array_equal(cwords, octx.words())
+    hi, lo, cnt = synth.kmer_table(panel, n_rows, k, ref_k, seed + 3)
+    ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+    ctx.kmc_scan(hi, lo, cnt)
+    _, _, _, counts = ctx.bf_export(BF_ALT)
+    assert np.array_equal(counts, obf.counts())
+    assert map_values_by_key(ctx) == dict(omap.items())
+    ms_f, ms_h, n_hits = ctx.scan_stats()
+    ctx.close()
+    return obf, octx, n_hits
+
+
+def test_scan_default_k35_r43_full_size_filter():
+    obf, octx, n_hits = _scan_case(35, 43, 1 << 33, 3000, 120000, 11)
+    assert obf.counts().any() and n_hits > 0
+
+
+def test_scan_tiny_filter_forces_collisions_and_context_hits():
+    # 2^17-bit filters: ~5% of random k-mers hit bf by collision, the reference scan fills
+    # context_bf, so the context test decides many increments
+    obf, octx, n_hits = _scan_case(35, 43, 1 << 17, 3000, 150000, 12)
+    assert octx.popcount() > 100 and n_hits > 5000
+
+
+def test_scan_without_summaries_is_identical():
+    _scan_case(35, 43, 1 << 17, 2000, 80000, 13, use_summary=0)
+
+
+@pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17)])
+def test_scan_generic_k(k, ref_k):
+    _scan_case(k, ref_k, (1 << 18) + 77, 1500, 60000, 100 + k)
+
+
+def test_ref_scan_with_non_acgt_bases_and_odd_modulus():
+    def edit(g):
+        rng = np.random.default_rng(3)
+        g[:50] = ord("N")
+        for p in rng.integers(100, len(g) - 100, size=300):
+            g[p] = rng.choice(np.frombuffer(b"NWMRYK", dtype=np.uint8))
+    _scan_case(35, 43, 1000003, 2000, 50000, 14, genome_edit=edit)
+
+
+def test_scan_is_linear_and_shards_sum():
+    """size-independent properties used at full size by bench.py: scanning a table twice doubles
+    every counter (mod 2^16 / 2^32); scanning two halves on two contexts and summing equals the whole."""
+    k, ref_k, bits = 35, 43, 1 << 22
+    panel = synth.snp_panel(2000, 21)
+    hi, lo, cnt = synth.kmer_table(panel, 100000, k, ref_k, 22)
+    res = []
+    for parts in ([slice(0, None)], [slice(0, None), slice(0, None)], [slice(0, 50000)], [slice(50000, None)]):
+        ctx = Context(k, ref_k, bits)
+        build_index_pair(ctx, panel, k, ref_k, bits)
+        for s in parts:
+            ctx.kmc_scan(hi[s], lo[s], cnt[s])
+        _, _, _, counts = ctx.bf_export(BF_ALT)
+        keys, vals = ctx.map_export()
+        order = np.argsort(np.array(keys, dtype=object))
+        res.append((counts.astype(np.uint32), vals[order].astype(np.int64)))
+        ctx.close()
+    whole, twice, a, b = res
+    assert np.array_equal((2 * whole[0]) & 0xFFFF, twice[0]) and np.array_equal(2 * whole[1], twice[1])
+    assert np.array_equal((a[0] + b[0]) & 0xFFFF, whole[0]) and np.array_equal(a[1] + b[1], whole[1])
