@@ -266,7 +266,18 @@ struct LdsIn {
     const u8 *p;
     __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
 };
-__global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 n_windows, int k, int ref_k, BFView bf,
+// The reference slides its centre k-mer by appending reference[p - (ref_k-k)/2]
+// (main.cpp:395-397).  When ref_k - k is odd that append runs one base ahead of a
+// true slide: window w >= 1 reads the centre at offset (ref_k-k) - (ref_k-k)/2,
+// and windows 1..k-1 still carry the tail of the first k-mer, i.e. a string with a
+// one-base gap.  CentreIn reproduces exactly that string (for even ref_k - k it is
+// the plain centred k-mer).
+struct CentreIn {
+    const u8 *p; // window start
+    int off_first, off_slide, keep; // keep = bytes still taken at the first window's offset
+    __device__ __forceinline__ u32 operator()(int i) const { return p[(i < keep ? off_first : off_slide) + i]; }
+};
+__global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0, u64 n_windows, int k, int ref_k, BFView bf,
                                                        BFView ctx)
 {
     __shared__ u8 sh[TPB + MG_MAX_KMER];
@@ -276,8 +287,10 @@ __global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 n_w
     for (int i = threadIdx.x; i < nbytes; i += TPB) sh[i] = contig[p0 + i];
     __syncthreads();
     if (threadIdx.x >= avail) return;
+    const u64 w = w0 + p0 + threadIdx.x; // window index inside the contig
     const int off = (ref_k - k) / 2;
-    CanonBytes<LdsIn> ck(LdsIn{sh + threadIdx.x + off}, k);
+    const int keep = w < (u64)k ? k - (int)w : 0;
+    CanonBytes<CentreIn> ck(CentreIn{sh + threadIdx.x, off, (ref_k - k) - off, keep}, k);
     const u64 idx = mod_size(xxh3_bytes(ck, k), bf.mod);
     if (!bf_maybe(bf, idx) || !bf_bit(bf, idx)) return;
     CanonBytes<LdsIn> cc(LdsIn{sh + threadIdx.x}, ref_k);
@@ -299,9 +312,28 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
                                                           BFView bf, MapView map, u32 *hit_row, u64 *hit_idx,
                                                           unsigned long long *hit_count)
 {
+    // Hits are staged per wave in LDS and flushed with ONE returning atomic per
+    // flush: a returning atomic per hit wave on a single counter word serialises
+    // at ~11 ns each and was 90 % of this kernel's time in the first version.
+    constexpr int STAGE = 128;
+    __shared__ u32 sh_row[TPB / 64][STAGE];
+    __shared__ u64 sh_idx[TPB / 64][STAGE];
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 stride = (u64)gridDim.x * TPB;
+    int staged = 0; // wave-uniform
+    auto flush = [&]() {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)staged);
+        base = __shfl(base, 0, 64);
+        for (int j = lane; j < staged; j += 64) {
+            hit_row[base + j] = sh_row[wave][j];
+            hit_idx[base + j] = sh_idx[wave][j];
+        }
+        staged = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n + ((0 - n) & 63); i += stride) {
         bool hit = false;
         u64 idx = 0;
@@ -319,17 +351,17 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
         }
         const u64 mask = __ballot(hit);
         if (mask) {
-            const int lane = threadIdx.x & 63;
-            unsigned long long base = 0;
-            if (lane == __ffsll((unsigned long long)mask) - 1) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
-            base = __shfl(base, __ffsll((unsigned long long)mask) - 1, 64);
             if (hit) {
-                const u64 j = base + __popcll(mask & ((1ULL << lane) - 1));
-                hit_row[j] = (u32)i;
-                hit_idx[j] = idx;
+                const int j = staged + __popcll(mask & ((1ULL << lane) - 1));
+                sh_row[wave][j] = (u32)i;
+                sh_idx[wave][j] = idx;
             }
+            staged += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (staged > STAGE - 64) flush();
         }
     }
+    if (staged) flush();
 }
 // Hit kernel: dense over the compacted rows.  context_bf.test_key on the ref_k-mer,
 // then bf.increment's rank + counter add.
@@ -1092,7 +1124,7 @@ MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
         const u64 nw = n_windows - w0 < slice ? n_windows - w0 : slice;
         void *d;
         TRY(upload(c, c->s_rows, contig + w0, nw + c->ref_k - 1, &d));
-        hipLaunchKernelGGL(ref_scan_kernel, dim3(nblocks(nw)), dim3(TPB), 0, c->stream, (const u8 *)d, nw, (int)c->k,
+        hipLaunchKernelGGL(ref_scan_kernel, dim3(nblocks(nw)), dim3(TPB), 0, c->stream, (const u8 *)d, w0, nw, (int)c->k,
                            (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));

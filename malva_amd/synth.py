@@ -255,6 +255,7 @@ def kmer_table(panel: Panel, n_rows, k, ref_k, seed, offsets=(-2, -1, 0, 1, 2), 
                 # a homozygous donor contributes each window once, as KMC lists distinct k-mers
                 het = panel.donor_gt[:, 0] != panel.donor_gt[:, 1]
                 w = w[het]
+            w = w[(CODE[w] <= 3).all(axis=1)]       # KMC drops windows that hold a non-ACGT symbol
             a, b = pack_ascii(w)
             his.append(a); los.append(b)
     hi = np.concatenate(his); lo = np.concatenate(los)
