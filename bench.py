@@ -180,8 +180,9 @@ def main():
         e1.synchronize()
         geno_ms.append(e0.elapsed_time(e1))
     filt_ms = float(np.mean([m[0] for m in scan_ms]))
-    hits_ms = float(np.mean([m[1] for m in scan_ms]))
-    n_hits = int(scan_ms[-1][2])
+    probe_ms = float(np.mean([m[1] for m in scan_ms]))
+    hits_ms = float(np.mean([m[2] for m in scan_ms]))
+    n_open, n_hits = int(scan_ms[-1][3]), int(scan_ms[-1][4])
     geno_ms_avg = float(np.mean(geno_ms))
 
     # ---- size-independent check of the full-size run: GT histogram is sane and the counters are consistent --
@@ -258,7 +259,8 @@ def main():
             "roofline": {"kernel": "scan_filter_kernel<35,43>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": n_rows, "avg_launch_ms": filt_ms},
-            "kernels_ms": {"scan_filter": filt_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg, "scan_hit_rows": n_hits},
+            "kernels_ms": {"scan_filter": filt_ms, "scan_probe": probe_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg,
+                           "gate_open_rows": n_open, "bf_hit_rows": n_hits},
             "genotype_roofline": {"achieved": GENO_BYTES_PER_SNP * n_vars / (geno_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "bytes_per_unit": GENO_BYTES_PER_SNP},
             "calls": called,

@@ -185,10 +185,11 @@ int mg_debug_bf_index(mg_ctx *ctx, int which, const char *rows, size_t stride, s
 /* same from packed k-mers of length klen (1..64), MSB-first right-aligned */
 int mg_debug_packed_index(mg_ctx *ctx, int which, const uint64_t *hi, const uint64_t *lo, size_t n, uint32_t klen,
                           uint64_t *idx_out);
-/* timing of the most recent mg_kmc_scan* in milliseconds (HIP events on the
- * context's stream): [0] filter kernel, [1] hit kernel; n_hits = rows that
- * reached the hit kernel */
-int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *n_hits);
+/* timing of the first chunk of the most recent mg_kmc_scan* in milliseconds (HIP
+ * events on the context's stream): ms_out[0] filter kernel, [1] probe kernel,
+ * [2] hit kernel; rows_out[0] = rows that passed the gate (last chunk),
+ * rows_out[1] = rows whose bf bit was set (whole call) */
+int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *rows_out);
 /* 0 disables the cache-resident summary bitmaps (A/B switch; results identical) */
 int mg_set_option(mg_ctx *ctx, const char *name, int64_t value);
 

@@ -262,10 +262,11 @@ class Context:
         self._ck(self._L.mg_kmc_scan_device(self.h, C.c_void_p(d_hi), C.c_void_p(d_lo), C.c_void_p(d_cnt), n))
 
     def scan_stats(self):
-        ms = (C.c_float * 2)()
-        nh = C.c_uint64()
-        self._ck(self._L.mg_scan_stats(self.h, ms, C.byref(nh)))
-        return float(ms[0]), float(ms[1]), nh.value
+        """-> (filter ms, probe ms, hits ms, open rows, bf-hit rows)"""
+        ms = (C.c_float * 3)()
+        nr = (C.c_uint64 * 2)()
+        self._ck(self._L.mg_scan_stats(self.h, ms, nr))
+        return float(ms[0]), float(ms[1]), float(ms[2]), int(nr[0]), int(nr[1])
 
     # counters exchange
     def counters_size(self):

@@ -144,17 +144,43 @@ struct BFView {
     u64 *words;        // size bits
     const u32 *blk;    // ones before each 512-bit block (valid once finalised)
     u32 *counts;       // one wrapping u32 per set bit; the u16 cell of the reference is its low half
-    const u64 *summary; // bit j = any bit set in [j << sum_shift, (j+1) << sum_shift)
+    // The gate: one cache-resident blocked Bloom filter in front of BOTH stores of the
+    // call-time scan, keyed by the filter slot idx = XXH3 % size (the exact map is
+    // addressed by the same XXH3, so one hash and one probe serve both).  Every set
+    // bit of `bf` and every exact-map key sets gate_k bits inside ONE 64-bit word:
+    // the word and the first bit from idx >> gate_shift, the others from the low
+    // gate_shift bits of idx.  All of them are functions of idx alone, so a k-mer that
+    // merely COLLIDES with a set bf bit (a Bloom false positive, which the reference
+    // counts) passes too.  A closed gate proves that neither bf.increment nor
+    // ref_bf.increment can do anything, so ~97 % of table rows finish after one
+    // L2-resident probe.  Only the `bf` view carries it.
+    u64 *gate;
     ModDesc mod;
-    u32 sum_shift;
-    u32 use_summary;
+    u32 gate_shift;
+    u32 gate_k;   // bits per entry, 1..4
+    u32 use_gate;
 };
 __device__ __forceinline__ bool bf_bit(const BFView &b, u64 idx) { return (b.words[idx >> 6] >> (idx & 63)) & 1; }
-__device__ __forceinline__ bool bf_maybe(const BFView &b, u64 idx)
+__device__ __forceinline__ u64 gate_word(const BFView &b, u64 idx) { return idx >> (b.gate_shift + 6); }
+__device__ __forceinline__ u64 gate_mask(const BFView &b, u64 idx)
 {
-    if (!b.use_summary) return true;
-    const u64 j = idx >> b.sum_shift;
-    return (b.summary[j >> 6] >> (j & 63)) & 1;
+    u64 m = 1ULL << ((idx >> b.gate_shift) & 63);
+    const u32 t = (u32)(idx & ((1ULL << b.gate_shift) - 1));
+    if (b.gate_k > 1) m |= 1ULL << ((t * 0x9E3779B1u) >> 26);
+    if (b.gate_k > 2) m |= 1ULL << ((t * 0x85EBCA77u) >> 26);
+    if (b.gate_k > 3) m |= 1ULL << ((t * 0xC2B2AE3Du) >> 26);
+    return m;
+}
+__device__ __forceinline__ bool gate_open(const BFView &b, u64 idx)
+{
+    if (!b.use_gate) return true;
+    const u64 m = gate_mask(b, idx);
+    return (b.gate[gate_word(b, idx)] & m) == m;
+}
+__device__ __forceinline__ void gate_set(const BFView &b, u64 idx)
+{
+    if (!b.gate) return;
+    atomicOr((unsigned long long *)&b.gate[gate_word(b, idx)], gate_mask(b, idx));
 }
 // rank(idx) = ones in [0, idx)   (rank_support_v<1>, bloom_filter.hpp:108)
 __device__ __forceinline__ u32 bf_rank(const BFView &b, u64 idx)
@@ -177,32 +203,32 @@ struct MapView {
     u64 *khi;
     u32 *ids;
     u32 *vals;
-    const u64 *summary; // bit (h >> (64 - sum_log2)) set for every stored key
     u32 cap_log2;
-    u32 sum_log2;
-    u32 use_summary;
+    u32 klen; // every key held here is exactly this long (other lengths live in the host overflow list)
 };
-__device__ __forceinline__ u64 map_hash(U128 key)
+// The table is addressed with the same XXH3 value the Bloom filter uses for the
+// k-mer (one hash per table row serves both stores): slot from the top bits, tag
+// from the middle.
+__device__ __forceinline__ u32 map_tag(u64 h) { return (u32)(h >> 8) | 0x80000000u; }
+__device__ __forceinline__ u64 map_slot(const MapView &m, u64 h) { return h >> (64 - m.cap_log2); }
+// XXH3 of the ASCII rendering of a packed canonical key (any length 1..64)
+struct LformIn {
+    U128 v;
+    __device__ __forceinline__ u32 operator()(int i) const
+    {
+        const u32 c = (u32)((i < 32 ? v.lo >> (2 * i) : v.hi >> (2 * (i - 32))) & 3);
+        return (0x54474341u >> (8 * c)) & 0xFF;
+    }
+};
+__device__ __forceinline__ u64 xxh3_lform(U128 key, int len)
 {
-    u64 h = key.lo ^ (key.hi * 0x9E3779B97F4A7C15ULL);
-    h *= 0xD6E8FEB86659FD93ULL;
-    h ^= h >> 32;
-    h *= 0xD6E8FEB86659FD93ULL;
-    h ^= h >> 32;
-    return h;
-}
-__device__ __forceinline__ u32 map_tag(u64 h) { return (u32)h | 0x80000000u; }
-__device__ __forceinline__ bool map_maybe(const MapView &m, u64 h)
-{
-    if (!m.use_summary) return true;
-    const u64 j = h >> (64 - m.sum_log2);
-    return (m.summary[j >> 6] >> (j & 63)) & 1;
+    return len >= 17 ? xxh3_packed(key, len) : xxh3_bytes(LformIn{key}, len);
 }
 // slot of a published key, or -1
 __device__ __forceinline__ long long map_find(const MapView &m, U128 key, u64 h)
 {
     const u64 mask = (1ULL << m.cap_log2) - 1;
-    u64 s = h >> (64 - m.cap_log2);
+    u64 s = map_slot(m, h);
     const u32 tag = map_tag(h);
     for (;;) {
         const u32 t = m.tags[s];

@@ -44,10 +44,10 @@ __device__ __forceinline__ int row_len(const u8 *row, int stride)
 // canonical form of an ASCII k-mer as the exact map keys it: regular (pure
 // upper-case ACGT, no NUL => never truncated) keys pack to an L-form;
 // anything else is "irregular" and is kept by the host-side overflow list.
-template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, int k, U128 *out)
+template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, int k, int klen, U128 *out)
 {
     U128 v{0, 0};
-    if (k > MG_MAX_PACKED_K) return false;
+    if (k != klen || k > MG_MAX_PACKED_K) return false;
     for (int i = 0; i < k; ++i) {
         const u32 code = code_of(c(i));
         if (code > 3) return false;
@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
     if (want_map) {
         U128 key;
         long long s = -1;
-        const bool regular = pack_regular(can, k, &key);
-        if (regular) s = map_find(map, key, map_hash(key));
+        const bool regular = pack_regular(can, k, (int)map.klen, &key);
+        if (regular) s = map_find(map, key, xxh3_bytes(can, k));
         if (irregular) irregular[i] = regular ? 0 : 1;
         if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
         if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.ids[s]], counters[i]);
@@ -87,7 +87,10 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
     }
     const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
     if (OP == OP_BF_INDEX) ((u64 *)out)[i] = idx;
-    if (OP == OP_BF_INSERT) atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
+    if (OP == OP_BF_INSERT) {
+        atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
+        gate_set(bf, idx);
+    }
     if (OP == OP_BF_TEST) ((u8 *)out)[i] = bf_bit(bf, idx);
     if (OP == OP_BF_INC) {
         if (bf_bit(bf, idx)) atomicAdd(&bf.counts[bf_rank(bf, idx)], counters[i]);
@@ -98,8 +101,8 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
 
 // KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows
 // inserted by earlier calls (ids are global insertion rows).
-__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, u32 row0,
-                                                         u8 *irregular)
+__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, BFView bf,
+                                                         u32 row0, u8 *irregular)
 {
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n) return;
@@ -107,13 +110,14 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
     const int k = row_len(row, (int)stride);
     CanonBytes<RowIn> can(RowIn{row}, k);
     U128 key;
-    const bool regular = pack_regular(can, k, &key);
+    const bool regular = pack_regular(can, k, (int)map.klen, &key);
     irregular[i] = regular ? 0 : 1;
     if (!regular) return;
-    const u64 h = map_hash(key);
+    const u64 h = xxh3_bytes(can, k);
+    gate_set(bf, mod_size(h, bf.mod));
     const u32 tag = map_tag(h);
     const u64 mask = (1ULL << map.cap_log2) - 1;
-    u64 s = h >> (64 - map.cap_log2);
+    u64 s = map_slot(map, h);
     const u32 my_id = row0 + (u32)i;
     bool done = false;
     // every lane retries inside one common loop, so a lane that owns a slot in
@@ -128,8 +132,6 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
                 atomicMin(&map.ids[s], my_id);
                 __threadfence();
                 __hip_atomic_store(&map.tags[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                const u64 j = h >> (64 - map.sum_log2);
-                atomicOr((unsigned long long *)&map.summary[j >> 6], 1ULL << (j & 63));
                 done = true;
                 continue;
             }
@@ -157,15 +159,20 @@ __global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView n
     if (s0 >= (1ULL << oldm.cap_log2)) return;
     if (oldm.tags[s0] < 2) return;
     U128 key{oldm.klo[s0], oldm.khi[s0]};
-    const u64 h = map_hash(key);
+    const u64 h = xxh3_lform(key, (int)oldm.klen);
     const u64 mask = (1ULL << newm.cap_log2) - 1;
-    u64 s = h >> (64 - newm.cap_log2);
+    u64 s = map_slot(newm, h);
     while (atomicCAS(&newm.tags[s], 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
     newm.klo[s] = key.lo;
     newm.khi[s] = key.hi;
     newm.ids[s] = oldm.ids[s0];
-    const u64 j = h >> (64 - newm.sum_log2);
-    atomicOr((unsigned long long *)&newm.summary[j >> 6], 1ULL << (j & 63));
+}
+// gate bits of every published key (after a filter import rebuilt the gate from the bits alone)
+__global__ void __launch_bounds__(TPB) map_gate_kernel(MapView m, BFView bf)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s >= (1ULL << m.cap_log2) || m.tags[s] < 2) return;
+    gate_set(bf, mod_size(xxh3_lform(U128{m.klo[s], m.khi[s]}, (int)m.klen), bf.mod));
 }
 
 // list of published (key, id) for export
@@ -234,18 +241,17 @@ __global__ void __launch_bounds__(TPB) blk_add_kernel(u32 *blk, u64 n_blk, const
     if (b < n_blk) blk[b] += tile_sums[blockIdx.x];
     if (b == n_blk) blk[b] = total; // rank(size) (bloom_filter.hpp:97)
 }
-// summary bit j = any bit in words [j << (S-6), (j+1) << (S-6)); one wave builds one u64
-__global__ void __launch_bounds__(TPB) summary_kernel(const u64 *words, u64 nwords, u64 *summary, u64 n_sum_bits, u32 sum_shift)
+// gate entries of every set filter bit (used when a filter is imported rather than built by inserts)
+__global__ void __launch_bounds__(TPB) gate_from_bits_kernel(BFView bf, u64 nwords)
 {
-    const u64 j = (u64)blockIdx.x * TPB + threadIdx.x;
-    bool any = false;
-    if (j < n_sum_bits) {
-        const u64 per = 1ULL << (sum_shift - 6);
-        const u64 w0 = j * per;
-        for (u64 w = w0; w < w0 + per && w < nwords; ++w) any |= words[w] != 0;
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 x = bf.words[w];
+    while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        gate_set(bf, w * 64 + b);
+        x &= x - 1;
     }
-    const u64 m = __ballot(any);
-    if ((threadIdx.x & 63) == 0 && (j >> 6) < ((n_sum_bits + 63) >> 6)) summary[j >> 6] = m;
 }
 __global__ void __launch_bounds__(TPB) mask_u16_kernel(const u32 *in, uint16_t *out, u64 n)
 {
@@ -292,96 +298,195 @@ __global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0,
     const int keep = w < (u64)k ? k - (int)w : 0;
     CanonBytes<CentreIn> ck(CentreIn{sh + threadIdx.x, off, (ref_k - k) - off, keep}, k);
     const u64 idx = mod_size(xxh3_bytes(ck, k), bf.mod);
-    if (!bf_maybe(bf, idx) || !bf_bit(bf, idx)) return;
+    if (!gate_open(bf, idx) || !bf_bit(bf, idx)) return;
     CanonBytes<LdsIn> cc(LdsIn{sh + threadIdx.x}, ref_k);
     const u64 cidx = mod_size(xxh3_bytes(cc, ref_k), ctx.mod);
     atomicOr((unsigned long long *)&ctx.words[cidx >> 6], 1ULL << (cidx & 63));
 }
 
 // ---- H10: KMC scan (main.cpp:482-500) -----------------------------------------
-// Filter kernel: one thread per table row.  Canonicalise the centre k-mer once,
-// probe the exact map (ref_bf.increment), hash it and test `bf`.  Rows whose bf
-// bit is set are rare; they are compacted into a hit list and finished by
-// scan_hits_kernel, so the ref_k-mer hash and the rank walk run at full lane
-// occupancy instead of dragging every wave through them.
-// Order of operations vs the reference: `bf.increment` is a no-op unless the bf
-// bit is set, so testing bf first and context_bf second gives identical counters.
-template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
-                                                          const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt,
-                                                          BFView bf, MapView map, u32 *hit_row, u64 *hit_idx,
-                                                          unsigned long long *hit_count)
-{
-    // Hits are staged per wave in LDS and flushed with ONE returning atomic per
-    // flush: a returning atomic per hit wave on a single counter word serialises
-    // at ~11 ns each and was 90 % of this kernel's time in the first version.
-    constexpr int STAGE = 128;
-    __shared__ u32 sh_row[TPB / 64][STAGE];
-    __shared__ u64 sh_idx[TPB / 64][STAGE];
-    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
-    const int off = (r - k) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 stride = (u64)gridDim.x * TPB;
-    int staged = 0; // wave-uniform
-    auto flush = [&]() {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)staged);
-        base = __shfl(base, 0, 64);
-        for (int j = lane; j < staged; j += 64) {
-            hit_row[base + j] = sh_row[wave][j];
-            hit_idx[base + j] = sh_idx[wave][j];
-        }
-        staged = 0;
-        __builtin_amdgcn_wave_barrier();
-    };
-    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n + ((0 - n) & 63); i += stride) {
-        bool hit = false;
-        u64 idx = 0;
-        if (i < n) {
-            const U128 m{lo[i], hi[i]};
-            const U128 l = mform_to_lform(m, r);
-            const U128 c = canon_sub(m, l, r, off, k);
-            const u64 hm = map_hash(c);
-            if (map_maybe(map, hm)) {
-                const long long s = map_find(map, c, hm);
-                if (s >= 0) atomicAdd(&map.vals[map.ids[s]], cnt[i]);
+// The scan is three kernels, each one dense in what it does:
+//
+//   scan_filter_kernel  every table row: canonicalise the centre k-mer, XXH3, slot,
+//                       ONE probe of the L2-resident gate.  Rows whose gate is open
+//                       (~3-4 %: true matches plus the gate's false positives) are
+//                       appended to the "open" list.  This kernel streams the table
+//                       and is the dominant one.
+//   scan_probe_kernel   open rows only: ref_bf.increment (tag walk in the exact map,
+//                       counter add) and the test of the real `bf` bit.  Rows whose
+//                       bf bit is set go to the "hit" list.
+//   scan_hits_kernel    hit rows only: context_bf.test_key on the ref_k-mer, then
+//                       bf.increment's rank + counter add.
+//
+// Doing the rare work inline instead (first versions) made nearly every wave walk
+// the rare path with 2-3 live lanes and eat its HBM latency: 2.0 ms vs 0.8 ms.
+// Order of operations vs the reference (main.cpp:495-499): `bf.increment` is a
+// no-op unless the bf bit is set, so testing bf before context_bf, and doing the map
+// increment in a different kernel, gives identical counters (all adds commute).
+//
+// List appends are staged per workgroup in LDS and flushed with ONE returning global
+// atomic per ~500+ entries: a returning atomic per appending wave on a single counter
+// word serialises at ~11 ns each (90 % of the first version's time, and still a third
+// of the filter kernel with per-wave staging at a 5 % append rate).
+template <int CAP, bool WITH_KEY> struct BlockStage {
+    u32 *rows;  // [CAP]
+    u64 *klo;   // [CAP] canonical centre k-mer travels with the row (WITH_KEY) so the
+    u64 *khi;   //       consumer does not re-fetch two random table lines per entry
+    u32 *n;     // entries staged
+    unsigned long long *base;
+    // every lane of the wave must call this (it ballots)
+    __device__ __forceinline__ void push(bool take, u32 row, U128 key)
+    {
+        const u64 mask = __ballot(take);
+        if (!mask) return;
+        const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
+        u32 off = 0;
+        if (lane == leader) off = atomicAdd(n, (u32)__popcll(mask));
+        off = __shfl(off, leader, 64);
+        if (take) {
+            const u32 q = off + __popcll(mask & ((1ULL << lane) - 1));
+            rows[q] = row;
+            if (WITH_KEY) {
+                klo[q] = key.lo;
+                khi[q] = key.hi;
             }
-            idx = mod_size(xxh3_packed(c, k), bf.mod);
-            hit = bf_maybe(bf, idx) && bf_bit(bf, idx);
-        }
-        const u64 mask = __ballot(hit);
-        if (mask) {
-            if (hit) {
-                const int j = staged + __popcll(mask & ((1ULL << lane) - 1));
-                sh_row[wave][j] = (u32)i;
-                sh_idx[wave][j] = idx;
-            }
-            staged += __popcll(mask);
-            __builtin_amdgcn_wave_barrier();
-            if (staged > STAGE - 64) flush();
         }
     }
-    if (staged) flush();
+    // every thread of the workgroup must call this; flushes when more than `keep` entries are staged
+    __device__ __forceinline__ void flush_if_above(u32 keep, u32 *g_rows, u64 *g_lo, u64 *g_hi, unsigned long long *g_count)
+    {
+        __syncthreads();
+        const u32 cnt = *n;
+        if (cnt > keep) {
+            if (threadIdx.x == 0) *base = atomicAdd(g_count, (unsigned long long)cnt);
+            __syncthreads();
+            const unsigned long long b = *base;
+            for (u32 j = threadIdx.x; j < cnt; j += TPB) {
+                g_rows[b + j] = rows[j];
+                if (WITH_KEY) {
+                    g_lo[b + j] = klo[j];
+                    g_hi[b + j] = khi[j];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) *n = 0;
+        }
+        __syncthreads();
+    }
+};
+
+// counters[0] = open rows, [1] = hit rows of the current chunk, [2] = hit rows of the whole call
+//
+// ROWS table rows per thread and iteration, in phases so that the memory operations of
+// one phase are all in flight together:
+//   A  load ROWS x (hi, lo)                 -- coalesced 8-byte loads, the only HBM stream
+//   B  canonicalise, XXH3, slot             -- pure VALU
+//   C  load ROWS gate words                 -- random 8-byte loads from a 2 MiB bitmap (L2)
+//   D  test, stage open rows
+// `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
+// 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
+template <int KC, int RC, int ROWS>
+__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, u64 n,
+                                                          int k_rt, int r_rt, BFView bf, u32 *open_row, u64 *open_lo,
+                                                          u64 *open_hi, unsigned long long *counters, int ablate)
+{
+    constexpr int CAP = TPB * ROWS + 768;
+    __shared__ u32 sh_rows[CAP];
+    __shared__ u64 sh_lo[CAP], sh_hi[CAP];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    BlockStage<CAP, true> st{sh_rows, sh_lo, sh_hi, &sh_n, &sh_base};
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const u64 step = (u64)gridDim.x * TPB * ROWS;
+    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
+        U128 c[ROWS];
+        u64 idx[ROWS], gate[ROWS];
+        bool valid[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // A
+            const u64 i = base + (u64)j * TPB + threadIdx.x;
+            valid[j] = i < n;
+            c[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
+            c[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // B
+            const U128 m = c[j];
+            if (!(ablate & 8)) c[j] = canon_sub(m, mform_to_lform(m, r), r, off, k);
+            const u64 h = (ablate & 4) ? (c[j].lo ^ c[j].hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed(c[j], k);
+            idx[j] = mod_size(h, bf.mod);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) // C
+            gate[j] = (ablate & 1) ? 0ULL : bf.use_gate ? bf.gate[gate_word(bf, idx[j])] : ~0ULL;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // D
+            const u64 gm = gate_mask(bf, idx[j]);
+            const bool open = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
+            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)c[j].hi));
+            st.push(open, (u32)(base + (u64)j * TPB + threadIdx.x), c[j]);
+        }
+        st.flush_if_above(CAP - TPB * ROWS, open_row, open_lo, open_hi, &counters[0]); // room for one more full iteration
+    }
+    st.flush_if_above(0, open_row, open_lo, open_hi, &counters[0]);
 }
-// Hit kernel: dense over the compacted rows.  context_bf.test_key on the ref_k-mer,
-// then bf.increment's rank + counter add.
+
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_probe_kernel(const u32 *__restrict__ cnt, int k_rt, BFView bf, MapView map,
+                                                         const u32 *open_row, const u64 *open_lo, const u64 *open_hi,
+                                                         u32 *hit_row, unsigned long long *counters)
+{
+    constexpr int CAP = TPB + 768;
+    __shared__ u32 sh_rows[CAP];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    BlockStage<CAP, false> st{sh_rows, nullptr, nullptr, &sh_n, &sh_base};
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt;
+    const u64 n_open = counters[0];
+    const u64 step = (u64)gridDim.x * TPB;
+    for (u64 base = (u64)blockIdx.x * TPB; base < n_open; base += step) {
+        const u64 j = base + threadIdx.x;
+        bool hit = false;
+        u32 row = 0;
+        if (j < n_open) {
+            row = open_row[j];
+            const U128 c{open_lo[j], open_hi[j]};
+            const u64 h = xxh3_packed(c, k);
+            const u64 idx = mod_size(h, bf.mod);
+            const u64 word = bf.words[idx >> 6];
+            const long long s = map_find(map, c, h);
+            if (s >= 0) atomicAdd(&map.vals[map.ids[s]], cnt[row]); // ref_bf.increment (main.cpp:495)
+            hit = (word >> (idx & 63)) & 1;
+        }
+        st.push(hit, row, U128{0, 0});
+        st.flush_if_above(CAP - TPB, hit_row, nullptr, nullptr, &counters[1]);
+    }
+    st.flush_if_above(0, hit_row, nullptr, nullptr, &counters[1]);
+}
+
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_hits_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
-                                                        const u32 *__restrict__ cnt, int r_rt, BFView bf, BFView ctx,
-                                                        const u32 *hit_row, const u64 *hit_idx,
-                                                        unsigned long long *hit_count)
+                                                        const u32 *__restrict__ cnt, int k_rt, int r_rt, BFView bf, BFView ctx,
+                                                        const u32 *hit_row, unsigned long long *counters)
 {
-    const int r = RC > 0 ? RC : r_rt;
-    const u64 nh = hit_count[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) hit_count[1] += nh; // running total of the whole scan call
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const u64 nh = counters[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] += nh;
     for (u64 j = (u64)blockIdx.x * TPB + threadIdx.x; j < nh; j += (u64)gridDim.x * TPB) {
         const u32 row = hit_row[j];
         const U128 m{lo[row], hi[row]};
         const U128 l = mform_to_lform(m, r);
-        const U128 c = canon_sub(m, l, r, 0, r);
-        const u64 cidx = mod_size(xxh3_packed(c, r), ctx.mod);
-        if (bf_bit(ctx, cidx)) continue;
-        atomicAdd(&bf.counts[bf_rank(bf, hit_idx[j])], cnt[row]);
+        const U128 cc = canon_sub(m, l, r, 0, r);
+        const u64 cidx = mod_size(xxh3_packed(cc, r), ctx.mod);
+        if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
+        const u64 idx = mod_size(xxh3_packed(canon_sub(m, l, r, off, k), k), bf.mod);
+        atomicAdd(&bf.counts[bf_rank(bf, idx)], cnt[row]);                // bf.increment (main.cpp:498)
     }
 }
 
@@ -469,8 +574,8 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
             i32 w = 0;
             if (a == 0) {
                 U128 key;
-                if (pack_regular(can, k, &key)) {
-                    const long long s = map_find(map, key, map_hash(key));
+                if (pack_regular(can, k, (int)map.klen, &key)) {
+                    const long long s = map_find(map, key, xxh3_bytes(can, k));
                     if (s >= 0) w = (i32)map.vals[map.ids[s]];
                 }
             } else {
@@ -494,19 +599,18 @@ struct BFState {
     u64 *words = nullptr;
     u32 *blk = nullptr;
     u32 *counts = nullptr;
-    u64 *summary = nullptr;
-    u64 n_sum_bits = 0;
-    u32 sum_shift = 6;
+    u64 *gate = nullptr; // only `bf` (MG_BF_ALT) owns one
+    u64 n_gate_bits = 0;
+    u32 gate_shift = 6;
     int mode = 0;
     ModDesc mod{};
 };
 struct MapState {
-    u32 cap_log2 = 0, sum_log2 = 0;
+    u32 cap_log2 = 0;
     u32 *tags = nullptr;
     u64 *klo = nullptr, *khi = nullptr;
     u32 *ids = nullptr;
     u32 *vals = nullptr;
-    u64 *summary = nullptr;
     u64 rows_total = 0; // insertion rows so far (upper bound on distinct keys; ids index space)
     u64 vals_cap = 0;
     std::unordered_map<std::string, int32_t> irregular; // keys the packed table cannot hold (N / NUL-truncated)
@@ -522,17 +626,22 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_hitrow, s_hitidx, s_misc[8];
+    Scratch s_rows, s_aux, s_out, s_irr, s_hitrow, s_hitidx, s_openlo, s_openhi, s_misc[8];
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
     float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
     float eps_for = -1.f;
     u8 *d_ref = nullptr;
     size_t ref_len = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool stats_valid = false;
     int use_summary = 1;
-    int bf_sum_log2 = 23, map_sum_log2 = 23;
+    bool gate_dirty = false; // something has been inserted into `bf`
+    int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
+    int scan_grid = 4096; // workgroups of the filter kernel (16 per CU)
+    int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
+    int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
+    int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
     std::string err;
 };
 
@@ -609,10 +718,11 @@ BFView view(const mg_ctx *c, int which)
     v.words = b.words;
     v.blk = b.blk;
     v.counts = b.counts;
-    v.summary = b.summary;
+    v.gate = b.gate;
     v.mod = b.mod;
-    v.sum_shift = b.sum_shift;
-    v.use_summary = (c->use_summary && b.summary && b.mode) ? 1 : 0;
+    v.gate_shift = b.gate_shift;
+    v.gate_k = (u32)c->gate_k;
+    v.use_gate = (c->use_summary && b.gate) ? 1 : 0;
     return v;
 }
 MapView view(const mg_ctx *c)
@@ -624,29 +734,38 @@ MapView view(const mg_ctx *c)
     v.khi = m.khi;
     v.ids = m.ids;
     v.vals = m.vals;
-    v.summary = m.summary;
     v.cap_log2 = m.cap_log2;
-    v.sum_log2 = m.sum_log2;
-    v.use_summary = c->use_summary ? 1 : 0;
+    v.klen = c->k;
     return v;
+}
+
+// (re)allocate the gate of `bf`: at most 2^gate_log2 bits, one per 2^gate_shift filter bits
+int alloc_gate(mg_ctx *c)
+{
+    BFState &b = c->bf[MG_BF_ALT];
+    u32 S = 6;
+    while (((b.size + (1ULL << S) - 1) >> S) > (1ULL << c->gate_log2)) ++S;
+    b.gate_shift = S;
+    b.n_gate_bits = (b.size + (1ULL << S) - 1) >> S;
+    if (b.gate) HIP_TRY(c, hipFree(b.gate));
+    b.gate = nullptr;
+    const size_t bytes = ((b.n_gate_bits + 63) / 64) * 8;
+    HIP_TRY(c, hipMalloc(&b.gate, bytes));
+    HIP_TRY(c, hipMemsetAsync(b.gate, 0, bytes, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
 }
 
 int map_alloc(mg_ctx *c, MapState &m, u32 cap_log2)
 {
     const u64 cap = 1ULL << cap_log2;
     m.cap_log2 = cap_log2;
-    u32 sl = cap_log2 + 2;
-    if (sl > (u32)c->map_sum_log2) sl = (u32)c->map_sum_log2;
-    if (sl < 6) sl = 6;
-    m.sum_log2 = sl;
     HIP_TRY(c, hipMalloc(&m.tags, cap * 4));
     HIP_TRY(c, hipMalloc(&m.klo, cap * 8));
     HIP_TRY(c, hipMalloc(&m.khi, cap * 8));
     HIP_TRY(c, hipMalloc(&m.ids, cap * 4));
-    HIP_TRY(c, hipMalloc(&m.summary, (1ULL << sl) / 8));
     HIP_TRY(c, hipMemsetAsync(m.tags, 0, cap * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(m.ids, 0xFF, cap * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(m.summary, 0, (1ULL << sl) / 8, c->stream));
     return MG_OK;
 }
 void map_free_table(MapState &m)
@@ -655,11 +774,9 @@ void map_free_table(MapState &m)
     hipFree(m.klo);
     hipFree(m.khi);
     hipFree(m.ids);
-    hipFree(m.summary);
     m.tags = nullptr;
     m.klo = m.khi = nullptr;
     m.ids = nullptr;
-    m.summary = nullptr;
 }
 // make room for `extra` more insertion rows: table load <= 1/4, vals indexable by row
 int map_reserve(mg_ctx *c, u64 extra)
@@ -688,7 +805,7 @@ int map_reserve(mg_ctx *c, u64 extra)
         TRY(map_alloc(c, m, want));
         MapView ov{};
         ov.tags = old.tags; ov.klo = old.klo; ov.khi = old.khi; ov.ids = old.ids; ov.cap_log2 = old.cap_log2;
-        ov.sum_log2 = old.sum_log2;
+        ov.klen = c->k;
         MapView nv = view(c);
         hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << old.cap_log2)), dim3(TPB), 0, c->stream, ov, nv);
         HIP_TRY(c, hipGetLastError());
@@ -697,7 +814,6 @@ int map_reserve(mg_ctx *c, u64 extra)
         hipFree(old.klo);
         hipFree(old.khi);
         hipFree(old.ids);
-        hipFree(old.summary);
     }
     return MG_OK;
 }
@@ -829,7 +945,7 @@ MG_EXPORT int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, ui
             return MG_ERR_NOMEM;
         }
     }
-    if (hipMalloc(&c->d_hit_count, 16) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (alloc_gate(c) != MG_OK || hipMalloc(&c->d_hit_count, 32) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         mg_destroy(c);
         return MG_ERR_HIP;
     }
@@ -846,11 +962,11 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
         hipFree(b.words);
         hipFree(b.blk);
         hipFree(b.counts);
-        hipFree(b.summary);
+        hipFree(b.gate);
     }
     map_free_table(c->map);
     hipFree(c->map.vals);
-    for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr, &c->s_hitrow, &c->s_hitidx}) hipFree(s->p);
+    for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr, &c->s_hitrow, &c->s_hitidx, &c->s_openlo, &c->s_openhi}) hipFree(s->p);
     for (auto &s : c->s_misc) hipFree(s.p);
     hipFree(c->d_hit_count);
     hipFree(c->d_ln);
@@ -882,8 +998,17 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
-    else if (!strcmp(name, "bf_summary_log2")) c->bf_sum_log2 = (int)value;
-    else if (!strcmp(name, "map_summary_log2")) c->map_sum_log2 = (int)value;
+    else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
+    else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
+    else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 4096;
+    else if (!strcmp(name, "gate_log2") || !strcmp(name, "gate_k")) {
+        if (c->map.rows_total || c->gate_dirty) return fail(c, MG_ERR_STATE, "%s must be set before the first insert", name);
+        if (!strcmp(name, "gate_k")) {
+            if (value < 1 || value > 4) return fail(c, MG_ERR_ARG, "gate_k must be 1..4");
+            c->gate_k = (int)value;
+        } else c->gate_log2 = (int)value;
+        return alloc_gate(c);
+    }
     else return fail(c, MG_ERR_ARG, "unknown option %s", name);
     return MG_OK;
 }
@@ -896,6 +1021,7 @@ MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride
     TRY(check_rows(c, rows, stride, n));
     // the reference lets add_key run in read mode too (the bit is set, the rank goes stale); refuse that
     if (c->bf[which].mode) return fail(c, MG_ERR_STATE, "mg_bf_insert after mg_bf_finalize");
+    if (which == MG_BF_ALT) c->gate_dirty = true;
     return run_rows<OP_BF_INSERT>(c, which, rows, stride, n, nullptr, nullptr, nullptr, 0, nullptr);
 }
 MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint8_t *out)
@@ -942,17 +1068,6 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
     b.counts = nullptr;
     HIP_TRY(c, hipMalloc(&b.counts, (total ? total : 1) * 4));
     HIP_TRY(c, hipMemsetAsync(b.counts, 0, (total ? total : 1) * 4, c->stream));
-    // summary bitmap: one bit per 2^sum_shift filter bits, sized to stay cache resident
-    u32 S = 6;
-    while (((b.size + (1ULL << S) - 1) >> S) > (1ULL << c->bf_sum_log2)) ++S;
-    b.sum_shift = S;
-    b.n_sum_bits = (b.size + (1ULL << S) - 1) >> S;
-    if (b.summary) hipFree(b.summary);
-    b.summary = nullptr;
-    HIP_TRY(c, hipMalloc(&b.summary, ((b.n_sum_bits + 63) / 64) * 8));
-    hipLaunchKernelGGL(summary_kernel, dim3(nblocks(((b.n_sum_bits + 63) / 64) * 64)), dim3(TPB), 0, c->stream, b.words,
-                       b.nwords, b.summary, b.n_sum_bits, S);
-    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     b.mode = 1;
     return MG_OK;
@@ -997,7 +1112,7 @@ MG_EXPORT int mg_map_insert(mg_ctx *c, const char *rows, size_t stride, size_t n
     TRY(upload(c, c->s_rows, rows, stride * n, &d_rows));
     TRY(scratch(c, c->s_irr, n, &d_irr));
     hipLaunchKernelGGL(map_insert_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u8 *)d_rows, stride, n, view(c),
-                       (u32)c->map.rows_total, (u8 *)d_irr);
+                       view(c, MG_BF_ALT), (u32)c->map.rows_total, (u8 *)d_irr);
     HIP_TRY(c, hipGetLastError());
     std::vector<u8> irr(n);
     HIP_TRY(c, hipMemcpyAsync(irr.data(), d_irr, n, hipMemcpyDeviceToHost, c->stream));
@@ -1135,22 +1250,34 @@ MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 // ---- KMC scan ----------------------------------------------------------------------------
 
 namespace {
-template <int KC, int RC>
-int launch_scan(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, u32 *hit_row, u64 *hit_idx)
+template <int KC, int RC, int ROWS>
+void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, u64 n, u32 *open_row, u64 *open_lo, u64 *open_hi)
 {
-    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 256u * 16u);
-    hipLaunchKernelGGL((scan_filter_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, n, (int)c->k,
-                       (int)c->ref_k, view(c, MG_BF_ALT), view(c), hit_row, hit_idx, c->d_hit_count);
-    return MG_OK;
+    const u64 per_block = (u64)TPB * ROWS;
+    const unsigned grid = (unsigned)std::min<u64>((n + per_block - 1) / per_block, (u64)c->scan_grid);
+    hipLaunchKernelGGL((scan_filter_kernel<KC, RC, ROWS>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, n, (int)c->k,
+                       (int)c->ref_k, view(c, MG_BF_ALT), open_row, open_lo, open_hi, c->d_hit_count, c->scan_ablate);
 }
 template <int KC, int RC>
-int launch_hits(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n_rows, const u32 *hit_row, const u64 *hit_idx)
+void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, u32 *open_row, u64 *open_lo,
+                       u64 *open_hi, u32 *hit_row, bool timed)
 {
-    // the hit count lives on the device; a fixed grid walks it with a stride, so no host round trip
-    const unsigned grid = (unsigned)std::min<u64>(nblocks(n_rows), 1024u);
-    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, (int)c->ref_k,
-                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), hit_row, hit_idx, c->d_hit_count);
-    return MG_OK;
+    if (timed) hipEventRecord(c->ev[0], c->stream);
+    switch (c->scan_rows) {
+    case 1: launch_filter_rows<KC, RC, 1>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
+    case 2: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
+    case 8: launch_filter_rows<KC, RC, 8>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
+    default: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
+    }
+    if (timed) hipEventRecord(c->ev[1], c->stream);
+    // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
+    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 2048u);
+    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_cnt, (int)c->k, view(c, MG_BF_ALT),
+                       view(c), (const u32 *)open_row, (const u64 *)open_lo, (const u64 *)open_hi, hit_row, c->d_hit_count);
+    if (timed) hipEventRecord(c->ev[2], c->stream);
+    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, 1024u)), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt,
+                       (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX), (const u32 *)hit_row, c->d_hit_count);
+    if (timed) hipEventRecord(c->ev[3], c->stream);
 }
 } // namespace
 
@@ -1163,28 +1290,24 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.tags) TRY(map_reserve(c, 0));
-    const u64 chunk = 1ULL << 28; // rows per launch pair; hit rows are u32 offsets inside a chunk
-    void *hr, *hx;
-    const u64 cap = n < chunk ? n : chunk;
-    TRY(scratch(c, c->s_hitrow, cap * 4, &hr));
-    TRY(scratch(c, c->s_hitidx, cap * 8, &hx));
+    const u64 chunk = 1ULL << 27; // rows per launch triple; list entries are u32 offsets inside a chunk
+    void *orow, *olo, *ohi, *hrow;
+    const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
+    TRY(scratch(c, c->s_hitrow, cap * 4, &orow));
+    TRY(scratch(c, c->s_hitidx, cap * 4, &hrow));
+    TRY(scratch(c, c->s_openlo, cap * 8, &olo));
+    TRY(scratch(c, c->s_openhi, cap * 8, &ohi));
     const bool d35_43 = c->k == 35 && c->ref_k == 43;
     c->stats_valid = false;
-    HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
     for (u64 r0 = 0; r0 < n; r0 += chunk) {
         const u64 nr = n - r0 < chunk ? n - r0 : chunk;
         const u64 *ph = (const u64 *)d_hi + r0, *pl = (const u64 *)d_lo + r0;
         const u32 *pc = (const u32 *)d_cnt + r0;
-        if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 8, c->stream));
-        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-        if (d35_43) launch_scan<35, 43>(c, ph, pl, pc, nr, (u32 *)hr, (u64 *)hx);
-        else launch_scan<0, 0>(c, ph, pl, pc, nr, (u32 *)hr, (u64 *)hx);
+        if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
+        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, (u32 *)orow, (u64 *)olo, (u64 *)ohi, (u32 *)hrow, r0 == 0);
+        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, (u32 *)orow, (u64 *)olo, (u64 *)ohi, (u32 *)hrow, r0 == 0);
         HIP_TRY(c, hipGetLastError());
-        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-        if (d35_43) launch_hits<35, 43>(c, ph, pl, pc, nr, (const u32 *)hr, (const u64 *)hx);
-        else launch_hits<0, 0>(c, ph, pl, pc, nr, (const u32 *)hr, (const u64 *)hx);
-        HIP_TRY(c, hipGetLastError());
-        if (r0 == 0) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     }
     c->stats_valid = true;
     return MG_OK;
@@ -1212,15 +1335,17 @@ MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 {
     if (!c) return MG_ERR_ARG;
     if (!c->stats_valid) return fail(c, MG_ERR_STATE, "no scan has run");
-    HIP_TRY(c, hipEventSynchronize(c->ev[2]));
+    HIP_TRY(c, hipEventSynchronize(c->ev[3]));
     if (ms_out) {
         HIP_TRY(c, hipEventElapsedTime(&ms_out[0], c->ev[0], c->ev[1]));
         HIP_TRY(c, hipEventElapsedTime(&ms_out[1], c->ev[1], c->ev[2]));
+        HIP_TRY(c, hipEventElapsedTime(&ms_out[2], c->ev[2], c->ev[3]));
     }
     if (n_hits) {
-        unsigned long long t[2] = {0, 0};
-        HIP_TRY(c, hipMemcpy(t, c->d_hit_count, 16, hipMemcpyDeviceToHost));
-        *n_hits = t[1];
+        unsigned long long t[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpy(t, c->d_hit_count, 32, hipMemcpyDeviceToHost));
+        n_hits[0] = t[0]; // open rows of the last chunk
+        n_hits[1] = t[2]; // bf hit rows of the whole call
     }
     return MG_OK;
 }
@@ -1455,6 +1580,15 @@ MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, c
     if (!words) return fail(c, MG_ERR_ARG, "words is NULL");
     HIP_TRY(c, hipMemcpy(b.words, words, b.nwords * 8, hipMemcpyHostToDevice));
     b.mode = 0;
+    if (which == MG_BF_ALT) { // the gate follows the bits: rebuild it from them and from the map's keys
+        TRY(alloc_gate(c));
+        hipLaunchKernelGGL(gate_from_bits_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), b.nwords);
+        if (c->map.tags)
+            hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
+                               view(c, MG_BF_ALT));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     if (mode) {
         TRY(mg_bf_finalize(c, which)); // rank is rebuilt on load, as bloom_filter.hpp:143 does
         if (n_counts != b.nset) return fail(c, MG_ERR_ARG, "counter count %llu != popcount %llu", (unsigned long long)n_counts,

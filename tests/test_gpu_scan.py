@@ -30,7 +30,7 @@ def _scan_case(k, ref_k, bf_bits, n_vars, n_rows, seed, use_summary=1, genome_ed
     _, _, _, counts = ctx.bf_export(BF_ALT)
     assert np.array_equal(counts, obf.counts())
     assert map_values_by_key(ctx) == dict(omap.items())
-    ms_f, ms_h, n_hits = ctx.scan_stats()
+    _, _, _, n_open, n_hits = ctx.scan_stats()
     ctx.close()
     return obf, octx, n_hits
 
