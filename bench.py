@@ -128,6 +128,8 @@ def main():
     d_g2 = torch.zeros(n_vars, dtype=torch.int32, device=dev)
     d_gq = torch.zeros(n_vars, dtype=torch.int32, device=dev)
     d_st = torch.zeros(n_vars, dtype=torch.uint8, device=dev)
+    d_goff = dev_i64((3 * np.arange(n_vars + 1)).astype(np.uint64))       # biallelic diploid: 3 genotypes per variant
+    d_probs = torch.zeros(3 * n_vars, dtype=torch.float64, device=dev)   # normalised likelihoods (GTS) + workspace
     n_bf, n_map = ctx.counters_size()
     d_counters = torch.zeros(n_bf + n_map, dtype=torch.int32, device=dev)
 
@@ -142,7 +144,7 @@ def main():
             ctx.counters_import_device(d_counters.data_ptr())
         ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
                                  d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
-                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr(), d_probs.data_ptr(), d_goff.data_ptr())
         if record:
             scan_ms.append(ctx.scan_stats())     # waits on the scan's own events only
 
@@ -175,7 +177,7 @@ def main():
         e0.record()
         ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
                                  d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
-                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+                                 d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr(), d_probs.data_ptr(), d_goff.data_ptr())
         e1.record()
         e1.synchronize()
         geno_ms.append(e0.elapsed_time(e1))
@@ -224,7 +226,7 @@ def main():
                                                   sub.pool[:2 * nv], sub.freq[:2 * nv], sub.present_mask[:nv], sub.flags[:nv], K, 0.001, 200, False)
         cpu_geno_s = time.perf_counter() - t0
         ctx.call_isolated_device(nv, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(), d_pm.data_ptr(),
-                                 d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(), d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr())
+                                 d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(), d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr(), d_probs.data_ptr(), d_goff.data_ptr())
         torch.cuda.synchronize()
         ok_gt = bool(np.array_equal(d_g1[:nv].cpu().numpy(), og1) and np.array_equal(d_g2[:nv].cpu().numpy(), og2)
                      and np.array_equal(d_gq[:nv].cpu().numpy(), ogq) and np.array_equal(d_cov[:2 * nv].cpu().numpy().view(np.uint32), ocov))

@@ -155,17 +155,22 @@ int mg_genotype(mg_ctx *ctx, const uint32_t *cov, const float *freq, const uint3
  * contigs already uploaded with mg_reference_upload; pos[v] is the variant's
  * offset in that buffer.  flags bit0: eligible (is_present and not within k of
  * a contig end, var_block.hpp:104).  present_mask bit a: some panel haplotype
- * carries allele a (build_alleles_combs, var_block.hpp:734-786). */
+ * carries allele a (build_alleles_combs, var_block.hpp:734-786).  probs (optional):
+ * normalised likelihood lists at caller-provided var_gt_off, as in mg_genotype. */
 int mg_reference_upload(mg_ctx *ctx, const char *ascii, size_t len);
 int mg_call_isolated(mg_ctx *ctx, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off,
                      const uint32_t *allele_off, const char *allele_pool, size_t pool_len, const float *freq,
                      const uint64_t *present_mask, const uint8_t *flags, float error_rate, int max_cov, int haploid,
-                     uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status);
-/* same, every array already resident on the device (asynchronous) */
+                     uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status, double *probs,
+                     const uint64_t *var_gt_off);
+/* same, every array already resident on the device (asynchronous).  d_probs / d_var_gt_off
+ * (both or neither; as in mg_genotype) double as the workspace that saves recomputing
+ * each likelihood for the normalisation pass. */
 int mg_call_isolated_device(mg_ctx *ctx, size_t n_vars, const void *d_pos, const void *d_var_allele_off,
                             const void *d_allele_off, const void *d_allele_pool, const void *d_freq,
                             const void *d_present_mask, const void *d_flags, float error_rate, int max_cov,
-                            int haploid, void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status);
+                            int haploid, void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status,
+                            void *d_probs, const void *d_var_gt_off);
 
 /* ---- index payloads  (bloom_filter.hpp:127-146, kmap.hpp:52-82) ----------- */
 

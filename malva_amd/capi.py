@@ -58,8 +58,8 @@ def lib():
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_reference_upload": [vp, vp, sz],
-        "mg_call_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp],
-        "mg_call_isolated_device": [vp, sz, vp, vp, vp, vp, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp],
+        "mg_call_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp, vp, vp],
+        "mg_call_isolated_device": [vp, sz, vp, vp, vp, vp, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp, vp, vp],
         "mg_bf_export": [vp, it, vp, vp],
         "mg_bf_import": [vp, it, it, u64, vp, vp, u64],
         "mg_map_export": [vp, vp, sz, vp],
@@ -323,7 +323,7 @@ class Context:
         self._ck(self._L.mg_reference_upload(self.h, _p(buf), buf.size))
 
     def call_isolated(self, pos, var_allele_off, allele_off, allele_pool, freq, present_mask, flags, error_rate,
-                      max_cov, haploid):
+                      max_cov, haploid, want_probs=False):
         pos = np.ascontiguousarray(pos, dtype=np.uint64)
         vo = np.ascontiguousarray(var_allele_off, dtype=np.uint32)
         ao = np.ascontiguousarray(allele_off, dtype=np.uint32)
@@ -338,14 +338,22 @@ class Context:
         g2 = np.zeros(n, dtype=np.int32)
         gq = np.zeros(n, dtype=np.int32)
         st = np.zeros(n, dtype=np.uint8)
+        probs = goff = None
+        if want_probs:
+            A = np.diff(vo.astype(np.int64))
+            goff = np.zeros(n + 1, dtype=np.uint64)
+            goff[1:] = np.cumsum(A if haploid else A * (A + 1) // 2)
+            probs = np.zeros(int(goff[-1]), dtype=np.float64)
         self._ck(self._L.mg_call_isolated(self.h, n, _p(pos), _p(vo), _p(ao), _p(pool), pool.size, _p(freq), _p(pm),
                                           _p(fl), C.c_float(error_rate), max_cov, int(haploid), _p(cov), _p(g1), _p(g2),
-                                          _p(gq), _p(st)))
+                                          _p(gq), _p(st), _p(probs), _p(goff)))
+        if want_probs:
+            return cov, g1, g2, gq, st, probs, goff
         return cov, g1, g2, gq, st
 
     def call_isolated_device(self, n, d_pos, d_vo, d_ao, d_pool, d_freq, d_pm, d_flags, error_rate, max_cov, haploid,
-                             d_cov, d_g1, d_g2, d_gq, d_st):
+                             d_cov, d_g1, d_g2, d_gq, d_st, d_probs=None, d_gt_off=None):
         v = C.c_void_p
         self._ck(self._L.mg_call_isolated_device(self.h, n, v(d_pos), v(d_vo), v(d_ao), v(d_pool), v(d_freq), v(d_pm),
                                                  v(d_flags), C.c_float(error_rate), max_cov, int(haploid), v(d_cov),
-                                                 v(d_g1), v(d_g2), v(d_gq), v(d_st)))
+                                                 v(d_g1), v(d_g2), v(d_gq), v(d_st), v(d_probs), v(d_gt_off)))

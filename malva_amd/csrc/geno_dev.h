@@ -149,18 +149,29 @@ __device__ inline void genotype_one(const u32 *cov, const float *freq, int A, co
         return;
     }
     *status = 0;
+    // pass 1: raw values (kept in `probs` when the caller gave room for them), total in list order
     double sum = 0.0;
-    if (p.haploid) {
-        for (int g = 0; g < A; ++g) sum += gt_value(cov, freq, A, total, g, -1, p);
-    } else {
-        for (int g1 = 0; g1 < A; ++g1)
-            for (int g2 = g1; g2 < A; ++g2) sum += gt_value(cov, freq, A, total, g1, g2, p);
-    }
-    double best = 0.0;
     int n = 0;
     if (p.haploid) {
         for (int g = 0; g < A; ++g, ++n) {
-            const double q = gt_value(cov, freq, A, total, g, -1, p) / sum;
+            const double val = gt_value(cov, freq, A, total, g, -1, p);
+            if (probs) probs[n] = val;
+            sum += val;
+        }
+    } else {
+        for (int g1 = 0; g1 < A; ++g1)
+            for (int g2 = g1; g2 < A; ++g2, ++n) {
+                const double val = gt_value(cov, freq, A, total, g1, g2, p);
+                if (probs) probs[n] = val;
+                sum += val;
+            }
+    }
+    // pass 2: normalise, first strictly greater wins
+    double best = 0.0;
+    n = 0;
+    if (p.haploid) {
+        for (int g = 0; g < A; ++g, ++n) {
+            const double q = (probs ? probs[n] : gt_value(cov, freq, A, total, g, -1, p)) / sum;
             if (probs) probs[n] = q;
             if (q > best) {
                 best = q;
@@ -171,7 +182,7 @@ __device__ inline void genotype_one(const u32 *cov, const float *freq, int A, co
     } else {
         for (int g1 = 0; g1 < A; ++g1)
             for (int g2 = g1; g2 < A; ++g2, ++n) {
-                const double q = gt_value(cov, freq, A, total, g1, g2, p) / sum;
+                const double q = (probs ? probs[n] : gt_value(cov, freq, A, total, g1, g2, p)) / sum;
                 if (probs) probs[n] = q;
                 if (q > best) {
                     best = q;

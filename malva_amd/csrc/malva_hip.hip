@@ -550,11 +550,51 @@ struct SigIn {
         return i < mp ? ref_left[i] : (i < mp + alen ? allele[i - mp] : ref_right[i - mp - alen]);
     }
 };
+// weight of one signature k-mer given as bytes: KMAP::get_count (allele 0) or BF::get_count
+template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, int k, bool is_ref, const BFView &bf, const MapView &map)
+{
+    CanonBytes<IN> can(in, k);
+    if (is_ref) {
+        U128 key;
+        if (pack_regular(can, k, (int)map.klen, &key)) {
+            const long long s = map_find(map, key, xxh3_bytes(can, k));
+            if (s >= 0) return (i32)map.vals[map.ids[s]];
+        }
+        return 0;
+    }
+    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
+    return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+}
+// 2-bit code of an upper-case ACGT byte without a table: (b >> 1) & 3 gives A0 C1 G3 T2
+__device__ __forceinline__ u32 acgt_code(u32 b, bool *ok)
+{
+    *ok = b == 'A' || b == 'C' || b == 'G' || b == 'T';
+    const u32 c = (b >> 1) & 3;
+    return c ^ (c >> 1);
+}
+__device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
+{
+    U128 r;
+    if (s == 0) return v;
+    if (s < 64) {
+        r.hi = (v.hi << s) | (v.lo >> (64 - s));
+        r.lo = v.lo << s;
+    } else {
+        r.hi = v.lo << (s - 64);
+        r.lo = 0;
+    }
+    return r;
+}
+// Fast path: both flanks and the allele are pure ACGT, so the signature is assembled in
+// 2-bit form from flanks packed once per variant (shared by its alleles), canonicalised
+// with integer compares and hashed with the register-resident XXH3 -- the same code the
+// scan uses.  Anything else (N / IUPAC in the window, k outside 17..64) takes weight_bytes.
 __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference, u64 n_vars, const u64 *pos,
                                                             const u32 *var_allele_off, const u32 *allele_off,
                                                             const u8 *pool, const float *freq, const u64 *present_mask,
                                                             const u8 *flags, int k, BFView bf, MapView map, GenoParams p,
-                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status)
+                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
+                                                            double *probs, const u64 *var_gt_off)
 {
     const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
     if (v >= n_vars) return;
@@ -564,28 +604,68 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
     for (u32 a = 0; a < A; ++a) cov[a] = 0;
     if (flags[v] & 1) {
         const u64 pm = present_mask[v];
+        const u8 *site = reference + pos[v];
+        const int lmax = k / 2, rmax = (k + 1) / 2;
+        const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
+        // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
+        u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
+        if (packed_ok) {
+            for (int i = 0; i < lmax; ++i) {
+                bool ok;
+                lf |= (u64)acgt_code(site[i - lmax], &ok) << (2 * i);
+                lbad |= (u64)!ok << i;
+            }
+            for (int i = 0; i < rmax; ++i) {
+                bool ok;
+                rf |= (u64)acgt_code(site[ref_size + i], &ok) << (2 * i);
+                rbad |= (u64)!ok << i;
+            }
+        }
         for (u32 a = 0; a < A && a < 64; ++a) {
             if (!((pm >> a) & 1)) continue;
             const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
             const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
             if (mp < 0 || ms < 0) continue; // alleles >= k take the general path (host contract)
-            SigIn in{reference + pos[v] - mp, pool + allele_off[a0 + a], reference + pos[v] + ref_size, mp, alen};
-            CanonBytes<SigIn> can(in, k);
-            i32 w = 0;
-            if (a == 0) {
-                U128 key;
-                if (pack_regular(can, k, (int)map.klen, &key)) {
-                    const long long s = map_find(map, key, xxh3_bytes(can, k));
-                    if (s >= 0) w = (i32)map.vals[map.ids[s]];
+            const u8 *al = pool + allele_off[a0 + a];
+            bool fast = packed_ok && (lbad >> (lmax - mp)) == 0 && (ms == 0 || (rbad & ((1ULL << ms) - 1)) == 0);
+            U128 L{0, 0};
+            if (fast) {
+                for (int i = 0; i < alen; ++i) {
+                    bool ok;
+                    const u64 code = acgt_code(al[i], &ok);
+                    fast &= ok;
+                    if (i < 32) L.lo |= code << (2 * i);
+                    else L.hi |= code << (2 * (i - 32));
+                }
+            }
+            i32 w;
+            if (fast) {
+                L = shl128(L, 2 * mp);
+                if (mp) L.lo |= lf >> (2 * (lmax - mp));                         // last mp bases of the left flank
+                if (ms) {
+                    const U128 r = shl128(U128{ms >= 32 ? rf : rf & ((1ULL << (2 * ms)) - 1), 0}, 2 * (mp + alen));
+                    L.lo |= r.lo;
+                    L.hi |= r.hi;
+                }
+                const U128 mk = mask128(2 * k);
+                const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - k)); // M-form of the k-mer
+                const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
+                const U128 key = lt128(L, rc) ? L : rc;
+                const u64 h = xxh3_packed(key, k);
+                if (a == 0) {
+                    const long long s = map_find(map, key, h);
+                    w = s >= 0 ? (i32)map.vals[map.ids[s]] : 0;
+                } else {
+                    const u64 idx = mod_size(h, bf.mod);
+                    w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
                 }
             } else {
-                const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
-                if (bf_bit(bf, idx)) w = (i32)(uint16_t)bf.counts[bf_rank(bf, idx)];
+                w = weight_bytes(SigIn{site - mp, al, site + ref_size, mp, alen}, k, a == 0, bf, map);
             }
             if (w > 0) cov[a] = (u32)(float)(u32)w;
         }
     }
-    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, nullptr);
+    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
 }
 
 } // namespace
@@ -1491,7 +1571,8 @@ MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_pos, const void *d_var_allele_off,
                                       const void *d_allele_off, const void *d_allele_pool, const void *d_freq,
                                       const void *d_present_mask, const void *d_flags, float error_rate, int max_cov, int haploid,
-                                      void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status)
+                                      void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs,
+                                      const void *d_var_gt_off)
 {
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
@@ -1503,7 +1584,8 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
     hipLaunchKernelGGL(call_isolated_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
                        (const float *)d_freq, (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT),
-                       view(c), p, (u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status);
+                       view(c), p, (u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status, (double *)d_probs,
+                       (const u64 *)d_var_gt_off);
     HIP_TRY(c, hipGetLastError());
     return MG_OK;
 }
@@ -1511,13 +1593,15 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
 MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off,
                                const uint32_t *allele_off, const char *allele_pool, size_t pool_len, const float *freq,
                                const uint64_t *present_mask, const uint8_t *flags, float error_rate, int max_cov, int haploid,
-                               uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status)
+                               uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status, double *probs,
+                               const uint64_t *var_gt_off)
 {
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!pos || !var_allele_off || !allele_off || !allele_pool || !freq || !present_mask || !flags || !cov_out || !gt1 || !gt2 ||
         !gq || !status)
         return fail(c, MG_ERR_ARG, "NULL argument");
+    if (probs && !var_gt_off) return fail(c, MG_ERR_ARG, "probs needs var_gt_off");
     const size_t na = var_allele_off[n_vars];
     // host-side contract checks: every window the kernel will read lies inside the uploaded reference
     for (size_t v = 0; v < n_vars; ++v)
@@ -1541,8 +1625,24 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
     TRY(scratch(c, c->s_misc[6], 4 * n_vars, &d_g2));
     TRY(scratch(c, c->s_misc[7], 4 * n_vars, &d_gq));
     TRY(scratch(c, c->s_irr, n_vars, &d_st));
+    // raw likelihoods are staged in a device workspace either way (one exp() per genotype instead of two)
+    std::vector<u64> goff_tmp;
+    if (!var_gt_off) {
+        goff_tmp.resize(n_vars + 1);
+        goff_tmp[0] = 0;
+        for (size_t v = 0; v < n_vars; ++v) {
+            const u64 A = var_allele_off[v + 1] - var_allele_off[v];
+            goff_tmp[v + 1] = goff_tmp[v] + (haploid ? A : A * (A + 1) / 2);
+        }
+        var_gt_off = goff_tmp.data();
+    }
+    const size_t ng = var_gt_off[n_vars];
+    void *d_pr, *d_go;
+    TRY(scratch(c, c->s_hitrow, 8 * (ng ? ng : 1), &d_pr));
+    TRY(upload(c, c->s_hitidx, var_gt_off, 8 * (n_vars + 1), &d_go));
     TRY(mg_call_isolated_device(c, n_vars, d_pos, d_vo, d_ao, d_pool, d_fr, d_pm, d_fl, error_rate, max_cov, haploid, d_cov, d_g1,
-                                d_g2, d_gq, d_st));
+                                d_g2, d_gq, d_st, d_pr, d_go));
+    if (probs && ng) HIP_TRY(c, hipMemcpyAsync(probs, d_pr, 8 * ng, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * na, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(gt1, d_g1, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(gt2, d_g2, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));

@@ -129,6 +129,9 @@ def test_call_isolated_mixed_variants(haploid):
     """fused device path vs the oracle's loop-B restatement on SNPs, MNPs, indels, 2-3 alleles"""
     k, ref_k, bits = 35, 43, 1 << 24
     panel = synth.mixed_panel(3000, 31 + haploid, k=k)
+    # every 7th variant gets a non-ACGT base inside its window: those take the byte-wise path on the device
+    for v in range(0, panel.n, 7):
+        panel.genome[panel.pos[v] - 1 - (v % 15)] = ord("N") if v % 2 else ord("R")
     ctx = Context(k, ref_k, bits)
     obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
     # weights: every signature k-mer gets a random count, through the ASCII increment API on both sides
@@ -138,6 +141,9 @@ def test_call_isolated_mixed_variants(haploid):
     rng = np.random.default_rng(77)
     w = rng.integers(0, 70, size=rows.shape[0]).astype(np.uint32)
     w[rng.random(rows.shape[0]) < 0.02] = 250        # some over-covered alleles
+    # REF signatures holding a non-ACGT byte are exact-map keys no KMC k-mer can ever match, so a scan
+    # leaves them at 0; the fused device path relies on that (they live in the host-side overflow list)
+    w[(is_ref == 1) & ~(synth.CODE[rows] <= 3).all(axis=1)] = 0
     sel = valid & (w > 0)
     pr = pad_rows(rows[sel])
     for r, isr, c in zip(pr, is_ref[sel], w[sel]):
@@ -149,9 +155,18 @@ def test_call_isolated_mixed_variants(haploid):
                                               panel.var_allele_off, panel.pool, panel.freq, panel.present_mask,
                                               panel.flags & 1, k, 0.001, 200, haploid)
     ctx.reference_upload(panel.genome)
-    cov, g1, g2, gq, st = ctx.call_isolated(panel.pos.astype(np.uint64), panel.var_allele_off, panel.allele_off, panel.pool,
-                                            panel.freq, panel.present_mask, panel.flags, 0.001, 200, haploid)
+    cov, g1, g2, gq, st, probs, goff = ctx.call_isolated(panel.pos.astype(np.uint64), panel.var_allele_off, panel.allele_off,
+                                                         panel.pool, panel.freq, panel.present_mask, panel.flags, 0.001, 200,
+                                                         haploid, want_probs=True)
     assert np.array_equal(cov, ocov)
     assert np.array_equal(g1, og1) and np.array_equal(g2, og2) and np.array_equal(gq, ogq)
+    for v in range(0, panel.n, 5):
+        if st[v] != GT_NORMAL:
+            continue
+        a0, a1 = int(panel.var_allele_off[v]), int(panel.var_allele_off[v + 1])
+        _, _, _, norm, _ = _oracle_variant(ocov[a0:a1], panel.freq[a0:a1], haploid)
+        pv = probs[int(goff[v]):int(goff[v + 1])]
+        both_nan = np.isnan(pv) & np.isnan(norm)
+        assert np.all(both_nan | (np.abs(pv - norm) <= TOL)), v
     assert (st == GT_OVERCOV).any() and (st == GT_NOCOV).any() and (st == GT_NORMAL).any()
     ctx.close()
