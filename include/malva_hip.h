@@ -179,6 +179,11 @@ int mg_call_isolated_device(mg_ctx *ctx, size_t n_vars, const void *d_pos, const
 int mg_bf_export(mg_ctx *ctx, int which, uint64_t *words_out, uint16_t *counts_out);
 int mg_bf_import(mg_ctx *ctx, int which, int mode, uint64_t size_bits, const uint64_t *words,
                  const uint16_t *counts, uint64_t n_counts);
+/* The same payload in sparse form (what the index file holds): the n_set ascending
+ * bit positions (= counter order) and the counters.  Export needs a finalised filter. */
+int mg_bf_export_sparse(mg_ctx *ctx, int which, uint64_t *positions_out, uint16_t *counts_out);
+int mg_bf_import_sparse(mg_ctx *ctx, int which, int mode, uint64_t size_bits, const uint64_t *positions,
+                        const uint16_t *counts, uint64_t n);
 /* KMAP: n keys as NUL-terminated rows of `stride` bytes + values */
 int mg_map_export(mg_ctx *ctx, char *rows_out, size_t stride, int32_t *vals_out);
 int mg_map_import(mg_ctx *ctx, const char *rows, size_t stride, size_t n, const int32_t *vals);

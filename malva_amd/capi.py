@@ -62,6 +62,8 @@ def lib():
         "mg_call_isolated_device": [vp, sz, vp, vp, vp, vp, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp, vp, vp],
         "mg_bf_export": [vp, it, vp, vp],
         "mg_bf_import": [vp, it, it, u64, vp, vp, u64],
+        "mg_bf_export_sparse": [vp, it, vp, vp],
+        "mg_bf_import_sparse": [vp, it, it, u64, vp, vp, u64],
         "mg_map_export": [vp, vp, sz, vp],
         "mg_map_import": [vp, vp, sz, sz, vp],
         "mg_debug_bf_index": [vp, it, vp, sz, sz, vp],
@@ -84,7 +86,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset",
             "mg_lookup_cover", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
-            "mg_bf_export", "mg_bf_import", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
+            "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_set_option"]
 
 
@@ -203,6 +205,19 @@ class Context:
         counts = np.ascontiguousarray(counts, dtype=np.uint16)
         self._ck(self._L.mg_bf_import(self.h, which, int(mode), size, _p(words), _p(counts) if counts.size else None,
                                       counts.size))
+
+    def bf_export_sparse(self, which):
+        size, nset, mode = self.bf_info(which)
+        pos = np.zeros(nset, dtype=np.uint64)
+        counts = np.zeros(nset, dtype=np.uint16)
+        self._ck(self._L.mg_bf_export_sparse(self.h, which, _p(pos) if nset else None, _p(counts) if nset else None))
+        return mode, size, pos, counts
+
+    def bf_import_sparse(self, which, mode, size, pos, counts):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        self._ck(self._L.mg_bf_import_sparse(self.h, which, int(mode), size, _p(pos) if pos.size else None,
+                                             _p(counts) if counts.size else None, pos.size))
 
     # KMAP
     def map_insert(self, rows):

@@ -253,6 +253,31 @@ __global__ void __launch_bounds__(TPB) gate_from_bits_kernel(BFView bf, u64 nwor
         x &= x - 1;
     }
 }
+// positions of the set bits in ascending (= counter) order; needs the rank directory
+__global__ void __launch_bounds__(TPB) bit_positions_kernel(BFView bf, u64 nwords, u64 *out)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 x = bf.words[w];
+    if (!x) return;
+    u64 r = bf_rank(bf, w * 64);
+    while (x) {
+        out[r++] = w * 64 + (u64)(__ffsll((unsigned long long)x) - 1);
+        x &= x - 1;
+    }
+}
+__global__ void __launch_bounds__(TPB) set_bits_kernel(BFView bf, const u64 *pos, u64 n, u64 size, int *bad)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u64 p = pos[i];
+    if (p >= size || (i && pos[i - 1] >= p)) {
+        *bad = 1; // out of range or not strictly ascending
+        return;
+    }
+    atomicOr((unsigned long long *)&bf.words[p >> 6], 1ULL << (p & 63));
+    gate_set(bf, p);
+}
 __global__ void __launch_bounds__(TPB) mask_u16_kernel(const u32 *in, uint16_t *out, u64 n)
 {
     const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
@@ -1698,6 +1723,68 @@ MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, c
             TRY(upload(c, c->s_out, counts, n_counts * 2, &d16));
             hipLaunchKernelGGL(widen_u16_kernel, dim3(nblocks(n_counts)), dim3(TPB), 0, c->stream, (const uint16_t *)d16, b.counts,
                                n_counts);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    return MG_OK;
+}
+
+// Sparse payloads: a filter is a few million set bits in 2^33..2^37, so the index file stores the
+// ascending positions of the set bits (= counter order) instead of gigabytes of zeros.
+MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out, uint16_t *counts_out)
+{
+    TRY(check_which(c, which));
+    BFState &b = c->bf[which];
+    if (!b.mode) return fail(c, MG_ERR_STATE, "sparse export needs the filter finalised (rank directory)");
+    if (positions_out && b.nset) {
+        void *d;
+        TRY(scratch(c, c->s_openlo, b.nset * 8, &d));
+        hipLaunchKernelGGL(bit_positions_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, which), b.nwords, (u64 *)d);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(positions_out, d, b.nset * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (counts_out) return mg_bf_export(c, which, nullptr, counts_out);
+    return MG_OK;
+}
+MG_EXPORT int mg_bf_import_sparse(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *positions,
+                                  const uint16_t *counts, uint64_t n)
+{
+    TRY(check_which(c, which));
+    BFState &b = c->bf[which];
+    if (size_bits != b.size) return fail(c, MG_ERR_ARG, "filter size %llu does not match the context (%llu)",
+                                         (unsigned long long)size_bits, (unsigned long long)b.size);
+    if (n && !positions) return fail(c, MG_ERR_ARG, "positions is NULL");
+    HIP_TRY(c, hipMemsetAsync(b.words, 0, b.nwords * 8, c->stream));
+    b.mode = 0;
+    if (which == MG_BF_ALT) {
+        TRY(alloc_gate(c));
+        if (c->map.tags)
+            hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
+                               view(c, MG_BF_ALT));
+        c->gate_dirty = true;
+    }
+    if (n) {
+        void *d;
+        int *d_bad = (int *)(c->d_hit_count + 3);
+        TRY(upload(c, c->s_openlo, positions, n * 8, &d));
+        HIP_TRY(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+        hipLaunchKernelGGL(set_bits_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, view(c, which), (const u64 *)d, (u64)n, b.size,
+                           d_bad);
+        HIP_TRY(c, hipGetLastError());
+        int bad = 0;
+        HIP_TRY(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (bad) return fail(c, MG_ERR_ARG, "bit positions must be strictly ascending and below the filter size");
+    }
+    if (mode) {
+        TRY(mg_bf_finalize(c, which));
+        if (b.nset != n) return fail(c, MG_ERR_ARG, "popcount %llu != positions %llu", (unsigned long long)b.nset, (unsigned long long)n);
+        if (n && counts) {
+            void *d16;
+            TRY(upload(c, c->s_out, counts, n * 2, &d16));
+            hipLaunchKernelGGL(widen_u16_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const uint16_t *)d16, b.counts, (u64)n);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }

@@ -1,0 +1,240 @@
+// Variant block: which variants are near enough to share k-mers, which chains of
+// neighbours a variant can be combined with, and the signature k-mers of every
+// allele.  Host-side restatement of VB (var_block.hpp:61-219, 408-786): this is
+// the irregular, allocation-heavy part of the path ("Irregular
+// enumeration"); it emits flat descriptors for mg_lookup_cover / mg_genotype, and
+// blocks that hold one short-allele variant bypass it (mg_call_isolated).
+#pragma once
+#include <set>
+
+#include "io.hpp"
+
+namespace malva {
+
+// std::string(s, pos, n): clips at the end, throws when pos > size (as the reference would)
+inline std::string substr_clip(const std::string &s, long pos, long n)
+{
+    if (pos < 0 || (size_t)pos > s.size()) throw std::out_of_range("reference window outside the contig");
+    if (n < 0) n = 0;
+    return s.substr((size_t)pos, (size_t)n);
+}
+
+// signatures[variant][allele] = list of signatures, each a list of k-mers  (VK_GROUP, var_block.hpp:33)
+using AlleleSignatures = std::map<int, std::vector<std::vector<std::string>>>;
+
+class Block {
+  public:
+    std::vector<Variant> vars;
+    int k;
+    explicit Block(int k_) : k(k_) {}
+    bool empty() const { return vars.empty(); }
+    void clear() { vars.clear(); }
+    void add(Variant &&v) { vars.push_back(std::move(v)); }
+
+    // var_block.hpp:408-412
+    static bool overlapping(const Variant &a, const Variant &b) { return a.ref_pos <= b.ref_pos && b.ref_pos < a.ref_pos + a.ref_size; }
+    // var_block.hpp:417-423: v1.pos + v1.ref_size - v1.min_size - 1 + extra + ceil(k/2) >= v2.pos
+    bool near(const Variant &a, const Variant &b, int extra = 0) const
+    {
+        return a.ref_pos + a.ref_size - a.min_size - 1 + extra + (k + 1) / 2 >= b.ref_pos;
+    }
+    bool near_to_last(const Variant &v) const { return near(vars.back(), v); } // var_block.hpp:77-80
+
+    // One variant, every allele shorter than k: the only chain is the variant itself and each allele
+    // carried by the panel has exactly one signature k-mer -- the case mg_call_isolated fuses on the device.
+    bool is_lone_short() const
+    {
+        if (vars.size() != 1) return false;
+        if (vars[0].ref_size >= k) return false;
+        for (const auto &a : vars[0].alts)
+            if ((int)a.size() >= k) return false;
+        return vars[0].n_alleles() <= 64;
+    }
+
+    // get_combs_on_the_right (step +1) / _left (step -1), var_block.hpp:436-525, 534-624.  The two are
+    // mirror images; ordered(x, y) puts the pair in genome order as the reference's argument order does.
+    std::vector<std::vector<int>> chains(int i, int step) const
+    {
+        const Variant &mid = vars[(size_t)i];
+        std::vector<std::vector<int>> out;
+        std::vector<int> sums;
+        auto ov = [&](const Variant &x, const Variant &y) { return step > 0 ? overlapping(x, y) : overlapping(y, x); };
+        auto nr = [&](const Variant &x, const Variant &y, int extra) { return step > 0 ? near(x, y, extra) : near(y, x, extra); };
+        bool halt = false;
+        for (int j = i + step; j >= 0 && j < (int)vars.size() && !halt; j += step) {
+            const Variant &cur = vars[(size_t)j];
+            if (!cur.is_present) continue;
+            if (ov(mid, cur)) continue;
+            const int gain = cur.ref_size - cur.min_size;
+            if (out.empty()) {
+                if (nr(mid, cur, 0)) {
+                    out.push_back({j});
+                    sums.push_back(gain);
+                }
+                continue;
+            }
+            bool added = false;
+            for (size_t c = 0; c < out.size(); ++c) {
+                if (!ov(vars[(size_t)out[c].back()], cur)) {
+                    added = true;
+                    if (nr(mid, cur, sums[c])) {
+                        out[c].push_back(j);
+                        sums[c] += gain;
+                    }
+                }
+            }
+            if (!added) {
+                std::vector<std::vector<int>> fresh;
+                std::vector<int> fresh_sums;
+                for (size_t c = 0; c < out.size(); ++c) {
+                    std::vector<int> nc = out[c];
+                    int ns = sums[c];
+                    // drop members that overlap cur (the reference indexes back() of an emptied vector
+                    // here: undefined behaviour, restated as "stop when empty")
+                    while (!nc.empty() && ov(vars[(size_t)nc.back()], cur)) {
+                        const Variant &m = vars[(size_t)nc.back()];
+                        ns -= m.ref_size - m.min_size;
+                        nc.pop_back();
+                    }
+                    nc.push_back(j);
+                    if (nr(mid, cur, ns)) {
+                        added = true;
+                        fresh.push_back(std::move(nc));
+                        fresh_sums.push_back(ns + gain);
+                    }
+                }
+                out.insert(out.end(), fresh.begin(), fresh.end());
+                sums.insert(sums.end(), fresh_sums.begin(), fresh_sums.end());
+                if (!added) halt = true;
+            }
+        }
+        return out;
+    }
+
+    // combine_combs, var_block.hpp:630-677
+    static std::vector<std::vector<int>> combine(const std::vector<std::vector<int>> &left, const std::vector<std::vector<int>> &right, int i)
+    {
+        std::vector<std::vector<int>> full;
+        if (left.empty() && right.empty()) return {{i}};
+        if (left.empty()) {
+            for (const auto &r : right) {
+                std::vector<int> c{i};
+                c.insert(c.end(), r.begin(), r.end());
+                full.push_back(std::move(c));
+            }
+            return full;
+        }
+        for (const auto &l : left) {
+            std::vector<int> base(l.rbegin(), l.rend());
+            base.push_back(i);
+            if (right.empty()) full.push_back(base);
+            else
+                for (const auto &r : right) {
+                    std::vector<int> c = base;
+                    c.insert(c.end(), r.begin(), r.end());
+                    full.push_back(std::move(c));
+                }
+        }
+        return full;
+    }
+
+    // build_alleles_combs + combine_haplotypes, var_block.hpp:709-786.  A set of allele picks along the
+    // chain; picks are compared by allele TEXT in the reference, i.e. by first index with that text.
+    std::set<std::vector<int>> allele_picks(const std::vector<int> &comb, int central, bool haploid) const
+    {
+        std::set<std::vector<int>> out;
+        auto canon = [&](int var, int allele) {
+            const Variant &v = vars[(size_t)var];
+            return v.allele_index(v.allele(allele)); // .at() throws if the GT names a dropped symbolic allele
+        };
+        const size_t n = comb.size();
+        for (size_t g = 0; g < vars[(size_t)central].genotypes.size(); ++g) {
+            std::vector<int> h1(n), h2(n);
+            bool phased = true;
+            for (size_t j = 0; j < n; ++j) {
+                const Variant &v = vars[(size_t)comb[j]];
+                h1[j] = canon(comb[j], v.genotypes.at(g).first);
+                if (!haploid) {
+                    h2[j] = canon(comb[j], v.genotypes.at(g).second);
+                    phased = phased && v.phasing.at(g);
+                }
+            }
+            if (haploid) {
+                out.insert(h1);
+            } else if (phased) {
+                out.insert(h1);
+                out.insert(h2);
+            } else {
+                if (n > 24) throw std::runtime_error("unphased chain of more than 24 variants (2^n haplotypes)");
+                for (uint32_t m = 0; m < (1u << n); ++m) { // every pick of hap1/hap2 per level
+                    std::vector<int> h(n);
+                    for (size_t j = 0; j < n; ++j) h[j] = (m >> j) & 1 ? h2[j] : h1[j];
+                    out.insert(std::move(h));
+                }
+            }
+        }
+        return out;
+    }
+
+    // extract_kmers, var_block.hpp:95-219
+    std::vector<AlleleSignatures> extract(const std::string &reference, bool haploid) const
+    {
+        std::vector<AlleleSignatures> result(vars.size());
+        for (int vi = 0; vi < (int)vars.size(); ++vi) {
+            const Variant &v = vars[(size_t)vi];
+            if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) continue;
+            const auto combs = combine(chains(vi, -1), chains(vi, +1), vi);
+            for (const auto &comb : combs) {
+                // get_ref_subs, var_block.hpp:682-702
+                std::vector<std::string> rsubs;
+                int last_end = -1;
+                for (int index : comb) {
+                    const Variant &cv = vars[(size_t)index];
+                    if (last_end != -1) rsubs.push_back(substr_clip(reference, last_end, cv.ref_pos - last_end));
+                    last_end = cv.ref_pos + cv.ref_size;
+                }
+                for (const auto &pick : allele_picks(comb, vi, haploid)) {
+                    std::vector<std::string> sig;
+                    std::string mid_allele;
+                    if (pick.size() == 1 && (int)vars[(size_t)comb[0]].allele(pick[0]).size() >= k) {
+                        mid_allele = vars[(size_t)comb[0]].allele(pick[0]);
+                        for (size_t p = 0; p + (size_t)k <= mid_allele.size(); ++p) sig.push_back(mid_allele.substr(p, (size_t)k));
+                    } else {
+                        std::string kmer;
+                        int mid_pos = 0;
+                        for (size_t j = 0; j < pick.size(); ++j) {
+                            const std::string &al = vars[(size_t)comb[j]].allele(pick[j]);
+                            if (comb[j] == vi) {
+                                mid_pos = (int)kmer.size();
+                                mid_allele = al;
+                            }
+                            kmer += al;
+                            if (j < rsubs.size()) kmer += rsubs[j];
+                        }
+                        const int first_part = mid_pos + (int)mid_allele.size() / 2;
+                        const int second_part = (int)kmer.size() - first_part;
+                        const int missing_prefix = k / 2 - first_part;
+                        const int missing_suffix = (k + 1) / 2 - second_part;
+                        if (missing_prefix >= 0) {
+                            const Variant &fv = vars[(size_t)comb.front()];
+                            kmer = substr_clip(reference, (long)fv.ref_pos - missing_prefix, missing_prefix) + kmer;
+                        } else
+                            kmer.erase(0, (size_t)-missing_prefix);
+                        if (missing_suffix >= 0) {
+                            const Variant &lv = vars[(size_t)comb.back()];
+                            kmer += substr_clip(reference, (long)lv.ref_pos + lv.ref_size, missing_suffix);
+                        } else {
+                            if ((size_t)-missing_suffix > kmer.size()) throw std::out_of_range("k-mer shorter than the cut");
+                            kmer.erase(kmer.size() - (size_t)-missing_suffix);
+                        }
+                        sig.push_back(std::move(kmer));
+                    }
+                    result[(size_t)vi][v.allele_index(mid_allele)].push_back(std::move(sig));
+                }
+            }
+        }
+        return result;
+    }
+};
+
+} // namespace malva

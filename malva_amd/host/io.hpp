@@ -1,0 +1,363 @@
+// Host I/O for the malva-geno driver: gz-transparent line reader, FASTA, and the
+// VCF text decode the hot path's record model needs.  These stand where the
+// reference uses kseq.h (main.cpp:117,283-295) and htslib (variant.hpp:66-211,
+// main.cpp:190-219); only the behaviour the reference observes through those
+// libraries is implemented (text VCF, plain or gzip/bgzip; no BCF).
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+namespace malva {
+
+// gzopen() reads plain files transparently, so one reader serves .vcf/.vcf.gz/.fa/.fa.gz
+class LineReader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+
+  public:
+    explicit LineReader(const std::string &path) : buf(1 << 20)
+    {
+        f = gzopen(path.c_str(), "rb");
+        if (f) gzbuffer(f, 1 << 20);
+    }
+    ~LineReader()
+    {
+        if (f) gzclose(f);
+    }
+    LineReader(const LineReader &) = delete;
+    LineReader &operator=(const LineReader &) = delete;
+    bool ok() const { return f != nullptr; }
+    // next line without its terminator ('\n' or "\r\n"); false at end of file
+    bool next(std::string &line)
+    {
+        line.clear();
+        for (;;) {
+            if (pos == end) {
+                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                if (n <= 0) {
+                    if (line.empty()) return false;
+                    break;
+                }
+                pos = 0;
+                end = (size_t)n;
+            }
+            const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
+            if (nl) {
+                line.append(buf.data() + pos, nl - (buf.data() + pos));
+                pos = (size_t)(nl - buf.data()) + 1;
+                break;
+            }
+            line.append(buf.data() + pos, end - pos);
+            pos = end;
+        }
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+    }
+};
+
+inline void upper_inplace(std::string &s)
+{
+    for (char &c : s) c = (char)toupper((unsigned char)c);
+}
+
+// main.cpp:283-295: id = first word of the header line, "chr" optionally stripped, sequence upper-cased
+struct Reference {
+    std::vector<std::string> names;
+    std::map<std::string, std::string> seqs;
+};
+inline bool read_fasta(const std::string &path, bool strip_chr, Reference &out)
+{
+    LineReader in(path);
+    if (!in.ok()) return false;
+    std::string line, name;
+    std::string *cur = nullptr;
+    while (in.next(line)) {
+        if (!line.empty() && line[0] == '>') {
+            size_t e = 1;
+            while (e < line.size() && !isspace((unsigned char)line[e])) ++e;
+            name = line.substr(1, e - 1);
+            if (strip_chr && name.compare(0, 3, "chr") == 0) name = name.substr(3);
+            if (!out.seqs.count(name)) out.names.push_back(name);
+            cur = &out.seqs[name];
+            cur->clear();
+        } else if (cur) {
+            for (char c : line)
+                if (!isspace((unsigned char)c)) cur->push_back((char)toupper((unsigned char)c));
+        }
+    }
+    return true;
+}
+
+inline void split(std::string_view s, char sep, std::vector<std::string_view> &out)
+{
+    out.clear();
+    size_t a = 0;
+    for (;;) {
+        const size_t b = s.find(sep, a);
+        if (b == std::string_view::npos) {
+            out.push_back(s.substr(a));
+            return;
+        }
+        out.push_back(s.substr(a, b - a));
+        a = b + 1;
+    }
+}
+
+// The record model of variant.hpp:43-62, minus what only printing needs elsewhere.
+struct Variant {
+    std::string seq_name;
+    int ref_pos = 0; // 0-based
+    std::string idx;
+    std::string ref_sub;
+    std::vector<std::string> alts; // symbolic <...> alleles dropped (variant.hpp:79-88)
+    float quality = NAN;
+    std::vector<std::pair<int, int>> genotypes; // per kept sample
+    std::vector<uint8_t> phasing;
+    int ref_size = 0, min_size = 0, max_size = 0;
+    bool has_alts = true, is_present = true;
+    std::vector<float> frequencies;
+    std::vector<uint32_t> coverages;
+
+    int n_alleles() const { return (int)alts.size() + 1; }
+    const std::string &allele(int i) const { return i == 0 ? ref_sub : alts.at((size_t)i - 1); }
+    // variant.hpp:228-240: first allele with this text (duplicated ALT strings collapse)
+    int allele_index(const std::string &a) const
+    {
+        if (ref_sub == a) return 0;
+        for (size_t i = 0; i < alts.size(); ++i)
+            if (alts[i] == a) return (int)i + 1;
+        return -1;
+    }
+};
+
+// Text VCF: header lines, sample subset (-s), and Variant decode as variant.hpp:66-211
+// sees it through htslib.
+class VcfReader {
+    LineReader in;
+    std::string pending;
+    bool have_pending = false;
+    std::vector<std::string_view> cols, fmt, fld, vals;
+
+  public:
+    std::vector<std::string> header_lines; // the ## lines
+    std::vector<std::string> samples;
+    std::vector<int> keep; // kept sample columns, VCF order (htslib keeps a mask)
+    std::string error;
+
+    VcfReader(const std::string &path, const std::string &samples_opt) : in(path)
+    {
+        if (!in.ok()) {
+            error = "cannot open " + path;
+            return;
+        }
+        std::string line;
+        while (in.next(line)) {
+            if (line.rfind("##", 0) == 0) header_lines.push_back(line);
+            else if (!line.empty() && line[0] == '#') {
+                split(line, '\t', cols);
+                for (size_t i = 9; i < cols.size(); ++i) samples.emplace_back(cols[i]);
+                break;
+            } else {
+                pending = line;
+                have_pending = true;
+                break;
+            }
+        }
+        if (samples_opt == "-") {
+            for (size_t i = 0; i < samples.size(); ++i) keep.push_back((int)i);
+        } else {
+            std::ifstream sf(samples_opt);
+            if (!sf) {
+                error = "ERROR: VCF samples subset (cannot open " + samples_opt + ")";
+                return;
+            }
+            std::set<std::string> want;
+            std::string s;
+            while (std::getline(sf, s)) {
+                while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+                if (!s.empty()) want.insert(s);
+            }
+            for (const auto &w : want)
+                if (std::find(samples.begin(), samples.end(), w) == samples.end()) {
+                    error = "ERROR: VCF samples subset (unknown sample " + w + ")";
+                    return;
+                }
+            for (size_t i = 0; i < samples.size(); ++i)
+                if (want.count(samples[i])) keep.push_back((int)i);
+        }
+    }
+    bool ok() const { return error.empty(); }
+
+    // false at end of file; throws std::runtime_error on records the reference would crash on
+    bool next(Variant &v, const std::string &freq_key, bool uniform)
+    {
+        std::string line;
+        for (;;) {
+            if (have_pending) {
+                line.swap(pending);
+                have_pending = false;
+            } else if (!in.next(line))
+                return false;
+            if (!line.empty() && line[0] != '#') break;
+        }
+        split(line, '\t', cols);
+        if (cols.size() < 8) throw std::runtime_error("malformed VCF record: " + line.substr(0, 60));
+        v = Variant();
+        v.seq_name = std::string(cols[0]);
+        v.ref_pos = atoi(std::string(cols[1]).c_str()) - 1;
+        v.idx = std::string(cols[2]);
+        v.ref_sub = std::string(cols[3]);
+        upper_inplace(v.ref_sub);
+        v.ref_size = (int)v.ref_sub.size();
+        if (cols[4] != ".") {
+            split(cols[4], ',', fld);
+            for (auto a : fld)
+                if (!a.empty() && a[0] != '<') {
+                    v.alts.emplace_back(a);
+                    upper_inplace(v.alts.back());
+                }
+        }
+        v.coverages.assign(v.alts.size() + 1, 0);
+        v.quality = cols[5] == "." ? NAN : (float)strtod(std::string(cols[5]).c_str(), nullptr);
+        // set_sizes, variant.hpp:108-124
+        if (v.alts.empty()) v.has_alts = false;
+        else {
+            v.min_size = v.max_size = v.ref_size;
+            for (const auto &a : v.alts) {
+                v.min_size = std::min(v.min_size, (int)a.size());
+                v.max_size = std::max(v.max_size, (int)a.size());
+            }
+        }
+        if (!v.has_alts) return true;
+        // extract_frequencies, variant.hpp:126-156
+        if (!uniform) {
+            std::vector<float> raw;
+            bool found = false;
+            if (cols[7] != ".") {
+                split(cols[7], ';', fld);
+                for (auto kv : fld)
+                    if (kv.size() > freq_key.size() && kv.compare(0, freq_key.size(), freq_key) == 0 && kv[freq_key.size()] == '=') {
+                        split(kv.substr(freq_key.size() + 1), ',', vals);
+                        for (auto x : vals) raw.push_back(x == "." ? NAN : (float)strtod(std::string(x).c_str(), nullptr));
+                        found = true;
+                        break;
+                    }
+            }
+            if (!found) throw std::runtime_error("INFO key " + freq_key + " missing at " + v.seq_name + ":" + std::string(cols[1]) +
+                                                 " (the reference dereferences a null pointer here)");
+            if (raw.size() < v.alts.size())
+                throw std::runtime_error("fewer " + freq_key + " values than ALT alleles at " + v.seq_name + ":" + std::string(cols[1]));
+            v.frequencies.assign(1, 0.f);
+            for (size_t i = 0; i < v.alts.size(); ++i) v.frequencies.push_back(raw[i]);
+            double acc = 0.0;
+            for (float f : v.frequencies) acc += f;
+            v.frequencies[0] = (float)(1.0 - acc);
+            if (v.frequencies[0] < 0) v.frequencies[0] = 0.0f;
+        } else {
+            const float u = (float)(1.0 / (double)(v.alts.size() + 1));
+            v.frequencies.assign(v.alts.size() + 1, u);
+        }
+        if (v.frequencies[0] == 1.0) v.is_present = false;
+        if (!v.is_present) return true;
+        // extract_genotypes, variant.hpp:158-211
+        int gi = -1;
+        if (cols.size() > 8) {
+            split(cols[8], ':', fmt);
+            for (size_t i = 0; i < fmt.size(); ++i)
+                if (fmt[i] == "GT") gi = (int)i;
+        }
+        if (gi < 0 || keep.empty()) {
+            v.has_alts = false; // variant.hpp:169-174
+            return true;
+        }
+        // what bcf_get_genotypes returns: per sample `ploidy` values, short samples padded with vector_end
+        struct G {
+            int allele; // -1 missing, -2 vector_end
+            bool phased;
+        };
+        std::vector<std::vector<G>> per(keep.size());
+        size_t ploidy = 0;
+        for (size_t s = 0; s < keep.size(); ++s) {
+            const size_t col = 9 + (size_t)keep[s];
+            std::string_view gt = ".";
+            if (col < cols.size()) {
+                split(cols[col], ':', fld);
+                if ((size_t)gi < fld.size()) gt = fld[(size_t)gi];
+            }
+            bool ph = false;
+            size_t a = 0;
+            for (size_t i = 0; i <= gt.size(); ++i)
+                if (i == gt.size() || gt[i] == '/' || gt[i] == '|') {
+                    const std::string_view tok = gt.substr(a, i - a);
+                    per[s].push_back({(tok.empty() || tok == ".") ? -1 : atoi(std::string(tok).c_str()), ph});
+                    if (i < gt.size()) ph = gt[i] == '|';
+                    a = i + 1;
+                }
+            ploidy = std::max(ploidy, per[s].size());
+        }
+        std::vector<G> flat;
+        flat.reserve(keep.size() * ploidy);
+        for (auto &p : per)
+            for (size_t j = 0; j < ploidy; ++j) flat.push_back(j < p.size() ? p[j] : G{-2, false});
+        for (size_t i = 0; i < keep.size(); ++i) {
+            const G first = flat[i * ploidy];
+            // curr_gt[1]: with ploidy 1 this is the NEXT sample's value (variant.hpp:184); past the last
+            // sample the reference reads beyond the array -- treated as vector_end here.
+            const G second = i * ploidy + 1 < flat.size() ? flat[i * ploidy + 1] : G{-2, false};
+            int a1, a2;
+            bool is_ph;
+            if (second.allele == -2) {
+                a1 = a2 = first.allele;
+                is_ph = true;
+            } else {
+                a1 = first.allele;
+                a2 = second.allele;
+                is_ph = second.phased;
+            }
+            v.genotypes.emplace_back(a1 < 0 ? 0 : a1, a2 < 0 ? 0 : a2);
+            v.phasing.push_back(is_ph ? 1 : 0);
+        }
+        return true;
+    }
+};
+
+// print_cleaned_header (main.cpp:190-219) as htslib renders it
+inline std::string cleaned_header(const std::vector<std::string> &lines_in, bool verbose)
+{
+    std::vector<std::string> lines = lines_in;
+    auto has_id = [&](const std::string &prefix) {
+        for (const auto &l : lines)
+            if (l.compare(0, prefix.size(), prefix) == 0 && (l[prefix.size()] == ',' || l[prefix.size()] == '>')) return true;
+        return false;
+    };
+    if (!has_id("##FILTER=<ID=PASS")) {
+        const size_t at = (!lines.empty() && lines[0].rfind("##fileformat", 0) == 0) ? 1 : 0;
+        lines.insert(lines.begin() + (long)at, "##FILTER=<ID=PASS,Description=\"All filters passed\">");
+    }
+    if (!has_id("##FORMAT=<ID=GT")) lines.push_back("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">");
+    if (!has_id("##FORMAT=<ID=GQ")) lines.push_back("##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">");
+    if (verbose) {
+        if (!has_id("##INFO=<ID=COVS")) lines.push_back("##INFO=<ID=COVS,Number=R,Type=Integer,Description=\"Allele coverages\">");
+        if (!has_id("##INFO=<ID=GTS")) lines.push_back("##INFO=<ID=GTS,Number=.,Type=String,Description=\"Genotypes Likelihood\">");
+    }
+    std::string out;
+    for (const auto &l : lines) out += l + "\n";
+    out += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tDONOR\n";
+    return out;
+}
+
+} // namespace malva

@@ -1,0 +1,724 @@
+// malva-geno index|call -- host driver of the MI355X-native hot path.
+//
+// Keeps the reference's command line (argument_parser.hpp:51-159), control flow
+// (index_main main.cpp:251-419, call_main :421-594) and VCF output, and hands
+// every k-mer store operation, both scans, coverage and likelihoods to
+// libmalva_hip.so through include/malva_hip.h.  There is no CPU implementation of
+// those in this program: without a GPU it stops at mg_create.
+#include <getopt.h>
+#include <sys/resource.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <iostream>
+#include <sstream>
+
+#include "block.hpp"
+extern "C" {
+#include "malva_hip.h"
+}
+
+using namespace malva;
+
+namespace {
+
+const char *USAGE =
+    "Usage: malva-geno <index|call> [-k KMER-SIZE] [-r REF-KMER-SIZE] [-c MAX-COV] "
+    "<reference.fa> <variants.vcf> <kmc_output_prefix>\n"
+    "\n"
+    "      -h, --help                        display this help and exit\n"
+    "      -k, --kmer-size                   size of the kmers to index (default:35)\n"
+    "      -r, --ref-kmer-size               size of the reference kmers to index (default:43)\n"
+    "      -e, --error-rate                  expected sample error rate (default:0.001)\n"
+    "      -s, --samples                     file containing the list of (VCF) samples to consider (default:-, i.e. all samples)\n"
+    "      -f, --freq-key                    a priori frequency key in the INFO column of the input VCF (default:AF)\n"
+    "      -c, --max-coverage                maximum coverage for variant alleles (default:200)\n"
+    "      -b, --bf-size                     bloom filter size in GB (default:4)\n"
+    "      -p, --strip-chr                   strip \"chr\" from sequence names (default:false)\n"
+    "      -u, --uniform                     use uniform a priori probabilities (default:false)\n"
+    "      -v, --verbose                     output COVS and GTS in INFO column (default: false)\n"
+    "      -1, --haploid                     run MALVA in haploid mode (default: false)\n"
+    "      -d, --device                      GPU to run on (default:0)          [this build]\n"
+    "\n"
+    "  <kmc_output_prefix>: <prefix>.txt or <prefix> holding `kmc_tools transform <db> dump` text\n"
+    "  (one `KMER<tab>count` per line).\n"
+    "  extra sub-command: dump-kmers (prints the signature k-mers of every block; no GPU needed)\n";
+
+struct Options { // argument_parser.hpp:51-66
+    unsigned k = 35, ref_k = 43;
+    float error_rate = 0.001f;
+    std::string samples = "-", freq_key = "AF";
+    unsigned max_coverage = 200;
+    uint64_t bf_size = 1ULL << 35;
+    bool strip_chr = false, uniform = false, verbose = false, haploid = false;
+    int device = 0;
+    std::string fasta_path, vcf_path, kmc_path;
+};
+
+bool parse_arguments(int argc, char **argv, Options &o)
+{
+    // same short options and long names as the reference, including its quirks: --strip-chr / --uniform are
+    // declared with required_argument and --haploid is spelt "haplod" (argument_parser.hpp:70-84)
+    static const option longopts[] = {{"kmer-size", required_argument, nullptr, 'k'},   {"ref-kmer-size", required_argument, nullptr, 'r'},
+                                      {"error-rate", required_argument, nullptr, 'e'},  {"freq-key", required_argument, nullptr, 'f'},
+                                      {"samples", required_argument, nullptr, 's'},     {"max-coverage", required_argument, nullptr, 'c'},
+                                      {"bf-size", required_argument, nullptr, 'b'},     {"strip-chr", required_argument, nullptr, 'p'},
+                                      {"uniform", required_argument, nullptr, 'u'},     {"verbose", no_argument, nullptr, 'v'},
+                                      {"haplod", no_argument, nullptr, '1'},            {"haploid", no_argument, nullptr, '1'},
+                                      {"device", required_argument, nullptr, 'd'},      {"help", no_argument, nullptr, 'h'},
+                                      {nullptr, 0, nullptr, 0}};
+    bool die = false;
+    optind = 1;
+    for (int c; (c = getopt_long(argc, argv, "k:r:e:s:f:c:b:d:hpuv1", longopts, nullptr)) != -1;) {
+        std::istringstream arg(optarg ? optarg : "");
+        switch (c) {
+        case 'p': o.strip_chr = true; break;
+        case 'u': o.uniform = true; break;
+        case 'k': arg >> o.k; break;
+        case 'r': arg >> o.ref_k; break;
+        case 'e': arg >> o.error_rate; break;
+        case 's': arg >> o.samples; break;
+        case 'f': arg >> o.freq_key; break;
+        case 'c': arg >> o.max_coverage; break;
+        case 'b':
+            arg >> o.bf_size;
+            o.bf_size *= 1ULL << 33; // "GB" on the command line, 2^33 bits each (argument_parser.hpp:119-123)
+            break;
+        case 'd': arg >> o.device; break;
+        case 'v': o.verbose = true; break;
+        case '1': o.haploid = true; break;
+        case '?': die = true; break;
+        case 'h': std::cout << USAGE; exit(EXIT_SUCCESS);
+        }
+    }
+    if (argc - optind < 3) {
+        std::cerr << "malva : missing arguments\n";
+        die = true;
+    } else if (argc - optind > 3) {
+        std::cerr << "malva : too many arguments\n";
+        die = true;
+    }
+    if (die) {
+        std::cerr << "\n" << USAGE;
+        return false;
+    }
+    o.fasta_path = argv[optind++];
+    o.vcf_path = argv[optind++];
+    o.kmc_path = argv[optind++];
+    return true;
+}
+
+// pelapsed(), main.cpp:93-115
+auto t_start = std::chrono::steady_clock::now();
+auto t_last = t_start;
+void pelapsed(const std::string &s, bool rollback = false)
+{
+    const auto now = std::chrono::steady_clock::now();
+    rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    char buf[512];
+    snprintf(buf, sizeof buf, "[malva-geno/%s] Execution Time %.4gs\n[malva-geno/%s] Time elapsed %.4gs\n[malva-geno/%s] Used CPU-time elapsed %.4gs\n"
+                              "[malva-geno/%s] Maximum memory used %ldMb\n",
+             s.c_str(), std::chrono::duration<double>(now - t_last).count(), s.c_str(), std::chrono::duration<double>(now - t_start).count(), s.c_str(),
+             ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, s.c_str(), ru.ru_maxrss / 1024);
+    std::cerr << buf << (rollback ? "\r" : "\n");
+    t_last = now;
+}
+
+struct Device {
+    mg_ctx *ctx = nullptr;
+    ~Device() { mg_destroy(ctx); }
+    void check(int rc, const char *what)
+    {
+        if (rc != MG_OK) throw std::runtime_error(std::string(what) + ": " + mg_last_error(ctx));
+    }
+};
+
+constexpr size_t STRIDE = 136; // MG_MAX_KMER + NUL, rounded to 8
+
+// fixed-stride ASCII rows for the batch calls
+struct Rows {
+    std::vector<char> data;
+    size_t n = 0;
+    void add(const std::string &kmer)
+    {
+        if (kmer.empty() || kmer.size() > MG_MAX_KMER) throw std::runtime_error("signature k-mer of length " + std::to_string(kmer.size()) + " (1.." +
+                                                                                std::to_string(MG_MAX_KMER) + " supported)");
+        data.resize(data.size() + STRIDE, 0);
+        memcpy(&data[n * STRIDE], kmer.data(), kmer.size());
+        ++n;
+    }
+    void clear()
+    {
+        data.clear();
+        n = 0;
+    }
+};
+
+bool file_exists(const std::string &p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+std::string index_path(const Options &o) // main.cpp:407 with this build's own container suffix
+{
+    return o.vcf_path + ".c" + std::to_string(o.ref_k) + ".k" + std::to_string(o.k) + ".malvax.hipz";
+}
+
+// The record loop shared by index_main (main.cpp:309-370) and call_main (:522-579).  on_block(block, reference
+// of `last_seq_name`) is called for every closed block.  Keeps the reference's control flow, including that
+// last_seq_name is refreshed only when a block is flushed.
+template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const Reference &refs, bool for_index, std::vector<std::string> *used, F on_block)
+{
+    static const std::string empty;
+    auto ref_of = [&](const std::string &name) -> const std::string & {
+        auto it = refs.seqs.find(name);
+        return it == refs.seqs.end() ? empty : it->second;
+    };
+    Block vb((int)o.k);
+    std::string last_seq_name;
+    Variant v;
+    size_t i = 0;
+    while (vcf.next(v, o.freq_key, o.uniform)) {
+        ++i;
+        if (i % 5000 == 0) pelapsed("Processed " + std::to_string(i) + " variants", true);
+        if (last_seq_name.empty()) {
+            last_seq_name = v.seq_name;
+            if (used) used->push_back(last_seq_name);
+        }
+        if (for_index ? (!v.has_alts || !v.is_present) : !v.has_alts) continue;
+        if (vb.empty()) {
+            vb.add(std::move(v));
+            continue;
+        }
+        if (!vb.near_to_last(v) || last_seq_name != v.seq_name) {
+            on_block(vb, last_seq_name, ref_of(last_seq_name));
+            vb.clear();
+            if (last_seq_name != v.seq_name) {
+                last_seq_name = v.seq_name;
+                if (used) used->push_back(last_seq_name);
+            }
+        }
+        vb.add(std::move(v));
+    }
+    if (!vb.empty()) {
+        on_block(vb, last_seq_name, ref_of(last_seq_name));
+        vb.clear();
+    }
+    return i;
+}
+
+// ---- index file: this build's own container (gzip): parameters, both filters in sparse form, the exact map ----
+template <class T> void gz_put(gzFile f, const T *p, size_t n)
+{
+    const char *b = (const char *)p;
+    size_t left = n * sizeof(T);
+    while (left) {
+        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
+        if (gzwrite(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: write failed");
+        b += chunk;
+        left -= chunk;
+    }
+}
+template <class T> void gz_get(gzFile f, T *p, size_t n)
+{
+    char *b = (char *)p;
+    size_t left = n * sizeof(T);
+    while (left) {
+        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
+        if (gzread(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: truncated");
+        b += chunk;
+        left -= chunk;
+    }
+}
+const char MAGIC[8] = {'M', 'G', 'H', 'I', 'P', 'X', '1', '\n'};
+
+void save_index(Device &dev, const Options &o)
+{
+    gzFile f = gzopen(index_path(o).c_str(), "wb1");
+    if (!f) throw std::runtime_error("cannot write " + index_path(o));
+    gz_put(f, MAGIC, 8);
+    const uint64_t hdr[3] = {o.k, o.ref_k, o.bf_size};
+    gz_put(f, hdr, 3);
+    for (int which : {MG_BF_CTX, MG_BF_ALT}) { // payload order of main.cpp:409-411: context_bf, bf, ref_bf
+        uint64_t size, nset;
+        int mode;
+        dev.check(mg_bf_info(dev.ctx, which, &size, &nset, &mode), "mg_bf_info");
+        std::vector<uint64_t> pos(nset);
+        std::vector<uint16_t> cnt(nset);
+        dev.check(mg_bf_export_sparse(dev.ctx, which, pos.data(), cnt.data()), "mg_bf_export_sparse");
+        const uint64_t h2[2] = {(uint64_t)mode, nset};
+        gz_put(f, h2, 2);
+        gz_put(f, pos.data(), nset);
+        gz_put(f, cnt.data(), nset);
+    }
+    uint64_t nkeys = 0;
+    dev.check(mg_map_size(dev.ctx, &nkeys), "mg_map_size");
+    std::vector<char> rows(nkeys * STRIDE);
+    std::vector<int32_t> vals(nkeys);
+    if (nkeys) dev.check(mg_map_export(dev.ctx, rows.data(), STRIDE, vals.data()), "mg_map_export");
+    gz_put(f, &nkeys, 1);
+    gz_put(f, rows.data(), rows.size());
+    gz_put(f, vals.data(), vals.size());
+    if (gzclose(f) != Z_OK) throw std::runtime_error("index file: close failed");
+}
+
+void load_index(Device &dev, const Options &o)
+{
+    gzFile f = gzopen(index_path(o).c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open index " + index_path(o) + " (run `malva-geno index` with the same -k -r -b first)");
+    char magic[8];
+    gz_get(f, magic, 8);
+    uint64_t hdr[3];
+    gz_get(f, hdr, 3);
+    if (memcmp(magic, MAGIC, 8) != 0 || hdr[0] != o.k || hdr[1] != o.ref_k || hdr[2] != o.bf_size) {
+        gzclose(f);
+        throw std::runtime_error("index " + index_path(o) + " was built with other -k/-r/-b");
+    }
+    for (int which : {MG_BF_CTX, MG_BF_ALT}) {
+        uint64_t h2[2];
+        gz_get(f, h2, 2);
+        std::vector<uint64_t> pos(h2[1]);
+        std::vector<uint16_t> cnt(h2[1]);
+        gz_get(f, pos.data(), pos.size());
+        gz_get(f, cnt.data(), cnt.size());
+        dev.check(mg_bf_import_sparse(dev.ctx, which, (int)h2[0], o.bf_size, pos.data(), cnt.data(), h2[1]), "mg_bf_import_sparse");
+    }
+    uint64_t nkeys = 0;
+    gz_get(f, &nkeys, 1);
+    std::vector<char> rows(nkeys * STRIDE);
+    std::vector<int32_t> vals(nkeys);
+    gz_get(f, rows.data(), rows.size());
+    gz_get(f, vals.data(), vals.size());
+    gzclose(f);
+    if (nkeys) dev.check(mg_map_import(dev.ctx, rows.data(), STRIDE, nkeys, vals.data()), "mg_map_import");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int index_main(const Options &o)
+{
+    Reference refs;
+    if (!read_fasta(o.fasta_path, o.strip_chr, refs)) {
+        std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
+        return 1;
+    }
+    VcfReader vcf(o.vcf_path, o.samples);
+    if (!vcf.ok()) {
+        std::cerr << vcf.error << std::endl;
+        return 1;
+    }
+    pelapsed("Reference processed");
+    Device dev;
+    if (mg_create(&dev.ctx, o.device, o.k, o.ref_k, o.bf_size) != MG_OK) {
+        std::cerr << "ERROR: no usable MI355X/HIP device " << o.device << " (or not enough memory for two filters of " << o.bf_size
+                  << " bits); this build has no CPU path" << std::endl;
+        return 1;
+    }
+    Rows ref_rows, alt_rows;
+    auto flush = [&](bool force) {
+        if (ref_rows.n && (force || ref_rows.n >= (1u << 20))) {
+            dev.check(mg_map_insert(dev.ctx, ref_rows.data.data(), STRIDE, ref_rows.n), "mg_map_insert");
+            ref_rows.clear();
+        }
+        if (alt_rows.n && (force || alt_rows.n >= (1u << 20))) {
+            dev.check(mg_bf_insert(dev.ctx, MG_BF_ALT, alt_rows.data.data(), STRIDE, alt_rows.n), "mg_bf_insert");
+            alt_rows.clear();
+        }
+    };
+    std::vector<std::string> used;
+    const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &, const std::string &reference) {
+        const auto sigs = vb.extract(reference, o.haploid); // main.cpp:349
+        for (const auto &per_allele : sigs)                  // add_kmers_to_bf, main.cpp:122-144
+            for (const auto &as : per_allele)
+                for (const auto &sig : as.second)
+                    for (const auto &kmer : sig) (as.first == 0 ? ref_rows : alt_rows).add(kmer);
+        flush(false);
+    });
+    flush(true);
+    pelapsed("Processed " + std::to_string(n) + " variants");
+    dev.check(mg_bf_finalize(dev.ctx, MG_BF_ALT), "mg_bf_finalize(bf)"); // main.cpp:378
+    pelapsed("BF creation complete");
+    for (const auto &name : used) { // main.cpp:383-401
+        auto it = refs.seqs.find(name);
+        static const std::string empty;
+        const std::string &seq = it == refs.seqs.end() ? empty : it->second;
+        dev.check(mg_ref_scan(dev.ctx, seq.data(), seq.size()), "mg_ref_scan");
+    }
+    pelapsed("Reference BF creation complete");
+    dev.check(mg_bf_finalize(dev.ctx, MG_BF_CTX), "mg_bf_finalize(context_bf)"); // main.cpp:404
+    save_index(dev, o);
+    return 0;
+}
+
+// ---- call -----------------------------------------------------------------------------------------------------
+// k-mer table: text dump, `KMER count` per line -> SoA 2-bit table in pieces
+struct TablePiece {
+    std::vector<uint64_t> hi, lo;
+    std::vector<uint32_t> cnt;
+    void clear()
+    {
+        hi.clear();
+        lo.clear();
+        cnt.clear();
+    }
+};
+
+void scan_table(Device &dev, const Options &o, const std::string &path)
+{
+    LineReader in(path);
+    if (!in.ok()) throw std::runtime_error("cannot open " + path);
+    TablePiece t;
+    Rows odd_ctx, odd_kmer; // rows with a non-ACGT symbol (KMC never lists any): exact ASCII path
+    std::vector<uint32_t> odd_cnt;
+    std::string line;
+    const size_t piece = 1u << 24;
+    uint64_t total = 0;
+    auto flush = [&]() {
+        if (!t.cnt.empty()) dev.check(mg_kmc_scan(dev.ctx, t.hi.data(), t.lo.data(), t.cnt.data(), t.cnt.size()), "mg_kmc_scan");
+        t.clear();
+    };
+    while (in.next(line)) {
+        if (line.empty()) continue;
+        size_t e = 0;
+        while (e < line.size() && !isspace((unsigned char)line[e])) ++e;
+        if (e != o.ref_k) throw std::runtime_error("k-mer table holds a " + std::to_string(e) + "-mer, expected -r " + std::to_string(o.ref_k));
+        const uint32_t count = (uint32_t)strtoul(line.c_str() + e, nullptr, 10);
+        uint64_t hi = 0, lo = 0;
+        bool acgt = true;
+        for (size_t i = 0; i < e; ++i) {
+            uint64_t code;
+            switch (toupper((unsigned char)line[i])) { // main.cpp:491 toupper
+            case 'A': code = 0; break;
+            case 'C': code = 1; break;
+            case 'G': code = 2; break;
+            case 'T': code = 3; break;
+            default: code = 0; acgt = false;
+            }
+            hi = (hi << 2) | (lo >> 62);
+            lo = (lo << 2) | code;
+        }
+        ++total;
+        if (!acgt) {
+            std::string ctx = line.substr(0, e);
+            upper_inplace(ctx);
+            odd_ctx.add(ctx);
+            odd_kmer.add(ctx.substr((o.ref_k - o.k) / 2, o.k));
+            odd_cnt.push_back(count);
+            continue;
+        }
+        t.hi.push_back(hi);
+        t.lo.push_back(lo);
+        t.cnt.push_back(count);
+        if (t.cnt.size() == piece) flush();
+    }
+    flush();
+    if (odd_cnt.size()) { // main.cpp:495-499 through the ASCII batch calls
+        std::vector<int32_t> ic(odd_cnt.begin(), odd_cnt.end());
+        dev.check(mg_map_increment(dev.ctx, odd_kmer.data.data(), STRIDE, odd_kmer.n, ic.data()), "mg_map_increment");
+        std::vector<uint8_t> in_ctx(odd_cnt.size());
+        dev.check(mg_bf_test(dev.ctx, MG_BF_CTX, odd_ctx.data.data(), STRIDE, odd_ctx.n, in_ctx.data()), "mg_bf_test");
+        Rows pass;
+        std::vector<uint32_t> pc;
+        for (size_t i = 0; i < odd_cnt.size(); ++i)
+            if (!in_ctx[i]) {
+                pass.add(std::string(&odd_kmer.data[i * STRIDE]));
+                pc.push_back(odd_cnt[i]);
+            }
+        if (pass.n) dev.check(mg_bf_increment(dev.ctx, MG_BF_ALT, pass.data.data(), STRIDE, pass.n, pc.data()), "mg_bf_increment");
+    }
+    std::cerr << "[malva-geno] scanned " << total << " k-mers" << std::endl;
+}
+
+// one output record waiting for its device results
+struct Rec {
+    std::string prefix; // CHROM .. QUAL columns
+    uint32_t n_alleles;
+    bool isolated;
+    size_t slot;     // variant index inside its batch
+    size_t allele0;  // first allele slot inside its batch
+    size_t gt0;      // first genotype slot inside its batch
+};
+struct Batch { // inputs of mg_call_isolated (isolated) or mg_lookup_cover + mg_genotype (general)
+    std::vector<uint64_t> pos, present;
+    std::vector<uint32_t> var_allele_off{0}, allele_off{0};
+    std::vector<char> pool;
+    std::vector<float> freq;
+    std::vector<uint8_t> flags;
+    Rows rows;
+    std::vector<uint8_t> is_ref;
+    std::vector<uint64_t> sig_kmer_off{0}, allele_sig_off{0}, var_gt_off{0};
+    // results
+    std::vector<uint32_t> cov;
+    std::vector<int32_t> g1, g2, gq;
+    std::vector<uint8_t> status;
+    std::vector<double> probs;
+    size_t n() const { return var_allele_off.size() - 1; }
+};
+
+std::string fmt_float(float q) // ostream << float, default precision
+{
+    char b[64];
+    snprintf(b, sizeof b, "%g", q);
+    return b;
+}
+
+int call_main(const Options &o)
+{
+    Reference refs;
+    if (!read_fasta(o.fasta_path, o.strip_chr, refs)) {
+        std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
+        return 1;
+    }
+    std::string table = o.kmc_path;
+    if (file_exists(o.kmc_path + ".kmc_pre") && !file_exists(o.kmc_path + ".txt") && !file_exists(o.kmc_path)) {
+        std::cerr << "ERROR: " << o.kmc_path << ".kmc_pre is a KMC database; this build reads the text dump -- run\n"
+                  << "       kmc_tools transform " << o.kmc_path << " dump " << o.kmc_path << ".txt" << std::endl;
+        return 1;
+    }
+    if (file_exists(o.kmc_path + ".txt")) table = o.kmc_path + ".txt";
+    if (!file_exists(table)) {
+        std::cerr << "ERROR: cannot open " << o.kmc_path << std::endl;
+        return 1;
+    }
+    Device dev;
+    if (mg_create(&dev.ctx, o.device, o.k, o.ref_k, o.bf_size) != MG_OK) {
+        std::cerr << "ERROR: no usable MI355X/HIP device " << o.device << "; this build has no CPU path" << std::endl;
+        return 1;
+    }
+    load_index(dev, o);
+    pelapsed("Reference processed");
+    scan_table(dev, o, table); // main.cpp:482-500
+    pelapsed("BF weights created");
+
+    // concatenated reference for the fused isolated path
+    std::map<std::string, uint64_t> contig_base;
+    {
+        std::string all;
+        for (const auto &name : refs.names) {
+            contig_base[name] = all.size();
+            all += refs.seqs.at(name);
+        }
+        dev.check(mg_reference_upload(dev.ctx, all.data(), all.size()), "mg_reference_upload");
+    }
+    {
+        VcfReader hdr(o.vcf_path, "-");
+        if (!hdr.ok()) {
+            std::cerr << hdr.error << std::endl;
+            return 1;
+        }
+        std::cout << cleaned_header(hdr.header_lines, o.verbose); // main.cpp:505-510
+    }
+    VcfReader vcf(o.vcf_path, o.samples);
+    if (!vcf.ok()) {
+        std::cerr << vcf.error << std::endl;
+        return 1;
+    }
+    pelapsed("VCF parsing and genotyping");
+
+    std::vector<Rec> recs;
+    Batch iso, gen;
+    const std::string best_default = o.haploid ? "0" : "0/0";
+    auto n_gt = [&](uint64_t A) { return o.haploid ? A : A * (A + 1) / 2; };
+
+    auto run_and_print = [&]() {
+        if (iso.n()) {
+            const size_t n = iso.n(), na = iso.var_allele_off.back();
+            iso.cov.resize(na); iso.g1.resize(n); iso.g2.resize(n); iso.gq.resize(n); iso.status.resize(n);
+            iso.probs.resize(o.verbose ? iso.var_gt_off.back() : 0);
+            dev.check(mg_call_isolated(dev.ctx, n, iso.pos.data(), iso.var_allele_off.data(), iso.allele_off.data(), iso.pool.data(), iso.pool.size(),
+                                       iso.freq.data(), iso.present.data(), iso.flags.data(), o.error_rate, (int)o.max_coverage, o.haploid, iso.cov.data(),
+                                       iso.g1.data(), iso.g2.data(), iso.gq.data(), iso.status.data(), o.verbose ? iso.probs.data() : nullptr,
+                                       o.verbose ? iso.var_gt_off.data() : nullptr),
+                      "mg_call_isolated");
+        }
+        if (gen.n()) {
+            const size_t n = gen.n(), na = gen.var_allele_off.back();
+            gen.cov.resize(na); gen.g1.resize(n); gen.g2.resize(n); gen.gq.resize(n); gen.status.resize(n);
+            gen.probs.resize(o.verbose ? gen.var_gt_off.back() : 0);
+            dev.check(mg_lookup_cover(dev.ctx, gen.rows.data.data(), STRIDE, gen.rows.n, gen.is_ref.data(), gen.sig_kmer_off.data(),
+                                      gen.sig_kmer_off.size() - 1, gen.allele_sig_off.data(), na, gen.cov.data()),
+                      "mg_lookup_cover"); // set_coverages, main.cpp:557
+            dev.check(mg_genotype(dev.ctx, gen.cov.data(), gen.freq.data(), gen.var_allele_off.data(), n, o.error_rate, (int)o.max_coverage, o.haploid,
+                                  gen.g1.data(), gen.g2.data(), gen.gq.data(), gen.status.data(), o.verbose ? gen.probs.data() : nullptr,
+                                  o.verbose ? gen.var_gt_off.data() : nullptr),
+                      "mg_genotype"); // vb.genotype + the GT/GQ part of output_variants, main.cpp:558-559
+        }
+        std::string out;
+        char num[64];
+        for (const Rec &r : recs) { // output_variants, var_block.hpp:337-396
+            const Batch &b = r.isolated ? iso : gen;
+            out += r.prefix;
+            out += "\tPASS\t";
+            const uint32_t *cov = &b.cov[r.allele0];
+            const uint8_t st = b.status[r.slot];
+            auto gname = [&](int a, int c) { return o.haploid ? std::to_string(a) : std::to_string(a) + "/" + std::to_string(c); };
+            if (o.verbose) {
+                out += "COVS=";
+                for (uint32_t a = 0; a < r.n_alleles; ++a) {
+                    out += std::to_string((int)cov[a]);
+                    out += a + 1 < r.n_alleles ? "," : "";
+                }
+                out += ";GTS=";
+                if (st == MG_GT_NORMAL) {
+                    size_t q = r.gt0;
+                    bool first = true;
+                    for (uint32_t a = 0; a < r.n_alleles; ++a)
+                        for (uint32_t c = a; c < (o.haploid ? a + 1 : r.n_alleles); ++c, ++q) {
+                            if (std::isnan(b.probs[q])) snprintf(num, sizeof num, "-nan"); // 0.0/0.0 on x86, as the reference prints it
+                            else snprintf(num, sizeof num, "%f", b.probs[q]);               // std::to_string(double)
+                            out += (first ? "" : ",") + gname((int)a, (int)c) + ":" + num;
+                            first = false;
+                        }
+                } else {
+                    // early-outs: one (best_geno, 0) per over-covered allele, or a single entry; 0/0 prints -nan
+                    size_t entries = 1;
+                    if (st == MG_GT_OVERCOV) {
+                        entries = 0;
+                        for (uint32_t a = 0; a < r.n_alleles; ++a) entries += (int)cov[a] > (int)o.max_coverage;
+                    }
+                    for (size_t e = 0; e < entries; ++e) out += (e ? "," : "") + best_default + (st == MG_GT_SINGLE ? ":1.000000" : ":-nan");
+                }
+            } else
+                out += ".";
+            out += "\tGT:GQ\t";
+            out += gname(b.g1[r.slot], b.g2[r.slot]); // early-outs and "nothing beats 0.0" come back as 0 / 0/0
+            out += ":" + std::to_string(b.gq[r.slot]) + "\n";
+        }
+        std::cout << out;
+        recs.clear();
+        iso = Batch();
+        gen = Batch();
+    };
+
+    auto prefix_of = [&](const Variant &v) {
+        std::string s = v.seq_name + "\t" + std::to_string(v.ref_pos + 1) + "\t" + v.idx + "\t" + v.ref_sub + "\t";
+        for (size_t i = 0; i < v.alts.size(); ++i) s += (i ? "," : "") + v.alts[i];
+        s += "\t";
+        s += std::isnan(v.quality) ? "." : fmt_float(v.quality);
+        return s;
+    };
+
+    const size_t n = for_each_block(vcf, o, refs, false, nullptr, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
+        const bool lone = vb.is_lone_short() && contig_base.count(seq_name);
+        if (lone) {
+            const Variant &v = vb.vars[0];
+            const uint32_t A = (uint32_t)v.n_alleles();
+            recs.push_back({prefix_of(v), A, true, iso.n(), iso.var_allele_off.back(), iso.var_gt_off.back()});
+            const bool eligible = v.is_present && v.ref_pos >= (int)o.k && v.ref_pos <= (int)reference.size() - (int)o.k; // var_block.hpp:104
+            uint64_t mask = 0;
+            if (eligible)
+                for (size_t g = 0; g < v.genotypes.size(); ++g) { // build_alleles_combs on a chain of one
+                    mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
+                    if (!o.haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
+                }
+            iso.pos.push_back(contig_base.at(seq_name) + (uint64_t)std::max(v.ref_pos, 0));
+            iso.present.push_back(mask);
+            iso.flags.push_back(eligible ? 1 : 0);
+            for (uint32_t a = 0; a < A; ++a) {
+                const std::string &al = v.allele((int)a);
+                iso.pool.insert(iso.pool.end(), al.begin(), al.end());
+                iso.allele_off.push_back((uint32_t)iso.pool.size());
+                iso.freq.push_back(v.frequencies[a]);
+            }
+            iso.var_allele_off.push_back(iso.var_allele_off.back() + A);
+            iso.var_gt_off.push_back(iso.var_gt_off.back() + n_gt(A));
+        } else {
+            const auto sigs = vb.extract(reference, o.haploid); // main.cpp:556
+            for (size_t vi = 0; vi < vb.vars.size(); ++vi) {
+                const Variant &v = vb.vars[vi];
+                const uint32_t A = (uint32_t)v.n_alleles();
+                recs.push_back({prefix_of(v), A, false, gen.n(), gen.var_allele_off.back(), gen.var_gt_off.back()});
+                for (uint32_t a = 0; a < A; ++a) {
+                    auto it = sigs[vi].find((int)a);
+                    if (it != sigs[vi].end())
+                        for (const auto &sig : it->second) {
+                            for (const auto &kmer : sig) {
+                                gen.rows.add(kmer);
+                                gen.is_ref.push_back(a == 0);
+                            }
+                            gen.sig_kmer_off.push_back(gen.rows.n);
+                        }
+                    gen.allele_sig_off.push_back(gen.sig_kmer_off.size() - 1);
+                    gen.freq.push_back(v.frequencies[a]);
+                }
+                gen.var_allele_off.push_back(gen.var_allele_off.back() + A);
+                gen.var_gt_off.push_back(gen.var_gt_off.back() + n_gt(A));
+            }
+        }
+        if (recs.size() >= 200000) run_and_print();
+    });
+    run_and_print();
+    std::cout.flush();
+    pelapsed("Processed " + std::to_string(n) + " variants");
+    pelapsed("Execution completed");
+    return 0;
+}
+
+// dump-kmers: host-only view of the enumerator (tests compare it with the oracle's block model)
+int dump_main(const Options &o)
+{
+    Reference refs;
+    if (!read_fasta(o.fasta_path, o.strip_chr, refs)) {
+        std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
+        return 1;
+    }
+    VcfReader vcf(o.vcf_path, o.samples);
+    if (!vcf.ok()) {
+        std::cerr << vcf.error << std::endl;
+        return 1;
+    }
+    const bool for_index = o.kmc_path == "index";
+    for_each_block(vcf, o, refs, for_index, nullptr, [&](Block &vb, const std::string &, const std::string &reference) {
+        const auto sigs = vb.extract(reference, o.haploid);
+        std::cout << "BLOCK " << vb.vars.size() << (vb.is_lone_short() ? " lone" : "") << "\n";
+        for (size_t vi = 0; vi < vb.vars.size(); ++vi) {
+            const Variant &v = vb.vars[vi];
+            std::cout << "VAR " << v.seq_name << " " << v.ref_pos + 1 << " " << v.ref_sub;
+            for (const auto &a : v.alts) std::cout << " " << a;
+            std::cout << " present=" << v.is_present << "\n";
+            for (const auto &as : sigs[vi]) {
+                std::vector<std::string> lines;
+                for (const auto &sig : as.second) {
+                    std::string l;
+                    for (const auto &kmer : sig) l += (l.empty() ? "" : ",") + kmer;
+                    lines.push_back(l);
+                }
+                std::sort(lines.begin(), lines.end()); // signature order is unordered_set order in the reference
+                for (const auto &l : lines) std::cout << "SIG " << as.first << " " << l << "\n";
+            }
+        }
+    });
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        std::cerr << "malva missing arguments\n" << USAGE << std::endl;
+        return 1;
+    }
+    Options o;
+    const std::string cmd = argv[1];
+    try {
+        if (cmd.compare(0, 5, "index") == 0) {
+            if (!parse_arguments(argc - 1, argv + 1, o)) return EXIT_FAILURE;
+            return index_main(o);
+        }
+        if (cmd.compare(0, 4, "call") == 0) {
+            if (!parse_arguments(argc - 1, argv + 1, o)) return EXIT_FAILURE;
+            return call_main(o);
+        }
+        if (cmd == "dump-kmers") {
+            if (!parse_arguments(argc - 1, argv + 1, o)) return EXIT_FAILURE;
+            return dump_main(o);
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+    std::cerr << "Could not interpret command " << argv[1] << ".\nAccepted commands are index and call." << std::endl;
+    return 1;
+}

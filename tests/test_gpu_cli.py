@@ -1,0 +1,65 @@
+"""End to end through the C++ driver on the GPU: `malva-geno index` + `malva-geno call`
+(bin/malva-geno over libmalva_hip.so) against the reference's golden VCF and against the oracle
+pipeline on clustered synthetic panels."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import vcf_synth
+from oracle import kmc_standin, pipeline
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin", "malva-geno")
+
+
+def run_cli(args, **kw):
+    if not os.path.exists(BIN):
+        pytest.fail("bin/malva-geno not built: run `make cli`")
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=900, **kw)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def test_haploid_example_byte_identical(tmp_path, golden_dir):
+    """README.md:131-140: MALVA -1 -k 35 -r 43 -b 1 -f AF haploid.fa haploid.vcf haploid.fq"""
+    fa = os.path.join(golden_dir, "haploid.fa")
+    vcf = str(tmp_path / "haploid.vcf.gz")
+    shutil.copy(os.path.join(golden_dir, "haploid.vcf.gz"), vcf)
+    prefix = str(tmp_path / "haploid_malva43.kmercount")
+    with open(prefix + ".txt", "w") as fh:
+        for km, c in kmc_standin.count_fastq(os.path.join(golden_dir, "haploid.fq"), 43):
+            fh.write("%s\t%d\n" % (km.decode(), c))
+    common = ["-1", "-k", "35", "-r", "43", "-b", "1", "-f", "AF", fa, vcf, prefix]
+    run_cli(["index"] + common)
+    out = run_cli(["call"] + common)
+    assert out == open(os.path.join(golden_dir, "haploid.malva.vcf")).read()
+
+
+@pytest.mark.parametrize("seed,haploid,verbose,k,ref_k", [(11, False, True, 35, 43), (12, True, True, 35, 43), (13, False, False, 31, 45),
+                                                            (14, False, True, 35, 63)])
+def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref_k):
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=60)
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, ref_k, seed, table + ".txt")
+    opt = pipeline.Options(haploid=haploid, verbose=verbose, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+    want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+    args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p"] + (["-1"] if haploid else []) + (["-v"] if verbose else [])
+    args += [prefix + ".fa", prefix + ".vcf", table]
+    run_cli(["index"] + args)
+    got = run_cli(["call"] + args)
+    assert got.count("\n") == want.count("\n")
+    strip = lambda s: "\n".join(";".join(p for p in l.split(";") if not p.startswith("GTS=")) if "GTS=" in l else l for l in s.split("\n"))
+    assert strip(got) == strip(want)                 # header, records, COVS, GT, GQ: identical
+    if got != want:                                   # GTS holds printf("%f") of doubles that may differ in the last bit of exp()
+        for a, b in zip(got.split("\n"), want.split("\n")):
+            if a != b:
+                fa = [float(x.split(":")[1]) for x in a.split("GTS=")[1].split("\t")[0].split(",")]
+                fb = [float(x.split(":")[1]) for x in b.split("GTS=")[1].split("\t")[0].split(",")]
+                assert all(abs(x - y) <= 1.000001e-6 or (x != x and y != y) for x, y in zip(fa, fb)), (a, b)
+    assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20

@@ -1,0 +1,105 @@
+"""Random clustered VCF + FASTA fixtures for the host-enumerator and CLI tests: SNPs, MNPs,
+insertions (some >= k), deletions, multi-allelic sites, overlapping records, phased and unphased
+genotypes, a non-present record, records near contig ends, two contigs, N/IUPAC in the reference."""
+import numpy as np
+
+
+def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35):
+    rng = np.random.default_rng(seed)
+    contigs = {}
+    for name, length in (("1", 9000), ("chr2", 4000)):
+        g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length)
+        for p in rng.integers(0, length, size=6):
+            g[p] = rng.choice(np.frombuffer(b"NRY", dtype=np.uint8))
+        contigs[name] = bytes(g).decode()
+    records = []
+    for name, seq in contigs.items():
+        centres = np.sort(rng.choice(np.arange(10, len(seq) - 10), size=n_clusters if name == "1" else n_clusters // 3, replace=False))
+        used = set()
+        for c in centres:
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(c + rng.integers(0, 28))
+                if pos in used or pos >= len(seq) - 70:
+                    continue
+                used.add(pos)
+                kind = rng.integers(0, 10)
+                ref_len = 1 if kind < 6 else int(rng.integers(1, 9))
+                ref = seq[pos:pos + ref_len]
+                if any(ch not in "ACGT" for ch in ref):
+                    continue
+                n_alt = 1 if rng.random() < 0.75 else int(rng.integers(2, 4))
+                alts = []
+                while len(alts) < n_alt:
+                    r = rng.random()
+                    alen = 1 if r < 0.55 else (int(rng.integers(2, 12)) if r < 0.95 else int(rng.integers(k, k + 8)))
+                    a = "".join(rng.choice(list("ACGT"), size=alen))
+                    if a != ref and a not in alts:
+                        alts.append(a)
+                if rng.random() < 0.04:
+                    alts.append("<DEL>")          # symbolic: dropped by the reader
+                records.append((name, pos, ref, alts))
+    records.sort(key=lambda r: (list(contigs).index(r[0]), r[1]))
+    samples = ["S%d" % i for i in range(n_samples)]
+    lines = ["##fileformat=VCFv4.2", '##INFO=<ID=AF,Number=A,Type=Float,Description="af">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">'] + \
+            ["##contig=<ID=%s,length=%d>" % (n, len(s)) for n, s in contigs.items()]
+    lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples))
+    for i, (name, pos, ref, alts) in enumerate(records):
+        real = [a for a in alts if not a.startswith("<")]
+        if i % 23 == 5:
+            af = [0.0] * len(alts)               # f[0] == 1 -> not present
+        else:
+            w = rng.dirichlet(np.ones(len(alts) + 1))[1:]
+            af = [round(float(x), 4) for x in w]
+        gts = []
+        for _ in samples:
+            if haploid:
+                gts.append(str(int(rng.integers(0, len(real) + 1))) if rng.random() > 0.03 else ".")
+            else:
+                a, b = int(rng.integers(0, len(real) + 1)), int(rng.integers(0, len(real) + 1))
+                sep = "|" if rng.random() < 0.7 else "/"
+                gts.append("%d%s%d" % (a, sep, b) if rng.random() > 0.03 else "./.")
+        qual = "." if i % 3 else "%d" % (10 + i % 90)
+        lines.append("%s\t%d\t%s\t%s\t%s\t%s\t.\tAF=%s\tGT\t%s" % (name, pos + 1, "." if i % 4 else "rs%d" % i, ref, ",".join(alts), qual,
+                                                                  ",".join("%g" % x for x in af), "\t".join(gts)))
+    with open(path_prefix + ".vcf", "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    with open(path_prefix + ".fa", "w") as fh:
+        for n, s in contigs.items():
+            fh.write(">%s some description\n" % n)
+            for a in range(0, len(s), 60):
+                fh.write(s[a:a + 60].lower() if (a // 60) % 7 == 3 else s[a:a + 60])
+                fh.write("\n")
+    return contigs, records
+
+
+def donor_table(contigs, records, ref_k, seed, path):
+    """a donor carrying a random allele of every record; `KMER count` dump of the canonical ref_k-mers
+    seen >= 2 times in 12x tiled 'reads' of the two donor haplotypes"""
+    from collections import Counter
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    counts = Counter()
+    for hap in range(2):
+        for name, seq in contigs.items():
+            out, last = [], 0
+            for (cn, pos, ref, alts) in records:
+                real = [a for a in alts if not a.startswith("<")]
+                if cn != name or pos < last:
+                    continue
+                pick = int(rng.integers(0, len(real) + 1))
+                out.append(seq[last:pos]); out.append(ref if pick == 0 else real[pick - 1])
+                last = pos + len(ref)
+            out.append(seq[last:])
+            donor = "".join(out).encode()
+            depth = int(rng.integers(3, 9))
+            for p in range(len(donor) - ref_k + 1):
+                w = donor[p:p + ref_k]
+                if w.strip(b"ACGT"):
+                    continue
+                rc = w.translate(comp)[::-1]
+                counts[min(w, rc)] += depth
+    with open(path, "w") as fh:
+        for km, c in sorted(counts.items()):
+            if c >= 2:
+                fh.write("%s\t%d\n" % (km.decode(), min(c, 255)))
