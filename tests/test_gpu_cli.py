@@ -42,7 +42,7 @@ def test_haploid_example_byte_identical(tmp_path, golden_dir):
                                                             (14, False, True, 35, 63)])
 def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref_k):
     prefix = str(tmp_path / "case")
-    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=60)
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=60, vcf_strip_chr=True)
     table = str(tmp_path / "donor.kmers")
     vcf_synth.donor_table(contigs, records, ref_k, seed, table + ".txt")
     opt = pipeline.Options(haploid=haploid, verbose=verbose, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)

@@ -4,7 +4,7 @@ genotypes, a non-present record, records near contig ends, two contigs, N/IUPAC 
 import numpy as np
 
 
-def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35):
+def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False):
     rng = np.random.default_rng(seed)
     contigs = {}
     for name, length in (("1", 9000), ("chr2", 4000)):
@@ -60,6 +60,8 @@ def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35
                 sep = "|" if rng.random() < 0.7 else "/"
                 gts.append("%d%s%d" % (a, sep, b) if rng.random() > 0.03 else "./.")
         qual = "." if i % 3 else "%d" % (10 + i % 90)
+        if vcf_strip_chr and name.startswith("chr"):
+            name = name[3:]                     # matches the FASTA id only under -p/--strip-chr
         lines.append("%s\t%d\t%s\t%s\t%s\t%s\t.\tAF=%s\tGT\t%s" % (name, pos + 1, "." if i % 4 else "rs%d" % i, ref, ",".join(alts), qual,
                                                                   ",".join("%g" % x for x in af), "\t".join(gts)))
     with open(path_prefix + ".vcf", "w") as fh:
