@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--b", type=int, default=4, help="filter size in units of 2^33 bits (malva-geno -b)")
     ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
     ap.add_argument("--cpu-variants", type=float, default=2e5)
-    ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident summary bitmaps")
+    ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share GPU 0 and reduce over gloo: exercises the multi-rank code path on a 1-GPU box (numbers meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -62,10 +64,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     K, R = 35, 43
     n_rows = int(args.kmers)

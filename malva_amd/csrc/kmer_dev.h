@@ -120,6 +120,12 @@ __device__ __forceinline__ u64 xxh3_packed(U128 c, int len)
 {
     return len > 32 ? xxh3_packed_33to64(c.lo, c.hi, len) : xxh3_packed_17to32(c.lo, c.hi, len);
 }
+// LEN known at compile time (33..64): the fixed-length form; LEN == 0: runtime length
+template <int LEN> __device__ __forceinline__ u64 xxh3_packed_k(U128 c, int len_rt)
+{
+    if constexpr (LEN >= 33 && LEN <= 64) return xxh3_packed_fixed<LEN>(c.lo, c.hi);
+    else return xxh3_packed(c, len_rt);
+}
 
 // ---- hash -> bit index (hash % _size, bloom_filter.hpp:84) --------------------
 // size = odd * 2^shift.  x mod size = ((x >> shift) mod odd) << shift | (x & (2^shift - 1)).

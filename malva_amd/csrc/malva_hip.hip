@@ -353,14 +353,20 @@ __global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0,
 // atomic per ~500+ entries: a returning atomic per appending wave on a single counter
 // word serialises at ~11 ns each (90 % of the first version's time, and still a third
 // of the filter kernel with per-wave staging at a 5 % append rate).
-template <int CAP, bool WITH_KEY> struct BlockStage {
-    u32 *rows;  // [CAP]
-    u64 *klo;   // [CAP] canonical centre k-mer travels with the row (WITH_KEY) so the
-    u64 *khi;   //       consumer does not re-fetch two random table lines per entry
-    u32 *n;     // entries staged
+//
+// A list entry IS the table row (hi, lo, count): the consumers never go back to the
+// table, which would cost two or three random 128-byte lines per entry.
+struct RowList {
+    u64 *hi, *lo;
+    u32 *cnt;
+};
+template <int CAP> struct BlockStage {
+    u64 *hi, *lo; // [CAP]
+    u32 *cnt;     // [CAP]
+    u32 *n;       // entries staged
     unsigned long long *base;
     // every lane of the wave must call this (it ballots)
-    __device__ __forceinline__ void push(bool take, u32 row, U128 key)
+    __device__ __forceinline__ void push(bool take, U128 m, u32 count)
     {
         const u64 mask = __ballot(take);
         if (!mask) return;
@@ -370,28 +376,24 @@ template <int CAP, bool WITH_KEY> struct BlockStage {
         off = __shfl(off, leader, 64);
         if (take) {
             const u32 q = off + __popcll(mask & ((1ULL << lane) - 1));
-            rows[q] = row;
-            if (WITH_KEY) {
-                klo[q] = key.lo;
-                khi[q] = key.hi;
-            }
+            lo[q] = m.lo;
+            hi[q] = m.hi;
+            cnt[q] = count;
         }
     }
     // every thread of the workgroup must call this; flushes when more than `keep` entries are staged
-    __device__ __forceinline__ void flush_if_above(u32 keep, u32 *g_rows, u64 *g_lo, u64 *g_hi, unsigned long long *g_count)
+    __device__ __forceinline__ void flush_if_above(u32 keep, const RowList &g, unsigned long long *g_count)
     {
         __syncthreads();
-        const u32 cnt = *n;
-        if (cnt > keep) {
-            if (threadIdx.x == 0) *base = atomicAdd(g_count, (unsigned long long)cnt);
+        const u32 c = *n;
+        if (c > keep) {
+            if (threadIdx.x == 0) *base = atomicAdd(g_count, (unsigned long long)c);
             __syncthreads();
             const unsigned long long b = *base;
-            for (u32 j = threadIdx.x; j < cnt; j += TPB) {
-                g_rows[b + j] = rows[j];
-                if (WITH_KEY) {
-                    g_lo[b + j] = klo[j];
-                    g_hi[b + j] = khi[j];
-                }
+            for (u32 j = threadIdx.x; j < c; j += TPB) {
+                g.hi[b + j] = hi[j];
+                g.lo[b + j] = lo[j];
+                g.cnt[b + j] = cnt[j];
             }
             __syncthreads();
             if (threadIdx.x == 0) *n = 0;
@@ -404,44 +406,46 @@ template <int CAP, bool WITH_KEY> struct BlockStage {
 //
 // ROWS table rows per thread and iteration, in phases so that the memory operations of
 // one phase are all in flight together:
-//   A  load ROWS x (hi, lo)                 -- coalesced 8-byte loads, the only HBM stream
+//   A  load ROWS x (hi, lo, cnt)            -- coalesced, non-temporal: the only HBM stream
 //   B  canonicalise, XXH3, slot             -- pure VALU
-//   C  load ROWS gate words                 -- random 8-byte loads from a 2 MiB bitmap (L2)
+//   C  load ROWS gate words                 -- random 8-byte loads from a 4 MiB bitmap (L2)
 //   D  test, stage open rows
 // `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
 // 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
 template <int KC, int RC, int ROWS>
-__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, u64 n,
-                                                          int k_rt, int r_rt, BFView bf, u32 *open_row, u64 *open_lo,
-                                                          u64 *open_hi, unsigned long long *counters, int ablate)
+__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
+                                                          const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt, BFView bf,
+                                                          RowList open, unsigned long long *counters, int ablate)
 {
-    constexpr int CAP = TPB * ROWS + 768;
-    __shared__ u32 sh_rows[CAP];
-    __shared__ u64 sh_lo[CAP], sh_hi[CAP];
+    constexpr int CAP = TPB * ROWS + 256;
+    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
+    __shared__ u32 sh_cnt[CAP];
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
-    BlockStage<CAP, true> st{sh_rows, sh_lo, sh_hi, &sh_n, &sh_base};
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
     const u64 step = (u64)gridDim.x * TPB * ROWS;
     for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
-        U128 c[ROWS];
+        U128 m[ROWS];
+        u32 count[ROWS];
         u64 idx[ROWS], gate[ROWS];
         bool valid[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // A
             const u64 i = base + (u64)j * TPB + threadIdx.x;
             valid[j] = i < n;
-            c[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
-            c[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
+            m[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
+            m[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
+            count[j] = valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // B
-            const U128 m = c[j];
-            if (!(ablate & 8)) c[j] = canon_sub(m, mform_to_lform(m, r), r, off, k);
-            const u64 h = (ablate & 4) ? (c[j].lo ^ c[j].hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed(c[j], k);
+            U128 c = m[j];
+            if (!(ablate & 8)) c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+            const u64 h = (ablate & 4) ? (c.lo ^ c.hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed_k<KC>(c, k);
             idx[j] = mod_size(h, bf.mod);
         }
 #pragma unroll
@@ -450,68 +454,69 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // D
             const u64 gm = gate_mask(bf, idx[j]);
-            const bool open = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
-            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)c[j].hi));
-            st.push(open, (u32)(base + (u64)j * TPB + threadIdx.x), c[j]);
+            const bool open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
+            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
+            st.push(open_j, m[j], count[j]);
         }
-        st.flush_if_above(CAP - TPB * ROWS, open_row, open_lo, open_hi, &counters[0]); // room for one more full iteration
+        st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
     }
-    st.flush_if_above(0, open_row, open_lo, open_hi, &counters[0]);
+    st.flush_if_above(0, open, &counters[0]);
 }
 
 template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_probe_kernel(const u32 *__restrict__ cnt, int k_rt, BFView bf, MapView map,
-                                                         const u32 *open_row, const u64 *open_lo, const u64 *open_hi,
-                                                         u32 *hit_row, unsigned long long *counters)
+__global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
+                                                         unsigned long long *counters)
 {
-    constexpr int CAP = TPB + 768;
-    __shared__ u32 sh_rows[CAP];
+    constexpr int CAP = TPB + 256;
+    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
+    __shared__ u32 sh_cnt[CAP];
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
-    BlockStage<CAP, false> st{sh_rows, nullptr, nullptr, &sh_n, &sh_base};
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
-    const int k = KC > 0 ? KC : k_rt;
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
     const u64 n_open = counters[0];
     const u64 step = (u64)gridDim.x * TPB;
     for (u64 base = (u64)blockIdx.x * TPB; base < n_open; base += step) {
         const u64 j = base + threadIdx.x;
         bool hit = false;
-        u32 row = 0;
+        U128 m{0, 0};
+        u32 count = 0;
         if (j < n_open) {
-            row = open_row[j];
-            const U128 c{open_lo[j], open_hi[j]};
-            const u64 h = xxh3_packed(c, k);
+            m = U128{open.lo[j], open.hi[j]};
+            count = open.cnt[j];
+            const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
+            const u64 h = xxh3_packed_k<KC>(c, k);
             const u64 idx = mod_size(h, bf.mod);
             const u64 word = bf.words[idx >> 6];
             const long long s = map_find(map, c, h);
-            if (s >= 0) atomicAdd(&map.vals[map.ids[s]], cnt[row]); // ref_bf.increment (main.cpp:495)
+            if (s >= 0) atomicAdd(&map.vals[map.ids[s]], count); // ref_bf.increment (main.cpp:495)
             hit = (word >> (idx & 63)) & 1;
         }
-        st.push(hit, row, U128{0, 0});
-        st.flush_if_above(CAP - TPB, hit_row, nullptr, nullptr, &counters[1]);
+        st.push(hit, m, count);
+        st.flush_if_above(CAP - TPB, hits, &counters[1]);
     }
-    st.flush_if_above(0, hit_row, nullptr, nullptr, &counters[1]);
+    st.flush_if_above(0, hits, &counters[1]);
 }
 
 template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_hits_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
-                                                        const u32 *__restrict__ cnt, int k_rt, int r_rt, BFView bf, BFView ctx,
-                                                        const u32 *hit_row, unsigned long long *counters)
+__global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFView bf, BFView ctx, RowList hits,
+                                                        unsigned long long *counters)
 {
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
     const u64 nh = counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] += nh;
     for (u64 j = (u64)blockIdx.x * TPB + threadIdx.x; j < nh; j += (u64)gridDim.x * TPB) {
-        const u32 row = hit_row[j];
-        const U128 m{lo[row], hi[row]};
+        const U128 m{hits.lo[j], hits.hi[j]};
         const U128 l = mform_to_lform(m, r);
         const U128 cc = canon_sub(m, l, r, 0, r);
-        const u64 cidx = mod_size(xxh3_packed(cc, r), ctx.mod);
+        const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
         if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
-        const u64 idx = mod_size(xxh3_packed(canon_sub(m, l, r, off, k), k), bf.mod);
-        atomicAdd(&bf.counts[bf_rank(bf, idx)], cnt[row]);                // bf.increment (main.cpp:498)
+        const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
+        atomicAdd(&bf.counts[bf_rank(bf, idx)], hits.cnt[j]);             // bf.increment (main.cpp:498)
     }
 }
 
@@ -731,7 +736,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_hitrow, s_hitidx, s_openlo, s_openhi, s_misc[8];
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8];
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
     float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
@@ -743,7 +748,7 @@ struct mg_ctx {
     int use_summary = 1;
     bool gate_dirty = false; // something has been inserted into `bf`
     int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
-    int scan_grid = 4096; // workgroups of the filter kernel (16 per CU)
+    int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
     int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
@@ -1071,7 +1076,9 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     }
     map_free_table(c->map);
     hipFree(c->map.vals);
-    for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr, &c->s_hitrow, &c->s_hitidx, &c->s_openlo, &c->s_openhi}) hipFree(s->p);
+    for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr}) hipFree(s->p);
+    for (auto &s : c->s_open) hipFree(s.p);
+    for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
     hipFree(c->d_hit_count);
     hipFree(c->d_ln);
@@ -1105,7 +1112,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
-    else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 4096;
+    else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 8192;
     else if (!strcmp(name, "gate_log2") || !strcmp(name, "gate_k")) {
         if (c->map.rows_total || c->gate_dirty) return fail(c, MG_ERR_STATE, "%s must be set before the first insert", name);
         if (!strcmp(name, "gate_k")) {
@@ -1356,32 +1363,30 @@ MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 
 namespace {
 template <int KC, int RC, int ROWS>
-void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, u64 n, u32 *open_row, u64 *open_lo, u64 *open_hi)
+void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
 {
     const u64 per_block = (u64)TPB * ROWS;
     const unsigned grid = (unsigned)std::min<u64>((n + per_block - 1) / per_block, (u64)c->scan_grid);
-    hipLaunchKernelGGL((scan_filter_kernel<KC, RC, ROWS>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, n, (int)c->k,
-                       (int)c->ref_k, view(c, MG_BF_ALT), open_row, open_lo, open_hi, c->d_hit_count, c->scan_ablate);
+    hipLaunchKernelGGL((scan_filter_kernel<KC, RC, ROWS>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, n, (int)c->k,
+                       (int)c->ref_k, view(c, MG_BF_ALT), open, c->d_hit_count, c->scan_ablate);
 }
 template <int KC, int RC>
-void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, u32 *open_row, u64 *open_lo,
-                       u64 *open_hi, u32 *hit_row, bool timed)
+void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed)
 {
     if (timed) hipEventRecord(c->ev[0], c->stream);
     switch (c->scan_rows) {
-    case 1: launch_filter_rows<KC, RC, 1>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
-    case 2: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
-    case 8: launch_filter_rows<KC, RC, 8>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
-    default: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, n, open_row, open_lo, open_hi); break;
+    case 1: launch_filter_rows<KC, RC, 1>(c, d_hi, d_lo, d_cnt, n, open); break;
+    case 4: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, d_cnt, n, open); break;
+    default: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
     }
     if (timed) hipEventRecord(c->ev[1], c->stream);
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 2048u);
-    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, d_cnt, (int)c->k, view(c, MG_BF_ALT),
-                       view(c), (const u32 *)open_row, (const u64 *)open_lo, (const u64 *)open_hi, hit_row, c->d_hit_count);
+    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
+                       view(c), open, hits, c->d_hit_count);
     if (timed) hipEventRecord(c->ev[2], c->stream);
-    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, 1024u)), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt,
-                       (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX), (const u32 *)hit_row, c->d_hit_count);
+    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, 1024u)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
+                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), hits, c->d_hit_count);
     if (timed) hipEventRecord(c->ev[3], c->stream);
 }
 } // namespace
@@ -1395,13 +1400,12 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.tags) TRY(map_reserve(c, 0));
-    const u64 chunk = 1ULL << 27; // rows per launch triple; list entries are u32 offsets inside a chunk
-    void *orow, *olo, *ohi, *hrow;
+    const u64 chunk = 1ULL << 27; // rows per launch triple (bounds the two lists' worst-case size)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
-    TRY(scratch(c, c->s_hitrow, cap * 4, &orow));
-    TRY(scratch(c, c->s_hitidx, cap * 4, &hrow));
-    TRY(scratch(c, c->s_openlo, cap * 8, &olo));
-    TRY(scratch(c, c->s_openhi, cap * 8, &ohi));
+    void *p[6];
+    Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
+    for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
+    const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
     const bool d35_43 = c->k == 35 && c->ref_k == 43;
     c->stats_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
@@ -1410,8 +1414,8 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         const u64 *ph = (const u64 *)d_hi + r0, *pl = (const u64 *)d_lo + r0;
         const u32 *pc = (const u32 *)d_cnt + r0;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
-        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, (u32 *)orow, (u64 *)olo, (u64 *)ohi, (u32 *)hrow, r0 == 0);
-        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, (u32 *)orow, (u64 *)olo, (u64 *)ohi, (u32 *)hrow, r0 == 0);
+        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0);
+        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0);
         HIP_TRY(c, hipGetLastError());
     }
     c->stats_valid = true;
@@ -1663,8 +1667,8 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
     }
     const size_t ng = var_gt_off[n_vars];
     void *d_pr, *d_go;
-    TRY(scratch(c, c->s_hitrow, 8 * (ng ? ng : 1), &d_pr));
-    TRY(upload(c, c->s_hitidx, var_gt_off, 8 * (n_vars + 1), &d_go));
+    TRY(scratch(c, c->s_open[0], 8 * (ng ? ng : 1), &d_pr));
+    TRY(upload(c, c->s_open[1], var_gt_off, 8 * (n_vars + 1), &d_go));
     TRY(mg_call_isolated_device(c, n_vars, d_pos, d_vo, d_ao, d_pool, d_fr, d_pm, d_fl, error_rate, max_cov, haploid, d_cov, d_g1,
                                 d_g2, d_gq, d_st, d_pr, d_go));
     if (probs && ng) HIP_TRY(c, hipMemcpyAsync(probs, d_pr, 8 * ng, hipMemcpyDeviceToHost, c->stream));
@@ -1739,7 +1743,7 @@ MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out,
     if (!b.mode) return fail(c, MG_ERR_STATE, "sparse export needs the filter finalised (rank directory)");
     if (positions_out && b.nset) {
         void *d;
-        TRY(scratch(c, c->s_openlo, b.nset * 8, &d));
+        TRY(scratch(c, c->s_open[0], b.nset * 8, &d));
         hipLaunchKernelGGL(bit_positions_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, which), b.nwords, (u64 *)d);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(positions_out, d, b.nset * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1768,7 +1772,7 @@ MG_EXPORT int mg_bf_import_sparse(mg_ctx *c, int which, int mode, uint64_t size_
     if (n) {
         void *d;
         int *d_bad = (int *)(c->d_hit_count + 3);
-        TRY(upload(c, c->s_openlo, positions, n * 8, &d));
+        TRY(upload(c, c->s_open[0], positions, n * 8, &d));
         HIP_TRY(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
         hipLaunchKernelGGL(set_bits_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, view(c, which), (const u64 *)d, (u64)n, b.size,
                            d_bad);

@@ -192,6 +192,30 @@ __device__ __forceinline__ u64 xxh3_packed_33to64(u64 lo, u64 hi, int len)
     acc += mul128_fold64(ascii8(lo, hi, len - 16) ^ sec64_at<16>(), ascii8(lo, hi, len - 8) ^ sec64_at<24>());
     return xxh3_avalanche(acc);
 }
+// The same for a compile-time length 33..64: the ASCII rendering is expanded ONCE into
+// ceil(LEN/4) dwords (one v_perm_b32 each) and the eight overlapping 8-byte reads of
+// XXH3's 33..64-byte path are cut out of them with v_alignbyte_b32, instead of expanding
+// sixteen dwords (the two read sets overlap almost entirely).
+template <int LEN> __device__ __forceinline__ u64 xxh3_packed_fixed(u64 lo, u64 hi)
+{
+    constexpr int NW = (LEN + 3) / 4;
+    u32 w[NW + 1];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = expand4((u32)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFF));
+    w[NW] = 0;
+    auto rd = [&](int o) -> u64 { // little-endian u64 at byte offset o of the ASCII string
+        const int i = o >> 2, s = o & 3;
+        const u32 a = s ? __builtin_amdgcn_alignbyte(w[i + 1], w[i], (u32)s) : w[i];
+        const u32 b = s ? __builtin_amdgcn_alignbyte(w[i + 2 <= NW ? i + 2 : NW], w[i + 1], (u32)s) : w[i + 1];
+        return (u64)a | ((u64)b << 32);
+    };
+    u64 acc = (u64)LEN * P64_1;
+    acc += mul128_fold64(rd(16) ^ sec64_at<32>(), rd(24) ^ sec64_at<40>());
+    acc += mul128_fold64(rd(LEN - 32) ^ sec64_at<48>(), rd(LEN - 24) ^ sec64_at<56>());
+    acc += mul128_fold64(rd(0) ^ sec64_at<0>(), rd(8) ^ sec64_at<8>());
+    acc += mul128_fold64(rd(LEN - 16) ^ sec64_at<16>(), rd(LEN - 8) ^ sec64_at<24>());
+    return xxh3_avalanche(acc);
+}
 // 17 <= len <= 32
 __device__ __forceinline__ u64 xxh3_packed_17to32(u64 lo, u64 hi, int len)
 {

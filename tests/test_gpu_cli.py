@@ -63,3 +63,24 @@ def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref
                 fb = [float(x.split(":")[1]) for x in b.split("GTS=")[1].split("\t")[0].split(",")]
                 assert all(abs(x - y) <= 1.000001e-6 or (x != x and y != y) for x, y in zip(fa, fb)), (a, b)
     assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
+
+
+def test_sars_cov2_panel_config_c1(tmp_path, golden_dir):
+    """BASELINE config C1: example/reference_sarsCov2.fasta + example/sars_cov2.vcf.gz (15,154 records x 27,934 haploid
+    samples, 3,479 multi-allelic), k=35 r=43 b=1, the haploid example's reads as the sample.  The compiled reference,
+    run on these inputs during the survey, emits 15,154 records with exactly two non-reference
+    calls: 17747 C>T 1:94 and 17858 A>G 1:100."""
+    fa = os.path.join(golden_dir, "reference_sarsCov2.fasta")
+    vcf = str(tmp_path / "sars_cov2.vcf.gz")
+    shutil.copy(os.path.join(golden_dir, "sars_cov2.vcf.gz"), vcf)
+    prefix = str(tmp_path / "sample.kmercount")
+    with open(prefix + ".txt", "w") as fh:
+        for km, c in kmc_standin.count_fastq(os.path.join(golden_dir, "haploid.fq"), 43):
+            fh.write("%s\t%d\n" % (km.decode(), c))
+    common = ["-1", "-k", "35", "-r", "43", "-b", "1", "-f", "AF", fa, vcf, prefix]
+    run_cli(["index"] + common)
+    out = run_cli(["call"] + common)
+    recs = [l.split("\t") for l in out.split("\n") if l and not l.startswith("#")]
+    assert len(recs) == 15154
+    nonref = [(r[1], r[3], r[4], r[9]) for r in recs if not r[9].startswith("0:")]
+    assert nonref == [("17747", "C", "T", "1:94"), ("17858", "A", "G", "1:100")]
