@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
+    ap.add_argument("--scan-ablate", type=int, default=0,
+                    help="profiling only (results invalid): filter-kernel ablation mask, see scan_filter_kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and reduce over gloo: exercises the multi-rank code path on a 1-GPU box (numbers meaningless)")
     args = ap.parse_args()
@@ -88,6 +90,8 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.no_summary:
         ctx.set_option("use_summary", 0)
+    if args.scan_ablate:
+        ctx.set_option("scan_ablate", args.scan_ablate)
     t0 = time.time()
     sig, _ = synth.snp_signature_rows(panel, K)
     stride = 40
@@ -243,6 +247,15 @@ def main():
                                   "%d variants through its loop-B restatement" % (ns, nv),
                         "variants_per_s": nv / cpu_geno_s}
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_scan_filter.json")
+    if os.path.exists(tpath) and not args.scan_ablate:
+        # HBM bytes per launch cannot be counted from inside this process: it comes from the rocprofv3 PMC passes
+        # of tools/profile_gpu.sh on this same command (FETCH_SIZE calibrated on the kernel's own 8-byte-per-lane
+        # stream, WRITE_SIZE as read), committed with the profile it was derived from.
+        t = json.load(open(tpath))
+        if t.get("units_per_launch") == n_rows and t.get("bf_bits") == bf_bits:
+            traffic = t["hbm_bytes_per_launch"]
     if rank == 0:
         total_kmers = n_rows * world * args.steps
         total_vars = n_vars * world * args.steps
@@ -266,7 +279,8 @@ def main():
                        "kmers_per_gpu": n_rows, "variants_per_gpu": n_vars, "bf_bits": bf_bits, "parallelism": "table rows x%d, variants x%d" % (world, world),
                        "summary_bitmaps": not args.no_summary},
             "roofline": {"kernel": "scan_filter_kernel<35,43>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_unit": SCAN_BYTES_PER_KMER,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
+                         "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * n_rows, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": n_rows, "avg_launch_ms": filt_ms},
             "kernels_ms": {"scan_filter": filt_ms, "scan_probe": probe_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg,
                            "gate_open_rows": n_open, "bf_hit_rows": n_hits},

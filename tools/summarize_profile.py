@@ -39,3 +39,34 @@ for k in sorted(acc):
     for c in sorted(acc[k]):
         v = acc[k][c]
         print("    %-24s mean %.6g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# ---- HBM traffic of the filter kernel, calibrated (MI355X_MICROARCH.md, HBM: FETCH_SIZE is uncalibrated for
+# access widths other than 16 B/lane -> calibrate on a known byte count in the kernel's own pattern) ----
+import json
+cal = []
+for f in glob.glob(os.path.join(out, "cal_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "scan_filter" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            cal.append(float(r["Counter_Value"]))
+k = "scan_filter_kernel<35,43>"
+if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+    rows = None
+    try:
+        rows = json.load(open(os.path.join(out, "bench_stats.json")))["config"]["kmers_per_gpu"]
+        bf_bits = json.load(open(os.path.join(out, "bench_stats.json")))["config"]["bf_bits"]
+    except Exception:
+        pass
+    if rows:
+        stream = 20.0 * rows
+        fetch_cal_kb = sum(cal) / len(cal)
+        factor = stream / (fetch_cal_kb * 1024.0)
+        fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+        write_kb = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
+        traffic = factor * fetch_kb * 1024.0 + write_kb * 1024.0
+        print()
+        print("== filter-kernel HBM traffic per launch ==")
+        print("stream-only FETCH_SIZE %.6g KB for a known %.6g B stream -> calibration factor %.3f" % (fetch_cal_kb, stream, factor))
+        print("FETCH_SIZE %.6g KB, WRITE_SIZE %.6g KB -> %.4g B per launch (algorithmic %.4g B)" % (fetch_kb, write_kb, traffic, 44.0 * rows))
+        json.dump({"kernel": k, "units_per_launch": rows, "bf_bits": bf_bits, "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb,
+                   "write_size_kb": write_kb, "fetch_calibration_factor": factor, "calibration": "FETCH_SIZE of the same kernel with only its 20 B/row stream (scan_ablate=3)",
+                   "algorithmic_bytes_per_launch": 44.0 * rows}, open(os.path.join(out, "traffic_scan_filter.json"), "w"), indent=1)
