@@ -48,7 +48,7 @@ for f in glob.glob(os.path.join(out, "cal_FETCH_SIZE", "**", "*counter_collectio
     for r in csv.DictReader(open(f)):
         if "scan_filter" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             cal.append(float(r["Counter_Value"]))
-k = "scan_filter_kernel<35,43>"
+k = "scan_filter_kernel"
 if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
     rows = None
     try:
