@@ -58,7 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
     from malva_amd import BF_ALT, BF_CTX, Context, synth
-    from malva_amd.dist import allreduce_counters_, rank_world
+    from malva_amd.dist import alias_int32, allreduce_counters_, rank_world
 
     rank, world = rank_world()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,8 +141,8 @@ def main():
     d_st = torch.zeros(n_vars, dtype=torch.uint8, device=dev)
     d_goff = dev_i64((3 * np.arange(n_vars + 1)).astype(np.uint64))       # biallelic diploid: 3 genotypes per variant
     d_probs = torch.zeros(3 * n_vars, dtype=torch.float64, device=dev)   # normalised likelihoods (GTS) + workspace
-    n_bf, n_map = ctx.counters_size()
-    d_counters = torch.zeros(n_bf + n_map, dtype=torch.int32, device=dev)
+    cptr, n_bf, n_map = ctx.counters_view()                 # [bf counters | map counters], one allocation inside the context
+    d_counters = alias_int32(cptr, n_bf + n_map, dev)         # reduced in place: no export/import copies
 
     scan_ms = []
 
@@ -150,9 +150,7 @@ def main():
         ctx.counters_reset()
         ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
         if world > 1:
-            ctx.counters_export_device(d_counters.data_ptr())
             allreduce_counters_(d_counters)
-            ctx.counters_import_device(d_counters.data_ptr())
         ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
                                  d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
                                  d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr(), d_probs.data_ptr(), d_goff.data_ptr())

@@ -121,6 +121,10 @@ int mg_counters_size(mg_ctx *ctx, uint64_t *n_bf, uint64_t *n_map);
 int mg_counters_export_device(mg_ctx *ctx, void *d_u32_out);
 int mg_counters_import_device(mg_ctx *ctx, const void *d_u32_in);
 int mg_counters_reset(mg_ctx *ctx);
+/* Zero-copy form: makes the two counter arrays one contiguous device allocation and returns
+ * it (valid until the next insert / finalize / import).  An in-place all-reduce over
+ * d_ptr[0 .. n_bf + n_map) replaces export + all-reduce + import. */
+int mg_counters_view(mg_ctx *ctx, void **d_ptr, uint64_t *n_bf, uint64_t *n_map);
 
 /* ---- per-variant path ----------------------------------------------------- */
 

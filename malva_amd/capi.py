@@ -55,6 +55,7 @@ def lib():
         "mg_counters_export_device": [vp, vp],
         "mg_counters_import_device": [vp, vp],
         "mg_counters_reset": [vp],
+        "mg_counters_view": [vp, vp, vp, vp],
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_reference_upload": [vp, vp, sz],
@@ -84,7 +85,7 @@ def lib():
 EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_synchronize", "mg_bf_insert", "mg_bf_test",
             "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
             "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
-            "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset",
+            "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_lookup_cover", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_set_option"]
@@ -294,6 +295,12 @@ class Context:
 
     def counters_import_device(self, d_ptr):
         self._ck(self._L.mg_counters_import_device(self.h, C.c_void_p(d_ptr)))
+
+    def counters_view(self):
+        """-> (device pointer, n_bf, n_map) of the contiguous [bf | map] u32 counter vector"""
+        p, a, b = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._ck(self._L.mg_counters_view(self.h, C.byref(p), C.byref(a), C.byref(b)))
+        return p.value, a.value, b.value
 
     def counters_reset(self):
         self._ck(self._L.mg_counters_reset(self.h))

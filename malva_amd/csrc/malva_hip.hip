@@ -602,6 +602,32 @@ __device__ __forceinline__ u32 acgt_code(u32 b, bool *ok)
     const u32 c = (b >> 1) & 3;
     return c ^ (c >> 1);
 }
+// n <= 32 bases starting at an arbitrary byte address -> 2-bit L-form, four bases per aligned
+// dword load.  *bad gets bit 4j set when dword j holds a byte outside ACGT (coarse on purpose:
+// a flagged span sends the allele down the exact byte-wise path).  Reads whole aligned dwords,
+// i.e. up to 3 bytes either side of the span: the reference buffer is padded for that.
+__device__ __forceinline__ void pack_span(const u8 *p, int n, u64 *codes, u64 *bad)
+{
+    const u64 addr = (u64)p;
+    const u32 *q = (const u32 *)(addr & ~3ULL);
+    const u32 sh = (u32)(addr & 3);
+    u64 c = 0, b = 0;
+    u32 prev = q[0];
+    for (int j = 0; 4 * j < n; ++j) {
+        const u32 next = q[j + 1];
+        const u32 d = sh ? __builtin_amdgcn_alignbyte(next, prev, sh) : prev;
+        u32 t = (d >> 1) & 0x03030303u; // per byte: A0 C1 G3 T2
+        t ^= (t >> 1) & 0x01010101u;    //           A0 C1 G2 T3
+        const u32 c8 = (t * 0x01041040u) >> 24;
+        const int left = n - 4 * j;
+        const u32 m = left >= 4 ? 0xFFFFFFFFu : ((1u << (8 * left)) - 1);
+        if ((expand4(c8) ^ d) & m) b |= 0xFULL << (4 * j);
+        c |= (u64)(left >= 4 ? c8 : (c8 & ((1u << (2 * left)) - 1))) << (8 * j);
+        prev = next;
+    }
+    *codes = c;
+    *bad = b;
+}
 __device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
 {
     U128 r;
@@ -640,16 +666,8 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
         // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
         u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
         if (packed_ok) {
-            for (int i = 0; i < lmax; ++i) {
-                bool ok;
-                lf |= (u64)acgt_code(site[i - lmax], &ok) << (2 * i);
-                lbad |= (u64)!ok << i;
-            }
-            for (int i = 0; i < rmax; ++i) {
-                bool ok;
-                rf |= (u64)acgt_code(site[ref_size + i], &ok) << (2 * i);
-                rbad |= (u64)!ok << i;
-            }
+            pack_span(site - lmax, lmax, &lf, &lbad);
+            pack_span(site + ref_size, rmax, &rf, &rbad);
         }
         for (u32 a = 0; a < A && a < 64; ++a) {
             if (!((pm >> a) & 1)) continue;
@@ -745,6 +763,7 @@ struct mg_ctx {
     size_t ref_len = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool stats_valid = false;
+    u32 *joined = nullptr; // when set: one allocation holding [bf counters | map counters] (mg_counters_view)
     int use_summary = 1;
     bool gate_dirty = false; // something has been inserted into `bf`
     int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
@@ -849,6 +868,25 @@ MapView view(const mg_ctx *c)
     return v;
 }
 
+// give the two counter arrays their own allocations again (before either has to be resized)
+int unjoin(mg_ctx *c)
+{
+    if (!c->joined) return MG_OK;
+    BFState &b = c->bf[MG_BF_ALT];
+    MapState &m = c->map;
+    u32 *nc = nullptr, *nv = nullptr;
+    HIP_TRY(c, hipMalloc(&nc, (b.nset ? b.nset : 1) * 4));
+    HIP_TRY(c, hipMalloc(&nv, (m.vals_cap ? m.vals_cap : 1) * 4));
+    if (b.nset) HIP_TRY(c, hipMemcpyAsync(nc, b.counts, b.nset * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (m.vals_cap) HIP_TRY(c, hipMemcpyAsync(nv, m.vals, m.vals_cap * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->joined);
+    c->joined = nullptr;
+    b.counts = nc;
+    m.vals = nv;
+    return MG_OK;
+}
+
 // (re)allocate the gate of `bf`: at most 2^gate_log2 bits, one per 2^gate_shift filter bits
 int alloc_gate(mg_ctx *c)
 {
@@ -895,6 +933,7 @@ int map_reserve(mg_ctx *c, u64 extra)
     const u64 need_rows = m.rows_total + extra;
     if (need_rows >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "exact map: more than 2^32-1 insertion rows");
     if (need_rows > m.vals_cap) {
+        TRY(unjoin(c));
         u64 ncap = need_rows + need_rows / 2 + 1024;
         u32 *nv = nullptr;
         HIP_TRY(c, hipMalloc(&nv, ncap * 4));
@@ -1068,6 +1107,11 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     if (!c) return MG_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    if (c->joined) { // the two counter arrays alias one allocation
+        hipFree(c->joined);
+        c->bf[MG_BF_ALT].counts = nullptr;
+        c->map.vals = nullptr;
+    }
     for (auto &b : c->bf) {
         hipFree(b.words);
         hipFree(b.blk);
@@ -1175,6 +1219,7 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
     hipLaunchKernelGGL(blk_add_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, b.blk, b.n_blk, (const u32 *)d_tiles,
                        (u32)total);
     HIP_TRY(c, hipGetLastError());
+    if (which == MG_BF_ALT) TRY(unjoin(c));
     b.nset = total;
     if (b.counts) hipFree(b.counts);
     b.counts = nullptr;
@@ -1487,6 +1532,31 @@ MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
     if (n_map) *n_map = c->map.rows_total;
     return MG_OK;
 }
+MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t *n_map)
+{
+    if (!c || !d_ptr) return MG_ERR_ARG;
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    BFState &b = c->bf[MG_BF_ALT];
+    MapState &m = c->map;
+    if (!c->joined) {
+        const u64 nb = b.nset, nm = m.rows_total;
+        u32 *j = nullptr;
+        HIP_TRY(c, hipMalloc(&j, (nb + nm ? nb + nm : 1) * 4));
+        if (nb) HIP_TRY(c, hipMemcpyAsync(j, b.counts, nb * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (nm) HIP_TRY(c, hipMemcpyAsync(j + nb, m.vals, nm * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(b.counts);
+        hipFree(m.vals);
+        c->joined = j;
+        b.counts = j;
+        m.vals = j + nb;
+        m.vals_cap = nm;
+    }
+    *d_ptr = c->joined;
+    if (n_bf) *n_bf = b.nset;
+    if (n_map) *n_map = m.rows_total;
+    return MG_OK;
+}
 MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
 {
     if (!c || !d_out) return MG_ERR_ARG;
@@ -1591,7 +1661,8 @@ MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
     if (c->d_ref) hipFree(c->d_ref);
     c->d_ref = nullptr;
     c->ref_len = 0;
-    HIP_TRY(c, hipMalloc(&c->d_ref, len ? len : 1));
+    HIP_TRY(c, hipMalloc(&c->d_ref, len + 64)); // padded: pack_span reads whole aligned dwords around a window
+    HIP_TRY(c, hipMemset(c->d_ref, 0, len + 64));
     if (len) HIP_TRY(c, hipMemcpy(c->d_ref, ascii, len, hipMemcpyHostToDevice));
     c->ref_len = len;
     return MG_OK;

@@ -32,3 +32,20 @@ def allreduce_counters_(t):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+class _DevArray:
+    """__cuda_array_interface__ carrier: lets torch alias device memory owned by the HIP library"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+
+def alias_int32(ptr, n, device):
+    """torch int32 tensor over n device words at ptr (no copy; the owner must outlive the tensor)"""
+    import torch
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int32, device=device)
+    t = torch.as_tensor(_DevArray(ptr, n, "<i4"), device=device)
+    assert t.data_ptr() == ptr
+    return t

@@ -85,3 +85,41 @@ def test_scan_is_linear_and_shards_sum():
     whole, twice, a, b = res
     assert np.array_equal((2 * whole[0]) & 0xFFFF, twice[0]) and np.array_equal(2 * whole[1], twice[1])
     assert np.array_equal((a[0] + b[0]) & 0xFFFF, whole[0]) and np.array_equal(a[1] + b[1], whole[1])
+
+
+def test_counters_view_aliases_and_export_import_roundtrip():
+    """the exchange step's two forms: export/import copies, and the zero-copy contiguous view"""
+    import torch
+    from malva_amd.dist import alias_int32
+    k, ref_k, bits = 35, 43, 1 << 22
+    panel = synth.snp_panel(1500, 41)
+    hi, lo, cnt = synth.kmer_table(panel, 60000, k, ref_k, 42)
+    ctx = Context(k, ref_k, bits)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # one stream for torch's ops and the context's: ordered
+    build_index_pair(ctx, panel, k, ref_k, bits)
+    ctx.kmc_scan(hi, lo, cnt)
+    n_bf, n_map = ctx.counters_size()
+    buf = torch.zeros(n_bf + n_map, dtype=torch.int32, device="cuda")
+    ctx.counters_export_device(buf.data_ptr()); ctx.synchronize()
+    before = map_values_by_key(ctx)
+    ptr, a, b = ctx.counters_view()
+    assert (a, b) == (n_bf, n_map)
+    view = alias_int32(ptr, a + b, torch.device("cuda", 0))
+    assert torch.equal(view, buf)                       # same content, now contiguous
+    view *= 2                                           # what an in-place all-reduce of two equal shards would leave
+    torch.cuda.synchronize()
+    after = map_values_by_key(ctx)
+    assert all(after[k_] == 2 * v for k_, v in before.items())
+    ctx.counters_import_device(buf.data_ptr()); ctx.synchronize()
+    assert map_values_by_key(ctx) == before
+    ctx.kmc_scan(hi, lo, cnt)                           # the joined arrays keep working as scan targets
+    assert all(v2 == 2 * v for (_, v), (_, v2) in zip(sorted(before.items()), sorted(map_values_by_key(ctx).items())))
+    ctx.map_insert(rows_of_random(k))                   # growing the map un-joins transparently
+    assert ctx.map_size() == len(before) + 5
+    ctx.close()
+
+
+def rows_of_random(k):
+    rng = np.random.default_rng(99)
+    from malva_amd.capi import rows_of
+    return rows_of([bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=k)) for _ in range(5)])
