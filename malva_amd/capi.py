@@ -1,5 +1,8 @@
 """ctypes binding of include/malva_hip.h.  No fallback: a missing or unloadable
-libmalva_hip.so is an error."""
+libmalva_hip.so is an error.
+
+Note for processes that also use PyTorch-ROCm: import torch (and touch the GPU with it) BEFORE creating a
+Context.  torch bundles its own HIP runtime and fails to find GPUs if /opt/rocm's runtime initialised first."""
 import ctypes as C
 import os
 

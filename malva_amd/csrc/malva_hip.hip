@@ -402,6 +402,44 @@ template <int CAP> struct BlockStage {
     }
 };
 
+// The same per wave (no workgroup barrier anywhere): the four waves of a workgroup then never
+// wait for each other, which matters in the filter kernel where the barrier pair per iteration
+// made every wave run at the pace of the slowest.
+template <int WCAP> struct WaveStage {
+    u64 *hi, *lo; // this wave's [WCAP] slices
+    u32 *cnt;
+    int staged;   // wave-uniform
+    __device__ __forceinline__ void flush(const RowList &g, unsigned long long *g_count)
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(g_count, (unsigned long long)staged);
+        b = __shfl(b, 0, 64);
+        for (int j = lane; j < staged; j += 64) {
+            g.hi[b + j] = hi[j];
+            g.lo[b + j] = lo[j];
+            g.cnt[b + j] = cnt[j];
+        }
+        staged = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // every lane of the wave must call this (it ballots)
+    __device__ __forceinline__ void push(bool take, U128 m, u32 count, const RowList &g, unsigned long long *g_count)
+    {
+        const u64 mask = __ballot(take);
+        if (!mask) return;
+        if (take) {
+            const int q = staged + __popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1));
+            lo[q] = m.lo;
+            hi[q] = m.hi;
+            cnt[q] = count;
+        }
+        staged += __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (staged > WCAP - 64) flush(g, g_count);
+    }
+};
+
 // counters[0] = open rows, [1] = hit rows of the current chunk, [2] = hit rows of the whole call
 //
 // ROWS table rows per thread and iteration, in phases so that the memory operations of
@@ -412,19 +450,26 @@ template <int CAP> struct BlockStage {
 //   D  test, stage open rows
 // `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
 // 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
-template <int KC, int RC, int ROWS>
+// VAR bit 0: per-wave staging (no barriers) instead of per-workgroup; bit 1 (ROWS == 2 only): each
+// thread takes two ADJACENT rows with 16-byte loads instead of two rows TPB apart with 8-byte loads.
+template <int KC, int RC, int ROWS, int VAR>
 __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
                                                           const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt, BFView bf,
                                                           RowList open, unsigned long long *counters, int ablate)
 {
-    constexpr int CAP = TPB * ROWS + 256;
+    constexpr bool WAVE = VAR & 1, VEC = (VAR & 2) && ROWS == 2;
+    constexpr int CAP = WAVE ? (TPB / 64) * 192 : TPB * ROWS + 256;
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
     __shared__ u32 sh_cnt[CAP];
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
     BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
-    if (threadIdx.x == 0) sh_n = 0;
-    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    WaveStage<192> ws{sh_hi + wv * 192, sh_lo + wv * 192, sh_cnt + wv * 192, 0};
+    if (!WAVE) {
+        if (threadIdx.x == 0) sh_n = 0;
+        __syncthreads();
+    }
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
     const u64 step = (u64)gridDim.x * TPB * ROWS;
@@ -433,13 +478,27 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
         u32 count[ROWS];
         u64 idx[ROWS], gate[ROWS];
         bool valid[ROWS];
+        if (VEC && base + (u64)TPB * 2 <= n) { // A, whole tile inside the table (table bases are 16-byte aligned)
+            typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
+            typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
+            const u64 i = base + 2 * (u64)threadIdx.x;
+            const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
+            const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
+            const v2u32 c2 = __builtin_nontemporal_load((const v2u32 *)(cnt + i));
+            m[0] = U128{l2.x, h2.x};
+            m[ROWS - 1] = U128{l2.y, h2.y};
+            count[0] = c2.x;
+            count[ROWS - 1] = c2.y;
+            valid[0] = valid[ROWS - 1] = true;
+        } else {
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // A
-            const u64 i = base + (u64)j * TPB + threadIdx.x;
-            valid[j] = i < n;
-            m[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
-            m[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
-            count[j] = valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
+            for (int j = 0; j < ROWS; ++j) { // A
+                const u64 i = VEC ? base + 2 * (u64)threadIdx.x + j : base + (u64)j * TPB + threadIdx.x;
+                valid[j] = i < n && (!VEC || i < base + (u64)TPB * 2);
+                m[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
+                m[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
+                count[j] = valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
+            }
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // B
@@ -456,11 +515,15 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
             const u64 gm = gate_mask(bf, idx[j]);
             const bool open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
             if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
-            st.push(open_j, m[j], count[j]);
+            if (WAVE) ws.push(open_j, m[j], count[j], open, &counters[0]);
+            else st.push(open_j, m[j], count[j]);
         }
-        st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
+        if (!WAVE) st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
     }
-    st.flush_if_above(0, open, &counters[0]);
+    if (WAVE) {
+        if (ws.staged) ws.flush(open, &counters[0]);
+    } else
+        st.flush_if_above(0, open, &counters[0]);
 }
 
 template <int KC, int RC>
@@ -769,6 +832,7 @@ struct mg_ctx {
     int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
     int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
+    int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
     int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
     std::string err;
@@ -1156,6 +1220,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
+    else if (!strcmp(name, "scan_variant")) c->scan_variant = (int)value & 3;
     else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 8192;
     else if (!strcmp(name, "gate_log2") || !strcmp(name, "gate_k")) {
         if (c->map.rows_total || c->gate_dirty) return fail(c, MG_ERR_STATE, "%s must be set before the first insert", name);
@@ -1407,13 +1472,25 @@ MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 // ---- KMC scan ----------------------------------------------------------------------------
 
 namespace {
-template <int KC, int RC, int ROWS>
-void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
+template <int KC, int RC, int ROWS, int VAR>
+void launch_filter_var(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
 {
     const u64 per_block = (u64)TPB * ROWS;
     const unsigned grid = (unsigned)std::min<u64>((n + per_block - 1) / per_block, (u64)c->scan_grid);
-    hipLaunchKernelGGL((scan_filter_kernel<KC, RC, ROWS>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, n, (int)c->k,
+    hipLaunchKernelGGL((scan_filter_kernel<KC, RC, ROWS, VAR>), dim3(grid), dim3(TPB), 0, c->stream, d_hi, d_lo, d_cnt, n, (int)c->k,
                        (int)c->ref_k, view(c, MG_BF_ALT), open, c->d_hit_count, c->scan_ablate);
+}
+template <int KC, int RC, int ROWS>
+void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
+{
+    // 16-byte loads need 16-byte aligned table bases (chunk offsets are multiples of 2^27 rows, so only the caller's bases matter)
+    const bool vec_ok = ROWS == 2 && ((((uintptr_t)d_hi | (uintptr_t)d_lo) & 15) == 0) && (((uintptr_t)d_cnt & 7) == 0);
+    switch ((c->scan_variant & 1) | ((c->scan_variant & 2) && vec_ok ? 2 : 0)) {
+    case 1: launch_filter_var<KC, RC, ROWS, 1>(c, d_hi, d_lo, d_cnt, n, open); break;
+    case 2: launch_filter_var<KC, RC, ROWS, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
+    case 3: launch_filter_var<KC, RC, ROWS, 3>(c, d_hi, d_lo, d_cnt, n, open); break;
+    default: launch_filter_var<KC, RC, ROWS, 0>(c, d_hi, d_lo, d_cnt, n, open); break;
+    }
 }
 template <int KC, int RC>
 void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed)
