@@ -257,7 +257,8 @@ def main():
     if rank == 0:
         total_kmers = n_rows * world * args.steps
         total_vars = n_vars * world * args.steps
-        achieved = SCAN_BYTES_PER_KMER * n_rows / (filt_ms * 1e-3) / 1e9
+        rows_per_launch = min(n_rows, 1 << 27)      # mg_kmc_scan_device walks the table in chunks of 2^27 rows; the first is timed
+        achieved = SCAN_BYTES_PER_KMER * rows_per_launch / (filt_ms * 1e-3) / 1e9
         out = {
             "metric": "KMC k-mers scanned/sec (whole call step: scan + counter all-reduce + genotyping), k=35 r=43",
             "value": total_kmers / elapsed,
@@ -276,10 +277,10 @@ def main():
                                    % (n_rows, n_vars, args.b),
                        "kmers_per_gpu": n_rows, "variants_per_gpu": n_vars, "bf_bits": bf_bits, "parallelism": "table rows x%d, variants x%d" % (world, world),
                        "summary_bitmaps": not args.no_summary},
-            "roofline": {"kernel": "scan_filter_kernel<35,43>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "scan_filter_kernel<35,43,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
-                         "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * n_rows, "bytes_per_unit": SCAN_BYTES_PER_KMER,
-                         "units_per_launch": n_rows, "avg_launch_ms": filt_ms},
+                         "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
+                         "units_per_launch": rows_per_launch, "avg_launch_ms": filt_ms},
             "kernels_ms": {"scan_filter": filt_ms, "scan_probe": probe_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg,
                            "gate_open_rows": n_open, "bf_hit_rows": n_hits},
             "genotype_roofline": {"achieved": GENO_BYTES_PER_SNP * n_vars / (geno_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

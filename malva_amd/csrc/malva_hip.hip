@@ -829,6 +829,7 @@ struct mg_ctx {
     u32 *joined = nullptr; // when set: one allocation holding [bf counters | map counters] (mg_counters_view)
     int use_summary = 1;
     bool gate_dirty = false; // something has been inserted into `bf`
+    bool gate_fixed = false; // gate_log2 was set by the caller: do not resize at finalize
     int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
     int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
@@ -1227,7 +1228,10 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
         if (!strcmp(name, "gate_k")) {
             if (value < 1 || value > 4) return fail(c, MG_ERR_ARG, "gate_k must be 1..4");
             c->gate_k = (int)value;
-        } else c->gate_log2 = (int)value;
+        } else {
+            c->gate_log2 = (int)value;
+            c->gate_fixed = true;
+        }
         return alloc_gate(c);
     }
     else return fail(c, MG_ERR_ARG, "unknown option %s", name);
@@ -1292,6 +1296,24 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
     HIP_TRY(c, hipMemsetAsync(b.counts, 0, (total ? total : 1) * 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     b.mode = 1;
+    if (which == MG_BF_ALT && !c->gate_fixed) {
+        // size the gate for what the index holds: >= 12 bits per entry (set bf bits + exact-map keys), a power
+        // of two, never below the default.  2e6 entries (C3) -> 2^25 bits = 4 MiB; 2e7 -> 2^28 = 32 MiB.
+        const u64 entries = b.nset + c->map.rows_total;
+        int want = 25;
+        while (want < 34 && (1ULL << want) < 12 * entries) ++want;
+        while (want > 6 && (1ULL << want) > b.size) --want;
+        if (want != c->gate_log2) {
+            c->gate_log2 = want;
+            TRY(alloc_gate(c));
+            hipLaunchKernelGGL(gate_from_bits_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), b.nwords);
+            if (c->map.tags)
+                hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
+                                   view(c, MG_BF_ALT));
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
     return MG_OK;
 }
 
