@@ -516,6 +516,8 @@ int call_main(const Options &o)
     }
     pelapsed("VCF parsing and genotyping");
 
+    // records per device round trip; MALVA_GENO_BATCH exists so tests can force many small batches
+    const size_t batch_records = getenv("MALVA_GENO_BATCH") ? (size_t)std::max(1L, atol(getenv("MALVA_GENO_BATCH"))) : 200000;
     std::vector<Rec> recs;
     Batch iso, gen;
     const std::string best_default = o.haploid ? "0" : "0/0";
@@ -646,7 +648,7 @@ int call_main(const Options &o)
                 gen.var_gt_off.push_back(gen.var_gt_off.back() + n_gt(A));
             }
         }
-        if (recs.size() >= 200000) run_and_print();
+        if (recs.size() >= batch_records) run_and_print();
     });
     run_and_print();
     std::cout.flush();

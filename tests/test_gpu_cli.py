@@ -84,3 +84,22 @@ def test_sars_cov2_panel_config_c1(tmp_path, golden_dir):
     assert len(recs) == 15154
     nonref = [(r[1], r[3], r[4], r[9]) for r in recs if not r[9].startswith("0:")]
     assert nonref == [("17747", "C", "T", "1:94"), ("17858", "A", "G", "1:100")]
+
+
+def test_c5_like_panel_many_batches(tmp_path):
+    """BASELINE config C5 shape: indel/MNP-heavy clustered blocks, k=35 r=63, diploid and haploid, a few thousand
+    records pushed through the driver in batches of 97 records (batch seams inside and between blocks)."""
+    for seed, haploid in ((21, False), (22, True)):
+        prefix = str(tmp_path / ("c5_%d" % seed))
+        contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=35, n_clusters=700, vcf_strip_chr=True)
+        table = str(tmp_path / ("donor_%d.kmers" % seed))
+        vcf_synth.donor_table(contigs, records, 63, seed, table + ".txt")
+        opt = pipeline.Options(haploid=haploid, verbose=True, k=35, ref_k=63, bf_size=1 << 33, strip_chr=True)
+        idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+        kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+        want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+        args = ["-k", "35", "-r", "63", "-b", "1", "-p", "-v"] + (["-1"] if haploid else []) + [prefix + ".fa", prefix + ".vcf", table]
+        run_cli(["index"] + args)
+        got = run_cli(["call"] + args, env=dict(os.environ, MALVA_GENO_BATCH="97"))
+        assert got == want
+        assert got.count("\n") > 1500

@@ -7,7 +7,8 @@ import numpy as np
 def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False):
     rng = np.random.default_rng(seed)
     contigs = {}
-    for name, length in (("1", 9000), ("chr2", 4000)):
+    scale = max(1, n_clusters // 40)
+    for name, length in (("1", 9000 * scale), ("chr2", 4000 * scale)):
         g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length)
         for p in rng.integers(0, length, size=6):
             g[p] = rng.choice(np.frombuffer(b"NRY", dtype=np.uint8))
