@@ -203,11 +203,16 @@ __device__ __forceinline__ u32 bf_rank(const BFView &b, u64 idx)
 // written, >= 2 fingerprint of a published key.  Keys are canonical L-forms.
 // ids[slot] = smallest insertion row that carried the key; vals[id] is its counter,
 // so the counter vector has the same layout on every GPU that replays the inserts.
+// One slot = one 32-byte record, so a probe touches ONE cache line whether it ends at an empty slot, a
+// foreign tag or the key itself (four parallel arrays cost up to four random 128-byte lines per hit).
+struct __attribute__((aligned(32))) MapSlot {
+    u32 tag; // 0 empty, 1 being written, >= 2 fingerprint of a published key
+    u32 id;  // smallest insertion row that carried the key: index of its counter in vals[]
+    u64 klo, khi;
+    u64 pad;
+};
 struct MapView {
-    u32 *tags;
-    u64 *klo;
-    u64 *khi;
-    u32 *ids;
+    MapSlot *slots;
     u32 *vals;
     u32 cap_log2;
     u32 klen; // every key held here is exactly this long (other lengths live in the host overflow list)
@@ -237,9 +242,9 @@ __device__ __forceinline__ long long map_find(const MapView &m, U128 key, u64 h)
     u64 s = map_slot(m, h);
     const u32 tag = map_tag(h);
     for (;;) {
-        const u32 t = m.tags[s];
+        const u32 t = m.slots[s].tag;
         if (t == 0) return -1;
-        if (t == tag && m.klo[s] == key.lo && m.khi[s] == key.hi) return (long long)s;
+        if (t == tag && m.slots[s].klo == key.lo && m.slots[s].khi == key.hi) return (long long)s;
         s = (s + 1) & mask;
     }
 }

@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
         if (regular) s = map_find(map, key, xxh3_bytes(can, k));
         if (irregular) irregular[i] = regular ? 0 : 1;
         if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
-        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.ids[s]], counters[i]);
-        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.ids[s]] : 0;
+        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.slots[s].id], counters[i]);
+        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
         return;
     }
     const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
@@ -123,15 +123,15 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
     // every lane retries inside one common loop, so a lane that owns a slot in
     // the "being written" state always finishes its publish before anyone spins on it
     for (int guard = 0; !done && guard < (1 << 30); ++guard) {
-        u32 t = __hip_atomic_load(&map.tags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 t = __hip_atomic_load(&map.slots[s].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) {
-            t = atomicCAS(&map.tags[s], 0u, 1u);
+            t = atomicCAS(&map.slots[s].tag, 0u, 1u);
             if (t == 0) {
-                map.klo[s] = key.lo;
-                map.khi[s] = key.hi;
-                atomicMin(&map.ids[s], my_id);
+                map.slots[s].klo = key.lo;
+                map.slots[s].khi = key.hi;
+                atomicMin(&map.slots[s].id, my_id);
                 __threadfence();
-                __hip_atomic_store(&map.tags[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&map.slots[s].tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 done = true;
                 continue;
             }
@@ -139,10 +139,10 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
         if (t == 1) continue; // owner is publishing: look again
         if (t == tag) {
             __threadfence();
-            const u64 a = __hip_atomic_load(&map.klo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 b = __hip_atomic_load(&map.khi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 a = __hip_atomic_load(&map.slots[s].klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 b = __hip_atomic_load(&map.slots[s].khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a == key.lo && b == key.hi) {
-                const u32 old = atomicMin(&map.ids[s], my_id);
+                const u32 old = atomicMin(&map.slots[s].id, my_id);
                 if (old < row0) map.vals[old] = 0; // kmers[ckmer] = 0 on a key from an earlier call
                 done = true;
                 continue;
@@ -152,38 +152,43 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
     }
 }
 
+__global__ void __launch_bounds__(TPB) map_clear_kernel(MapSlot *slots, u64 cap)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s < cap) slots[s] = MapSlot{0u, 0xFFFFFFFFu, 0, 0, 0};
+}
 // move every published entry of an old table into a new (larger, empty) one
 __global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm)
 {
     const u64 s0 = (u64)blockIdx.x * TPB + threadIdx.x;
     if (s0 >= (1ULL << oldm.cap_log2)) return;
-    if (oldm.tags[s0] < 2) return;
-    U128 key{oldm.klo[s0], oldm.khi[s0]};
+    if (oldm.slots[s0].tag < 2) return;
+    U128 key{oldm.slots[s0].klo, oldm.slots[s0].khi};
     const u64 h = xxh3_lform(key, (int)oldm.klen);
     const u64 mask = (1ULL << newm.cap_log2) - 1;
     u64 s = map_slot(newm, h);
-    while (atomicCAS(&newm.tags[s], 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
-    newm.klo[s] = key.lo;
-    newm.khi[s] = key.hi;
-    newm.ids[s] = oldm.ids[s0];
+    while (atomicCAS(&newm.slots[s].tag, 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
+    newm.slots[s].klo = key.lo;
+    newm.slots[s].khi = key.hi;
+    newm.slots[s].id = oldm.slots[s0].id;
 }
 // gate bits of every published key (after a filter import rebuilt the gate from the bits alone)
 __global__ void __launch_bounds__(TPB) map_gate_kernel(MapView m, BFView bf)
 {
     const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s >= (1ULL << m.cap_log2) || m.tags[s] < 2) return;
-    gate_set(bf, mod_size(xxh3_lform(U128{m.klo[s], m.khi[s]}, (int)m.klen), bf.mod));
+    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
+    gate_set(bf, mod_size(xxh3_lform(U128{m.slots[s].klo, m.slots[s].khi}, (int)m.klen), bf.mod));
 }
 
 // list of published (key, id) for export
 __global__ void __launch_bounds__(TPB) map_dump_kernel(MapView m, u64 *klo, u64 *khi, u32 *ids, unsigned long long *count)
 {
     const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s >= (1ULL << m.cap_log2) || m.tags[s] < 2) return;
+    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
     const unsigned long long j = atomicAdd(count, 1ULL);
-    klo[j] = m.klo[s];
-    khi[j] = m.khi[s];
-    ids[j] = m.ids[s];
+    klo[j] = m.slots[s].klo;
+    khi[j] = m.slots[s].khi;
+    ids[j] = m.slots[s].id;
 }
 
 // ---- finalize: rank directory, counters, summary ---------------------------
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             const u64 idx = mod_size(h, bf.mod);
             const u64 word = bf.words[idx >> 6];
             const long long s = map_find(map, c, h);
-            if (s >= 0) atomicAdd(&map.vals[map.ids[s]], count); // ref_bf.increment (main.cpp:495)
+            if (s >= 0) atomicAdd(&map.vals[map.slots[s].id], count); // ref_bf.increment (main.cpp:495)
             hit = (word >> (idx & 63)) & 1;
         }
         st.push(hit, m, count);
@@ -651,7 +656,7 @@ template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, in
         U128 key;
         if (pack_regular(can, k, (int)map.klen, &key)) {
             const long long s = map_find(map, key, xxh3_bytes(can, k));
-            if (s >= 0) return (i32)map.vals[map.ids[s]];
+            if (s >= 0) return (i32)map.vals[map.slots[s].id];
         }
         return 0;
     }
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
                 const u64 h = xxh3_packed(key, k);
                 if (a == 0) {
                     const long long s = map_find(map, key, h);
-                    w = s >= 0 ? (i32)map.vals[map.ids[s]] : 0;
+                    w = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
                 } else {
                     const u64 idx = mod_size(h, bf.mod);
                     w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
@@ -798,9 +803,7 @@ struct BFState {
 };
 struct MapState {
     u32 cap_log2 = 0;
-    u32 *tags = nullptr;
-    u64 *klo = nullptr, *khi = nullptr;
-    u32 *ids = nullptr;
+    MapSlot *slots = nullptr; // `tags` in the comments below = the tag field of these records
     u32 *vals = nullptr;
     u64 rows_total = 0; // insertion rows so far (upper bound on distinct keys; ids index space)
     u64 vals_cap = 0;
@@ -923,10 +926,7 @@ MapView view(const mg_ctx *c)
 {
     const MapState &m = c->map;
     MapView v{};
-    v.tags = m.tags;
-    v.klo = m.klo;
-    v.khi = m.khi;
-    v.ids = m.ids;
+    v.slots = m.slots;
     v.vals = m.vals;
     v.cap_log2 = m.cap_log2;
     v.klen = c->k;
@@ -973,23 +973,15 @@ int map_alloc(mg_ctx *c, MapState &m, u32 cap_log2)
 {
     const u64 cap = 1ULL << cap_log2;
     m.cap_log2 = cap_log2;
-    HIP_TRY(c, hipMalloc(&m.tags, cap * 4));
-    HIP_TRY(c, hipMalloc(&m.klo, cap * 8));
-    HIP_TRY(c, hipMalloc(&m.khi, cap * 8));
-    HIP_TRY(c, hipMalloc(&m.ids, cap * 4));
-    HIP_TRY(c, hipMemsetAsync(m.tags, 0, cap * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(m.ids, 0xFF, cap * 4, c->stream));
+    HIP_TRY(c, hipMalloc(&m.slots, cap * sizeof(MapSlot)));
+    hipLaunchKernelGGL(map_clear_kernel, dim3(nblocks(cap)), dim3(TPB), 0, c->stream, m.slots, cap);
+    HIP_TRY(c, hipGetLastError());
     return MG_OK;
 }
 void map_free_table(MapState &m)
 {
-    hipFree(m.tags);
-    hipFree(m.klo);
-    hipFree(m.khi);
-    hipFree(m.ids);
-    m.tags = nullptr;
-    m.klo = m.khi = nullptr;
-    m.ids = nullptr;
+    hipFree(m.slots);
+    m.slots = nullptr;
 }
 // make room for `extra` more insertion rows: table load <= 1/4, vals indexable by row
 int map_reserve(mg_ctx *c, u64 extra)
@@ -1012,22 +1004,19 @@ int map_reserve(mg_ctx *c, u64 extra)
     }
     u32 want = 10;
     while ((1ULL << want) < need_rows * 4) ++want;
-    if (!m.tags) return map_alloc(c, m, want);
+    if (!m.slots) return map_alloc(c, m, want);
     if (want > m.cap_log2) {
-        MapState old = m; // shallow copy of pointers
-        m.tags = nullptr;
-        TRY(map_alloc(c, m, want));
         MapView ov{};
-        ov.tags = old.tags; ov.klo = old.klo; ov.khi = old.khi; ov.ids = old.ids; ov.cap_log2 = old.cap_log2;
+        ov.slots = m.slots;
+        ov.cap_log2 = m.cap_log2;
         ov.klen = c->k;
+        m.slots = nullptr;
+        TRY(map_alloc(c, m, want));
         MapView nv = view(c);
-        hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << old.cap_log2)), dim3(TPB), 0, c->stream, ov, nv);
+        hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << ov.cap_log2)), dim3(TPB), 0, c->stream, ov, nv);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipFree(old.tags);
-        hipFree(old.klo);
-        hipFree(old.khi);
-        hipFree(old.ids);
+        hipFree(ov.slots);
     }
     return MG_OK;
 }
@@ -1307,7 +1296,7 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
             c->gate_log2 = want;
             TRY(alloc_gate(c));
             hipLaunchKernelGGL(gate_from_bits_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), b.nwords);
-            if (c->map.tags)
+            if (c->map.slots)
                 hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
                                    view(c, MG_BF_ALT));
             HIP_TRY(c, hipGetLastError());
@@ -1371,7 +1360,7 @@ MG_EXPORT int mg_map_test(mg_ctx *c, const char *rows, size_t stride, size_t n, 
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     std::vector<u8> irr(n);
     TRY(run_rows<OP_MAP_TEST>(c, 0, rows, stride, n, nullptr, nullptr, out, 1, irr.data()));
     for (size_t i = 0; i < n; ++i)
@@ -1383,7 +1372,7 @@ MG_EXPORT int mg_map_increment(mg_ctx *c, const char *rows, size_t stride, size_
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!counters) return fail(c, MG_ERR_ARG, "counters is NULL");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     std::vector<u8> irr(n);
     TRY(run_rows<OP_MAP_INC>(c, 0, rows, stride, n, counters, nullptr, nullptr, 0, irr.data()));
     for (size_t i = 0; i < n; ++i)
@@ -1398,7 +1387,7 @@ MG_EXPORT int mg_map_get_count(mg_ctx *c, const char *rows, size_t stride, size_
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     std::vector<u8> irr(n);
     TRY(run_rows<OP_MAP_GET>(c, 0, rows, stride, n, nullptr, nullptr, out, 4, irr.data()));
     for (size_t i = 0; i < n; ++i)
@@ -1417,7 +1406,7 @@ int map_dump(mg_ctx *c, std::vector<u64> *klo, std::vector<u64> *khi, std::vecto
     klo->clear();
     khi->clear();
     ids->clear();
-    if (!m.tags) return MG_OK;
+    if (!m.slots) return MG_OK;
     const u64 cap = 1ULL << m.cap_log2;
     const u64 maxn = m.rows_total < cap ? m.rows_total : cap;
     if (maxn == 0) return MG_OK;
@@ -1543,7 +1532,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         return fail(c, MG_ERR_LIMIT, "packed scan supports 17 <= k <= ref_k <= 64 (k=%u ref_k=%u)", c->k, c->ref_k);
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     const u64 chunk = 1ULL << 27; // rows per launch triple (bounds the two lists' worst-case size)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
     void *p[6];
@@ -1695,7 +1684,7 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
     if (allele_sig_off[n_alleles] != n_sigs || sig_kmer_off[n_sigs] != n_rows)
         return fail(c, MG_ERR_ARG, "descriptor offsets do not close (sigs %zu rows %zu)", n_sigs, n_rows);
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     void *d_rows, *d_isref, *d_w, *d_so, *d_ao, *d_cov;
     TRY(upload(c, c->s_rows, rows, stride * n_rows, &d_rows));
     TRY(upload(c, c->s_misc[0], is_ref, n_rows, &d_isref));
@@ -1777,7 +1766,7 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
     if (n_vars == 0) return MG_OK;
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
-    if (!c->map.tags) TRY(map_reserve(c, 0));
+    if (!c->map.slots) TRY(map_reserve(c, 0));
     GenoParams p;
     TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
     hipLaunchKernelGGL(call_isolated_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
@@ -1882,7 +1871,7 @@ MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, c
     if (which == MG_BF_ALT) { // the gate follows the bits: rebuild it from them and from the map's keys
         TRY(alloc_gate(c));
         hipLaunchKernelGGL(gate_from_bits_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), b.nwords);
-        if (c->map.tags)
+        if (c->map.slots)
             hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
                                view(c, MG_BF_ALT));
         HIP_TRY(c, hipGetLastError());
@@ -1934,7 +1923,7 @@ MG_EXPORT int mg_bf_import_sparse(mg_ctx *c, int which, int mode, uint64_t size_
     b.mode = 0;
     if (which == MG_BF_ALT) {
         TRY(alloc_gate(c));
-        if (c->map.tags)
+        if (c->map.slots)
             hipLaunchKernelGGL(map_gate_kernel, dim3(nblocks(1ULL << c->map.cap_log2)), dim3(TPB), 0, c->stream, view(c),
                                view(c, MG_BF_ALT));
         c->gate_dirty = true;
