@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
+    ap.add_argument("--pack16-from", type=int, default=4, help="world size from which the counter all-reduce tries the 16-bit packed form")
     ap.add_argument("--scan-ablate", type=int, default=0,
                     help="profiling only (results invalid): filter-kernel ablation mask, see scan_filter_kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -58,7 +59,7 @@ def main():
     import torch
     import torch.distributed as dist
     from malva_amd import BF_ALT, BF_CTX, Context, synth
-    from malva_amd.dist import alias_int32, allreduce_counters_, rank_world
+    from malva_amd.dist import alias_int32, allreduce_counters_, allreduce_counters_packed_, rank_world
 
     rank, world = rank_world()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,12 +146,18 @@ def main():
     d_counters = alias_int32(cptr, n_bf + n_map, dev)         # reduced in place: no export/import copies
 
     scan_ms = []
+    packed_steps = []
 
     def step(record=False):
         ctx.counters_reset()
         ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
         if world > 1:
-            allreduce_counters_(d_counters)
+            # from 4 ranks up the vector (8 MB per rank's variants) is worth halving on the wire; below that the
+            # guard's extra round trip costs more than it saves
+            if world >= args.pack16_from:
+                packed_steps.append(allreduce_counters_packed_(d_counters))
+            else:
+                allreduce_counters_(d_counters)
         ctx.call_isolated_device(n_vars, d_pos.data_ptr(), d_vo.data_ptr(), d_ao.data_ptr(), d_pool.data_ptr(), d_freq.data_ptr(),
                                  d_pm.data_ptr(), d_fl.data_ptr(), 0.001, 200, False, d_cov.data_ptr(), d_g1.data_ptr(),
                                  d_g2.data_ptr(), d_gq.data_ptr(), d_st.data_ptr(), d_probs.data_ptr(), d_goff.data_ptr())
@@ -202,7 +209,7 @@ def main():
 
     cpu_baseline = None
     parity_sample = None
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:       # the CPU leg runs at N=1 only
         from oracle import capi as ocapi
         ns = int(min(args.cpu_sample, n_rows))
         log(rank, "cpu baseline: importing the device-built filters into the oracle ...")
@@ -276,7 +283,9 @@ def main():
             "config": {"workload": "C3 per GPU: %.3g KMC k-mers + %.3g isolated biallelic SNPs, k=35 r=43 b=%d, table resident in HBM"
                                    % (n_rows, n_vars, args.b),
                        "kmers_per_gpu": n_rows, "variants_per_gpu": n_vars, "bf_bits": bf_bits, "parallelism": "table rows x%d, variants x%d" % (world, world),
-                       "summary_bitmaps": not args.no_summary},
+                       "summary_bitmaps": not args.no_summary,
+                       "exchange": ("none" if world == 1 else "all_reduce(sum,int32) over %d counters, in place%s" % (
+                           n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
             "roofline": {"kernel": "scan_filter_kernel<35,43,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,

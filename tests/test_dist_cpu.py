@@ -83,3 +83,35 @@ def test_two_rank_shard_scan_allreduce_equals_whole(tmp_path):
     assert np.array_equal(reduced[:n_bf] & 0xFFFF, whole[:n_bf] & 0xFFFF)
     assert np.array_equal(reduced[n_bf:], whole[n_bf:])
     assert whole[n_bf:].max() > 0 and (whole[:n_bf] > 0).any()
+
+
+def _pack_worker(rank, world, port, out, big):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from malva_amd.dist import allreduce_counters_packed_
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    v = rng.integers(0, 65535 // world + 1, size=20001, dtype=np.int64)
+    if big and rank == 1:
+        v[777] = 0xFFFFFF00                       # one large u32 partial: the guard must fall back to 32-bit
+    t = torch.from_numpy(v.astype(np.uint32).view(np.int32).copy())
+    took = allreduce_counters_packed_(t)
+    if rank == 0:
+        np.save(out, np.concatenate([t.numpy().view(np.uint32), np.array([int(took)], dtype=np.uint32)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_packed_allreduce_is_exact_or_falls_back(tmp_path, big):
+    world = 3
+    out = str(tmp_path / "p.npy")
+    mp.spawn(_pack_worker, args=(world, _free_port(), out, big), nprocs=world, join=True)
+    got = np.load(out)
+    want = np.zeros(20001, dtype=np.uint64)
+    for r in range(world):
+        v = np.random.default_rng(100 + r).integers(0, 65535 // world + 1, size=20001, dtype=np.int64)
+        if big and r == 1:
+            v[777] = 0xFFFFFF00
+        want += v.astype(np.uint64)
+    assert np.array_equal(got[:-1], (want & 0xFFFFFFFF).astype(np.uint32))
+    assert int(got[-1]) == (0 if big else 1)
