@@ -137,6 +137,21 @@ int mg_lookup_cover(mg_ctx *ctx, const char *rows, size_t stride, size_t n_rows,
                     const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
                     uint32_t *cov_out);
 
+/* VB::extract_kmers (var_block.hpp:95-219, chains :436-677, haplotype picks :709-786) fused with
+ * set_coverages (main.cpp:151-184) for blocks of any shape, enumerated ON THE DEVICE.  Variants are flat
+ * across blocks (blk_var_off); pos is the 0-based position in the block's contig, which starts at
+ * blk_ref_base in the uploaded reference and is blk_ref_len long; canon[slot] = first allele index of
+ * the variant with the same text (variant.hpp:228); gt[v * n_samples + s] = a1 | a2 << 7 | phased << 14
+ * for the kept panel samples (variant.hpp:158-211).  cov_out as in mg_lookup_cover, one slot per
+ * (variant, allele).  overflow_out[v] = 1 where a fixed device capacity (8 chains per side, 12 members per
+ * chain, 10 unphased members, 127 alleles, k <= 64) or a window clipped by a contig end was hit: redo
+ * that variant's block through the host enumerator + mg_lookup_cover. */
+int mg_cover_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                    const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                    const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                    const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                    const uint16_t *gt, uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out);
+
 /* Result codes of mg_genotype / mg_call_isolated per variant */
 #define MG_GT_NORMAL 0   /* likelihood list computed                              */
 #define MG_GT_OVERCOV 1  /* some allele > max_cov: (best_geno,0) per such allele  */

@@ -784,6 +784,289 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
     genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
 }
 
+// ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
+// VB::extract_kmers (var_block.hpp:95-219) with get_combs_on_the_right/left (:436-624), combine_combs (:630-677),
+// get_ref_subs (:682-702) and build_alleles_combs / combine_haplotypes (:709-786), fused with set_coverages
+// (main.cpp:151-184).  One workgroup per variant.  The reference builds the SET of distinct haplotype picks per
+// chain and takes, per allele, the max over signatures; a max does not care about duplicates, so here every
+// (chain, panel sample, haplotype pick) is simply evaluated and max-reduced -- thousands of redundant hashes
+// are cheaper on this machine than a device-side set.
+// Fixed capacities (chains per side, chain length, unphased fan-out): a variant that exceeds one is flagged in
+// `overflow` and its block is redone by the host enumerator + mg_lookup_cover, so results never depend on them.
+struct BlockBatch {
+    const u8 *reference;      // concatenated contigs (mg_reference_upload)
+    const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
+    const u32 *blk_ref_len;   //            and its length
+    const u32 *blk_var_off;   // [n_blocks + 1]
+    const u32 *var_block;     // [n_vars] block of each variant
+    const i32 *pos;           // 0-based position in the contig
+    const u32 *ref_size, *min_size;
+    const u8 *present;
+    const u32 *var_allele_off; // [n_vars + 1] allele slots
+    const u32 *allele_off;     // [n_slots + 1] into pool
+    const u8 *pool;
+    const u8 *canon;           // [n_slots] first allele index of the variant with the same text
+    const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14
+    u32 n_samples;
+    int haploid, k;
+};
+constexpr int BK_MAXC = 8;   // chains per side
+constexpr int BK_MAXL = 12;  // members per chain
+constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
+constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
+
+struct BkChains {
+    int n;
+    int len[BK_MAXC];
+    int sum[BK_MAXC];
+    int mem[BK_MAXC][BK_MAXL];
+};
+
+// get_combs_on_the_right (step +1) / _left (step -1); indices are batch-global variant indices inside [b0, b1)
+__device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
+{
+    const int k = B.k;
+    auto ov = [&](int x, int y) { // overlapping(left, right) with (x, y) given in scan order
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return B.pos[l] <= B.pos[r] && B.pos[r] < B.pos[l] + (int)B.ref_size[l];
+    };
+    auto nr = [&](int x, int y, int extra) {
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra + (k + 1) / 2 >= B.pos[r];
+    };
+    out->n = 0;
+    bool halt = false;
+    for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
+        if (!B.present[j]) continue;
+        if (ov(i, j)) continue;
+        const int gain = (int)B.ref_size[j] - (int)B.min_size[j];
+        if (out->n == 0) {
+            if (nr(i, j, 0)) {
+                out->mem[0][0] = j;
+                out->len[0] = 1;
+                out->sum[0] = gain;
+                out->n = 1;
+            }
+            continue;
+        }
+        bool added = false;
+        const int n0 = out->n;
+        for (int c = 0; c < n0; ++c) {
+            if (!ov(out->mem[c][out->len[c] - 1], j)) {
+                added = true;
+                if (nr(i, j, out->sum[c])) {
+                    if (out->len[c] >= BK_MAXL) return false;
+                    out->mem[c][out->len[c]++] = j;
+                    out->sum[c] += gain;
+                }
+            }
+        }
+        if (!added) {
+            for (int c = 0; c < n0; ++c) {
+                int len = out->len[c], ns = out->sum[c];
+                while (len > 0 && ov(out->mem[c][len - 1], j)) {
+                    const int m = out->mem[c][len - 1];
+                    ns -= (int)B.ref_size[m] - (int)B.min_size[m];
+                    --len;
+                }
+                if (nr(i, j, ns)) {
+                    added = true;
+                    if (out->n >= BK_MAXC || len + 1 > BK_MAXL) return false;
+                    const int d = out->n++;
+                    for (int q = 0; q < len; ++q) out->mem[d][q] = out->mem[c][q];
+                    out->mem[d][len] = j;
+                    out->len[d] = len + 1;
+                    out->sum[d] = ns + gain;
+                }
+            }
+            if (!added) halt = true;
+        }
+    }
+    return true;
+}
+
+struct LdsBytes {
+    const u8 *p;
+    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
+};
+// weight of the k-mer in buf[0, len): packed fast path when it is k pure-ACGT bases, byte-wise otherwise
+__device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, const BFView &bf, const MapView &map)
+{
+    if (len >= 17 && len <= MG_MAX_PACKED_K) {
+        U128 L{0, 0};
+        bool ok = true;
+        for (int i = 0; i < len; ++i) {
+            bool o;
+            const u64 code = acgt_code(buf[i], &o);
+            ok &= o;
+            if (i < 32) L.lo |= code << (2 * i);
+            else L.hi |= code << (2 * (i - 32));
+        }
+        if (ok) {
+            const U128 mk = mask128(2 * len);
+            const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - len));
+            const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+            const U128 key = lt128(L, rc) ? L : rc;
+            const u64 h = xxh3_packed(key, len);
+            if (is_ref) {
+                if (len != (int)map.klen) return 0;
+                const long long s = map_find(map, key, h);
+                return s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+            }
+            const u64 idx = mod_size(h, bf.mod);
+            return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+        }
+    }
+    return weight_bytes(LdsBytes{buf}, len, is_ref, bf, map);
+}
+
+__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow)
+{
+    __shared__ BkChains sh_left, sh_right;
+    __shared__ int sh_comb[BK_MAXC * BK_MAXC][BK_MAXCOMB];
+    __shared__ int sh_comb_len[BK_MAXC * BK_MAXC], sh_comb_mid[BK_MAXC * BK_MAXC];
+    __shared__ int sh_ncomb, sh_bad;
+    __shared__ u32 sh_cov[128];
+    __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
+    __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
+    const int g = blockIdx.x;
+    if ((u64)g >= n_vars) return;
+    const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
+    const u32 blk = B.var_block[g];
+    const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
+    const u8 *ref = B.reference + B.blk_ref_base[blk];
+    const i32 ref_len = (i32)B.blk_ref_len[blk];
+    const int k = B.k;
+    for (u32 a = threadIdx.x; a < 128; a += TPB) sh_cov[a] = 0;
+    if (threadIdx.x < 4) sh_slide[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        sh_bad = 0;
+        sh_ncomb = 0;
+        const bool eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
+        if (A > 127 || k > MG_MAX_PACKED_K) sh_bad = 1;
+        else if (eligible) {
+            if (!bk_chains(B, b0, b1, g, -1, &sh_left) || !bk_chains(B, b0, b1, g, +1, &sh_right)) sh_bad = 1;
+            else { // combine_combs
+                const int nl = sh_left.n ? sh_left.n : 1, nrr = sh_right.n ? sh_right.n : 1;
+                for (int l = 0; l < nl; ++l)
+                    for (int r = 0; r < nrr; ++r) {
+                        int *comb = sh_comb[sh_ncomb];
+                        int len = 0;
+                        if (sh_left.n)
+                            for (int q = sh_left.len[l] - 1; q >= 0; --q) comb[len++] = sh_left.mem[l][q];
+                        sh_comb_mid[sh_ncomb] = len;
+                        comb[len++] = g;
+                        if (sh_right.n)
+                            for (int q = 0; q < sh_right.len[r]; ++q) comb[len++] = sh_right.mem[r][q];
+                        sh_comb_len[sh_ncomb++] = len;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (sh_bad) {
+        if (threadIdx.x == 0) overflow[g] = 1;
+        for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
+        return;
+    }
+    u8 *buf = sh_buf[threadIdx.x];
+    bool bad = false;
+    for (int c = 0; c < sh_ncomb; ++c) {
+        const int *comb = sh_comb[c];
+        const int m = sh_comb_len[c], jm = sh_comb_mid[c];
+        const int first_pos = B.pos[comb[0]];
+        const int last_end = B.pos[comb[m - 1]] + (int)B.ref_size[comb[m - 1]];
+        for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
+            bool phased = true;
+            if (!B.haploid)
+                for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
+            u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
+            if (!B.haploid && !phased && m > BK_MAXU) {
+                bad = true;
+                continue;
+            }
+            for (u32 pick = 0; pick < npick; ++pick) {
+                // allele of member j under this pick
+                auto allele_of = [&](int j) -> u32 {
+                    const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
+                    const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
+                    if (B.haploid) return a1;
+                    if (phased) return pick ? a2 : a1;
+                    return (pick >> j) & 1 ? a2 : a1;
+                };
+                // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
+                int len_v = 0, mid_pos = 0, mid_len = 0;
+                u32 mid_allele = 0;
+                for (int j = 0; j < m; ++j) {
+                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                    if (j == jm) {
+                        mid_pos = len_v;
+                        mid_len = al;
+                        mid_allele = allele_of(j);
+                    }
+                    len_v += al;
+                    if (j + 1 < m) len_v += B.pos[comb[j + 1]] - (B.pos[comb[j]] + (int)B.ref_size[comb[j]]);
+                }
+                const u32 mid_canon = B.canon[a0 + mid_allele];
+                if (m == 1 && mid_len >= k) { // the whole allele is the signature: sliding k-mers, done below
+                    atomicOr(&sh_slide[mid_canon >> 5], 1u << (mid_canon & 31));
+                    continue;
+                }
+                const int first_part = mid_pos + mid_len / 2;
+                const int mp = k / 2 - first_part;                  // missing_prefix (negative: cut)
+                const int ms = (k + 1) / 2 - (len_v - first_part);  // missing_suffix
+                if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
+                    bad = true; // the reference clips or throws here: leave it to the host path
+                    continue;
+                }
+                // W[x] = Vext[x - mp] for x in [0, k), where Vext is V with the reference continuing on both sides:
+                // a piece that covers v in [vs, vs + L) lands at x in [vs + mp, vs + L + mp), clipped to the window
+                for (int x = 0; x < mp && x < k; ++x) buf[x] = ref[first_pos - mp + x];
+                int vs = 0;
+                for (int j = 0; j < m; ++j) {
+                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                    const u8 *ap = B.pool + B.allele_off[slot];
+                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                    for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) buf[x] = ap[x - mp - vs];
+                    vs += al;
+                    if (j + 1 < m) {
+                        const int gs = B.pos[comb[j]] + (int)B.ref_size[comb[j]];
+                        const int gl = B.pos[comb[j + 1]] - gs;
+                        for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) buf[x] = ref[gs + (x - mp - vs)];
+                        vs += gl;
+                    }
+                }
+                for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
+                const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
+                if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+            }
+        }
+    }
+    if (bad) sh_bad = 1;
+    __syncthreads();
+    // sliding signatures of lone long alleles (var_block.hpp:130-144): truncating running mean over the allele's k-mers
+    for (u32 a = threadIdx.x; a < A; a += TPB) {
+        if (!((sh_slide[a >> 5] >> (a & 31)) & 1)) continue;
+        const u8 *ap = B.pool + B.allele_off[a0 + a];
+        const int al = (int)(B.allele_off[a0 + a + 1] - B.allele_off[a0 + a]);
+        u32 curr = 0;
+        i32 n = 0;
+        for (int p = 0; p + k <= al; ++p) {
+            for (int x = 0; x < k; ++x) buf[x] = ap[p + x];
+            const i32 w = bk_weight(buf, k, a == 0, bf, map);
+            if (w > 0) {
+                curr = (curr * (u32)n + (u32)w) / (u32)(n + 1);
+                ++n;
+            }
+        }
+        atomicMax(&sh_cov[a], curr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) overflow[g] = sh_bad ? 1 : 0;
+    for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
+}
+
 } // namespace
 
 // ===========================================================================
@@ -1739,6 +2022,61 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
     HIP_TRY(c, hipMemcpyAsync(gq, d_gq, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(status, d_st, n_vars, hipMemcpyDeviceToHost, c->stream));
     if (probs && ng) HIP_TRY(c, hipMemcpyAsync(probs, d_pr, 8 * ng, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                              const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                              const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                              const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
+                              uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
+{
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off ||
+        !pool || !canon || (n_samples && !gt) || !cov_out || !overflow_out)
+        return fail(c, MG_ERR_ARG, "NULL argument");
+    if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (blk_var_off[n_blocks] != n_vars) return fail(c, MG_ERR_ARG, "block offsets do not close");
+    if (!c->map.slots) TRY(map_reserve(c, 0));
+    const size_t na = var_allele_off[n_vars];
+    if (allele_off[na] > pool_len) return fail(c, MG_ERR_ARG, "allele offsets exceed the pool");
+    std::vector<u32> var_block(n_vars);
+    for (size_t b = 0; b < n_blocks; ++b) {
+        if (blk_ref_base[b] + blk_ref_len[b] > c->ref_len) return fail(c, MG_ERR_ARG, "block %zu lies outside the uploaded reference", b);
+        for (u32 v = blk_var_off[b]; v < blk_var_off[b + 1]; ++v) var_block[v] = (u32)b;
+    }
+    BlockBatch B{};
+    void *d[14];
+    TRY(upload(c, c->s_misc[0], blk_ref_base, 8 * n_blocks, &d[0]));
+    TRY(upload(c, c->s_misc[1], blk_ref_len, 4 * n_blocks, &d[1]));
+    TRY(upload(c, c->s_misc[2], blk_var_off, 4 * (n_blocks + 1), &d[2]));
+    TRY(upload(c, c->s_misc[3], var_block.data(), 4 * n_vars, &d[3]));
+    TRY(upload(c, c->s_misc[4], pos, 4 * n_vars, &d[4]));
+    TRY(upload(c, c->s_misc[5], ref_size, 4 * n_vars, &d[5]));
+    TRY(upload(c, c->s_misc[6], min_size, 4 * n_vars, &d[6]));
+    TRY(upload(c, c->s_misc[7], present, n_vars, &d[7]));
+    TRY(upload(c, c->s_rows, var_allele_off, 4 * (n_vars + 1), &d[8]));
+    TRY(upload(c, c->s_aux, allele_off, 4 * (na + 1), &d[9]));
+    TRY(upload(c, c->s_open[0], pool, pool_len, &d[10]));
+    TRY(upload(c, c->s_open[1], canon, na, &d[11]));
+    TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
+    void *d_cov, *d_ovf;
+    TRY(scratch(c, c->s_out, 4 * na, &d_cov));
+    TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
+    B.reference = c->d_ref;
+    B.blk_ref_base = (const u64 *)d[0]; B.blk_ref_len = (const u32 *)d[1]; B.blk_var_off = (const u32 *)d[2];
+    B.var_block = (const u32 *)d[3]; B.pos = (const i32 *)d[4]; B.ref_size = (const u32 *)d[5]; B.min_size = (const u32 *)d[6];
+    B.present = (const u8 *)d[7]; B.var_allele_off = (const u32 *)d[8]; B.allele_off = (const u32 *)d[9]; B.pool = (const u8 *)d[10];
+    B.canon = (const u8 *)d[11]; B.gt = (const uint16_t *)d[12];
+    B.n_samples = n_samples; B.haploid = haploid; B.k = (int)c->k;
+    hipLaunchKernelGGL(cover_blocks_kernel, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
+                       (u32 *)d_cov, (u8 *)d_ovf);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * na, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }

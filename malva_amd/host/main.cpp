@@ -448,6 +448,15 @@ struct Batch { // inputs of mg_call_isolated (isolated) or mg_lookup_cover + mg_
     Rows rows;
     std::vector<uint8_t> is_ref;
     std::vector<uint64_t> sig_kmer_off{0}, allele_sig_off{0}, var_gt_off{0};
+    // general blocks, enumerated on the device (mg_cover_blocks); the Block objects are kept until the batch has
+    // run, for the variants the device hands back (overflow) and for the panel genotypes
+    std::vector<Block> blocks;
+    std::vector<const std::string *> block_ref;
+    std::vector<uint64_t> blk_base;
+    std::vector<uint32_t> blk_len, blk_var_off{0}, ref_size, min_size;
+    std::vector<int32_t> ipos;
+    std::vector<uint8_t> is_present, canon;
+    size_t genotype_cells = 0;
     // results
     std::vector<uint32_t> cov;
     std::vector<int32_t> g1, g2, gq;
@@ -538,9 +547,66 @@ int call_main(const Options &o)
             const size_t n = gen.n(), na = gen.var_allele_off.back();
             gen.cov.resize(na); gen.g1.resize(n); gen.g2.resize(n); gen.gq.resize(n); gen.status.resize(n);
             gen.probs.resize(o.verbose ? gen.var_gt_off.back() : 0);
-            dev.check(mg_lookup_cover(dev.ctx, gen.rows.data.data(), STRIDE, gen.rows.n, gen.is_ref.data(), gen.sig_kmer_off.data(),
-                                      gen.sig_kmer_off.size() - 1, gen.allele_sig_off.data(), na, gen.cov.data()),
-                      "mg_lookup_cover"); // set_coverages, main.cpp:557
+            // panel genotypes of the batch as one [variant][sample] matrix of a1 | a2 << 7 | phased << 14
+            const uint32_t n_samples = (uint32_t)vcf.keep.size();
+            std::vector<uint16_t> gt((size_t)n * n_samples, 0);
+            std::vector<uint8_t> overflow(n, 0);
+            bool device_ok = o.k <= MG_MAX_PACKED_K && !getenv("MALVA_GENO_HOST_ENUM"); // the variable forces the host enumerator (tests)
+            {
+                size_t g = 0;
+                for (const Block &b : gen.blocks)
+                    for (const Variant &v : b.vars) {
+                        if (v.n_alleles() > 127) device_ok = false;
+                        for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
+                            const auto &p2 = v.genotypes[s_];
+                            if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
+                                throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
+                                                         " (the reference reads out of bounds here)");
+                            gt[g * n_samples + s_] = (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
+                        }
+                        ++g;
+                    }
+            }
+            if (device_ok)
+                dev.check(mg_cover_blocks(dev.ctx, gen.blocks.size(), gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
+                                          gen.ref_size.data(), gen.min_size.data(), gen.is_present.data(), gen.var_allele_off.data(),
+                                          gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), gt.data(), n_samples, o.haploid,
+                                          gen.cov.data(), overflow.data()),
+                          "mg_cover_blocks"); // extract_kmers + set_coverages, main.cpp:556-557
+            else
+                std::fill(overflow.begin(), overflow.end(), 1);
+            // blocks the device handed back (a capacity was exceeded, or a window was clipped by a contig end):
+            // host enumerator + mg_lookup_cover for exactly those blocks
+            size_t n_fallback = 0;
+            for (size_t b = 0; b < gen.blocks.size(); ++b) {
+                bool redo = false;
+                for (uint32_t v = gen.blk_var_off[b]; v < gen.blk_var_off[b + 1]; ++v) redo = redo || overflow[v];
+                if (!redo) continue;
+                ++n_fallback;
+                const Block &blk = gen.blocks[b];
+                const auto sigs = blk.extract(*gen.block_ref[b], o.haploid);
+                Rows rows;
+                std::vector<uint8_t> is_ref;
+                std::vector<uint64_t> sig_off{0}, al_off{0};
+                for (size_t vi = 0; vi < blk.vars.size(); ++vi)
+                    for (int a = 0; a < blk.vars[vi].n_alleles(); ++a) {
+                        auto it = sigs[vi].find(a);
+                        if (it != sigs[vi].end())
+                            for (const auto &sig : it->second) {
+                                for (const auto &kmer : sig) {
+                                    rows.add(kmer);
+                                    is_ref.push_back(a == 0);
+                                }
+                                sig_off.push_back(rows.n);
+                            }
+                        al_off.push_back(sig_off.size() - 1);
+                    }
+                const size_t slot0 = gen.var_allele_off[gen.blk_var_off[b]];
+                dev.check(mg_lookup_cover(dev.ctx, rows.data.data(), STRIDE, rows.n, is_ref.data(), sig_off.data(), sig_off.size() - 1, al_off.data(),
+                                          al_off.size() - 1, gen.cov.data() + slot0),
+                          "mg_lookup_cover");
+            }
+            if (n_fallback) std::cerr << "[malva-geno] " << n_fallback << " block(s) enumerated on the host" << std::endl;
             dev.check(mg_genotype(dev.ctx, gen.cov.data(), gen.freq.data(), gen.var_allele_off.data(), n, o.error_rate, (int)o.max_coverage, o.haploid,
                                   gen.g1.data(), gen.g2.data(), gen.gq.data(), gen.status.data(), o.verbose ? gen.probs.data() : nullptr,
                                   o.verbose ? gen.var_gt_off.data() : nullptr),
@@ -626,28 +692,34 @@ int call_main(const Options &o)
             iso.var_allele_off.push_back(iso.var_allele_off.back() + A);
             iso.var_gt_off.push_back(iso.var_gt_off.back() + n_gt(A));
         } else {
-            const auto sigs = vb.extract(reference, o.haploid); // main.cpp:556
-            for (size_t vi = 0; vi < vb.vars.size(); ++vi) {
-                const Variant &v = vb.vars[vi];
+            // main.cpp:556-557: extract_kmers + set_coverages happen on the device for the whole batch of blocks
+            auto cb = contig_base.find(seq_name);
+            gen.blk_base.push_back(cb == contig_base.end() ? 0 : cb->second);
+            gen.blk_len.push_back((uint32_t)reference.size());
+            for (const Variant &v : vb.vars) {
                 const uint32_t A = (uint32_t)v.n_alleles();
                 recs.push_back({prefix_of(v), A, false, gen.n(), gen.var_allele_off.back(), gen.var_gt_off.back()});
+                gen.ipos.push_back(v.ref_pos);
+                gen.ref_size.push_back((uint32_t)v.ref_size);
+                gen.min_size.push_back((uint32_t)v.min_size);
+                gen.is_present.push_back(v.is_present);
                 for (uint32_t a = 0; a < A; ++a) {
-                    auto it = sigs[vi].find((int)a);
-                    if (it != sigs[vi].end())
-                        for (const auto &sig : it->second) {
-                            for (const auto &kmer : sig) {
-                                gen.rows.add(kmer);
-                                gen.is_ref.push_back(a == 0);
-                            }
-                            gen.sig_kmer_off.push_back(gen.rows.n);
-                        }
-                    gen.allele_sig_off.push_back(gen.sig_kmer_off.size() - 1);
+                    const std::string &al = v.allele((int)a);
+                    gen.pool.insert(gen.pool.end(), al.begin(), al.end());
+                    gen.allele_off.push_back((uint32_t)gen.pool.size());
+                    gen.canon.push_back((uint8_t)std::min(255, v.allele_index(al)));
                     gen.freq.push_back(v.frequencies[a]);
                 }
                 gen.var_allele_off.push_back(gen.var_allele_off.back() + A);
                 gen.var_gt_off.push_back(gen.var_gt_off.back() + n_gt(A));
+                gen.genotype_cells += v.genotypes.size();
             }
+            gen.blk_var_off.push_back((uint32_t)gen.n());
+            gen.block_ref.push_back(&reference);
+            gen.blocks.push_back(std::move(vb));
+            vb = Block((int)o.k);
         }
+        if (gen.genotype_cells >= (200u << 20)) run_and_print(); // bound the panel genotypes held in memory
         if (recs.size() >= batch_records) run_and_print();
     });
     run_and_print();

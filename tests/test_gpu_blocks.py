@@ -1,0 +1,91 @@
+"""General variant blocks enumerated ON THE DEVICE (mg_cover_blocks: chains, haplotype picks, signature assembly,
+lookup, coverage) against the oracle's block model + set_coverages on clustered synthetic panels."""
+import numpy as np
+import pytest
+
+import vcf_synth
+from malva_amd import BF_ALT, BF_CTX, Context
+from malva_amd.capi import rows_of
+from oracle import capi as ocapi
+from oracle import pipeline
+from oracle.model import VCFReader, flatten_vk, read_fasta
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_blocks(blocks, contig_base, contig_len):
+    """[(VB, contig name)] -> flat arrays of mg_cover_blocks"""
+    bb, bl, bo = [], [], [0]
+    pos, rs, ms, pr, vo, ao, pool, canon, gts = [], [], [], [], [0], [0], bytearray(), [], []
+    n_samples = None
+    for vb, name in blocks:
+        bb.append(contig_base.get(name, 0)); bl.append(contig_len.get(name, 0))
+        for v in vb.variants:
+            pos.append(v.ref_pos); rs.append(v.ref_size); ms.append(v.min_size if v.alts else v.ref_size); pr.append(int(v.is_present))
+            alleles = [v.ref_sub] + v.alts
+            for a, al in enumerate(alleles):
+                pool += al.encode(); ao.append(len(pool)); canon.append(v.get_allele_index(al))
+            vo.append(vo[-1] + len(alleles))
+            g = np.zeros(len(v.genotypes), dtype=np.uint16)
+            for s, ((a1, a2), ph) in enumerate(zip(v.genotypes, v.phasing)):
+                assert a1 < len(alleles) and a2 < len(alleles)
+                g[s] = a1 | (a2 << 7) | (int(ph) << 14)
+            gts.append(g)
+        bo.append(len(pos))
+    n_samples = max((len(g) for g in gts), default=0)
+    gt = np.zeros((len(pos), n_samples), dtype=np.uint16)
+    for i, g in enumerate(gts):
+        gt[i, :len(g)] = g           # non-present variants carry no genotypes; their rows are never read
+    return dict(blk_ref_base=bb, blk_ref_len=bl, blk_var_off=bo, pos=pos, ref_size=rs, min_size=ms, present=pr, var_allele_off=vo,
+                allele_off=ao, pool=np.frombuffer(bytes(pool), dtype=np.uint8), canon=canon, gt=gt, n_samples=n_samples)
+
+
+@pytest.mark.parametrize("seed,haploid,k,ref_k", [(31, False, 35, 43), (32, True, 35, 43), (33, False, 31, 41), (34, False, 21, 29),
+                                                  (35, True, 63, 64), (36, False, 35, 63)])
+def test_device_enumeration_matches_oracle(tmp_path, seed, haploid, k, ref_k):
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=120, vcf_strip_chr=True)
+    table = str(tmp_path / "donor.txt")
+    vcf_synth.donor_table(contigs, records, ref_k, seed, table)
+    opt = pipeline.Options(haploid=haploid, k=k, ref_k=ref_k, bf_size=1 << 24, strip_chr=True)
+    fa, vcf = prefix + ".fa", prefix + ".vcf"
+    idx = pipeline.index(fa, vcf, opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table)]
+    pipeline.scan(idx, kmers, opt)
+    refs = read_fasta(fa, True)
+    # the same index and counters on the device, through the ASCII batch calls
+    ctx = Context(k, ref_k, opt.bf_size)
+    bits = idx.bf.set_positions()
+    ctx.bf_import_sparse(BF_ALT, 1, opt.bf_size, bits, idx.bf.counts())
+    ctx.bf_import_sparse(BF_CTX, 1, opt.bf_size, idx.context_bf.set_positions(), idx.context_bf.counts())
+    items = list(idx.ref_bf.items())
+    ctx.map_import([k_ for k_, _ in items], np.array([v for _, v in items], dtype=np.int32))
+    names = list(refs)
+    base, off = {}, 0
+    for n in names:
+        base[n] = off; off += len(refs[n])
+    ctx.reference_upload("".join(refs[n] for n in names).encode())
+    blocks, want = [], []
+    reader = VCFReader(vcf, "-")
+    vbs = []
+    last = ""
+    for vb, reference, used in pipeline._blocks(reader, opt, refs, False):
+        if vb is None:
+            break
+        # the block's contig: the one whose sequence it was evaluated against
+        name = next((n for n in names if refs[n] is reference or refs[n] == reference), names[0])
+        blocks.append((vb, name))
+        km = vb.extract_kmers(reference, haploid)
+        ks, is_ref, so, ao = flatten_vk(km, [len(v.alts) + 1 for v in vb.variants])
+        w = ocapi.lookup_weights(idx.bf, idx.ref_bf, ocapi.rows_from_kmers(ks)[0], np.array(is_ref, np.uint8)) if ks else np.zeros(0, np.int32)
+        want.append(ocapi.set_coverages(w, so, ao))
+    want = np.concatenate(want)
+    args = pack_blocks(blocks, base, {n: len(refs[n]) for n in names})
+    cov, ovf = ctx.cover_blocks(**args, haploid=haploid)
+    ok = np.repeat(ovf == 0, np.diff(np.array(args["var_allele_off"])))
+    assert ok.mean() > 0.9, "too many variants fell back: %.2f" % (1 - ok.mean())
+    assert np.array_equal(cov[ok], want[ok])
+    assert (want[ok] > 0).sum() > 50
+    # variants flagged overflow must be genuinely beyond a device capacity or clipped by a contig end -- never wrong
+    print("fallback variants: %d of %d" % (int(ovf.sum()), len(ovf)))
+    ctx.close()
