@@ -43,8 +43,20 @@ def pack_blocks(blocks, contig_base, contig_len):
 @pytest.mark.parametrize("seed,haploid,k,ref_k", [(31, False, 35, 43), (32, True, 35, 43), (33, False, 31, 41), (34, False, 21, 29),
                                                   (35, True, 63, 64), (36, False, 35, 63)])
 def test_device_enumeration_matches_oracle(tmp_path, seed, haploid, k, ref_k):
+    _run_case(tmp_path, seed, haploid, k, ref_k, dense=False)
+
+
+@pytest.mark.parametrize("seed,haploid", [(41, False), (42, True), (43, False)])
+def test_dense_clusters_hit_the_device_capacities(tmp_path, seed, haploid):
+    """6-15 variants inside 22 bp with overlapping deletions: long chains, many chains per side, long unphased runs.
+    Whatever the device does not hand back must still equal the oracle, and it must hand back only a minority."""
+    _run_case(tmp_path, seed, haploid, 35, 43, dense=True)
+
+
+def _run_case(tmp_path, seed, haploid, k, ref_k, dense):
     prefix = str(tmp_path / "case")
-    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=120, vcf_strip_chr=True)
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=40 if dense else 120, vcf_strip_chr=True,
+                                           dense=dense, n_samples=4 if dense else 5)
     table = str(tmp_path / "donor.txt")
     vcf_synth.donor_table(contigs, records, ref_k, seed, table)
     opt = pipeline.Options(haploid=haploid, k=k, ref_k=ref_k, bf_size=1 << 24, strip_chr=True)
@@ -83,9 +95,11 @@ def test_device_enumeration_matches_oracle(tmp_path, seed, haploid, k, ref_k):
     args = pack_blocks(blocks, base, {n: len(refs[n]) for n in names})
     cov, ovf = ctx.cover_blocks(**args, haploid=haploid)
     ok = np.repeat(ovf == 0, np.diff(np.array(args["var_allele_off"])))
-    assert ok.mean() > 0.9, "too many variants fell back: %.2f" % (1 - ok.mean())
+    assert ok.mean() > (0.3 if dense else 0.9), "too many variants fell back: %.2f" % (1 - ok.mean())
     assert np.array_equal(cov[ok], want[ok])
     assert (want[ok] > 0).sum() > 50
+    if dense:
+        assert ovf.sum() > 0                   # the capacities were actually reached somewhere
     # variants flagged overflow must be genuinely beyond a device capacity or clipped by a contig end -- never wrong
     print("fallback variants: %d of %d" % (int(ovf.sum()), len(ovf)))
     ctx.close()

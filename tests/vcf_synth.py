@@ -4,7 +4,7 @@ genotypes, a non-present record, records near contig ends, two contigs, N/IUPAC 
 import numpy as np
 
 
-def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False):
+def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False, dense=False):
     rng = np.random.default_rng(seed)
     contigs = {}
     scale = max(1, n_clusters // 40)
@@ -18,8 +18,8 @@ def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35
         centres = np.sort(rng.choice(np.arange(10, len(seq) - 10), size=n_clusters if name == "1" else n_clusters // 3, replace=False))
         used = set()
         for c in centres:
-            for _ in range(int(rng.integers(1, 6))):
-                pos = int(c + rng.integers(0, 28))
+            for _ in range(int(rng.integers(6, 16)) if dense else int(rng.integers(1, 6))):
+                pos = int(c + rng.integers(0, 22 if dense else 28))
                 if pos in used or pos >= len(seq) - 70:
                     continue
                 used.add(pos)
