@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One-off soak: many random clustered panels through bin/malva-geno (GPU) vs the oracle pipeline.
+usage: python tools/soak_cli.py [first_seed] [n]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vcf_synth  # noqa: E402
+from oracle import pipeline  # noqa: E402
+
+BIN = os.path.join(ROOT, "bin", "malva-geno")
+first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad = 0
+for seed in range(first, first + n):
+    haploid, dense, verbose = bool(seed & 1), bool(seed & 2), bool(seed & 4)
+    k, ref_k = [(35, 43), (31, 41), (35, 63), (25, 33)][(seed >> 3) & 3]
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "c")
+        contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=30 if dense else 80, dense=dense,
+                                               n_samples=3 + seed % 6, vcf_strip_chr=True)
+        table = os.path.join(d, "t")
+        vcf_synth.donor_table(contigs, records, ref_k, seed, table + ".txt")
+        opt = pipeline.Options(haploid=haploid, verbose=verbose, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
+        idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+        kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+        want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+        args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p"] + (["-1"] if haploid else []) + (["-v"] if verbose else [])
+        args += [prefix + ".fa", prefix + ".vcf", table]
+        r = subprocess.run([BIN, "index"] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        ok = r.stdout == want
+        nonref = sum(1 for l in want.split("\n") if l and not l.startswith("#") and not l.split("\t")[-1].startswith(("0:", "0/0:")))
+        print("seed %d haploid=%d dense=%d verbose=%d k=%d r=%d records=%d nonref=%d %s %s" % (
+            seed, haploid, dense, verbose, k, ref_k, want.count("\n"), nonref, "OK" if ok else "MISMATCH",
+            "(host blocks)" if "enumerated on the host" in r.stderr else ""), flush=True)
+        if not ok:
+            bad += 1
+            for a, b in zip(r.stdout.split("\n"), want.split("\n")):
+                if a != b:
+                    print("  got :", a[:300]); print("  want:", b[:300]); break
+print("mismatching cases:", bad)
+sys.exit(1 if bad else 0)
