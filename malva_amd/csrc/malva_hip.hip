@@ -27,1045 +27,9 @@ namespace {
 
 constexpr int TPB = 256;
 
-// ---- ASCII rows -------------------------------------------------------------
-
-struct RowIn {
-    const u8 *p;
-    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
-};
-__device__ __forceinline__ int row_len(const u8 *row, int stride)
-{
-    const int lim = stride < MG_MAX_KMER + 1 ? stride : MG_MAX_KMER + 1;
-    int n = 0;
-    while (n < lim && row[n]) ++n;
-    return n;
-}
-
-// canonical form of an ASCII k-mer as the exact map keys it: regular (pure
-// upper-case ACGT, no NUL => never truncated) keys pack to an L-form;
-// anything else is "irregular" and is kept by the host-side overflow list.
-template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, int k, int klen, U128 *out)
-{
-    U128 v{0, 0};
-    if (k != klen || k > MG_MAX_PACKED_K) return false;
-    for (int i = 0; i < k; ++i) {
-        const u32 code = code_of(c(i));
-        if (code > 3) return false;
-        if (i < 32) v.lo |= (u64)code << (2 * i);
-        else v.hi |= (u64)code << (2 * (i - 32));
-    }
-    *out = v;
-    return true;
-}
-
-enum RowOp { OP_BF_INSERT, OP_BF_TEST, OP_BF_INC, OP_BF_GET, OP_BF_INDEX, OP_MAP_TEST, OP_MAP_INC, OP_MAP_GET, OP_WEIGHT };
-
-// One thread per row.  H4/H5/H7/H8 (bloom_filter.hpp:81-125) and H9
-// (kmap.hpp:99-131) in batch form, plus the mixed lookup of set_coverages
-// (main.cpp:166-170).  out type depends on the op.
-template <int OP>
-__global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride, size_t n, BFView bf, MapView map,
-                                                   const u32 *counters, const u8 *is_ref, void *out, u8 *irregular)
-{
-    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const u8 *row = rows + i * stride;
-    const int k = row_len(row, (int)stride);
-    CanonBytes<RowIn> can(RowIn{row}, k);
-    bool want_map = OP == OP_MAP_TEST || OP == OP_MAP_INC || OP == OP_MAP_GET;
-    if (OP == OP_WEIGHT) want_map = is_ref[i] != 0;
-    if (want_map) {
-        U128 key;
-        long long s = -1;
-        const bool regular = pack_regular(can, k, (int)map.klen, &key);
-        if (regular) s = map_find(map, key, xxh3_bytes(can, k));
-        if (irregular) irregular[i] = regular ? 0 : 1;
-        if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
-        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.slots[s].id], counters[i]);
-        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
-        return;
-    }
-    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
-    if (OP == OP_BF_INDEX) ((u64 *)out)[i] = idx;
-    if (OP == OP_BF_INSERT) {
-        atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
-        gate_set(bf, idx);
-    }
-    if (OP == OP_BF_TEST) ((u8 *)out)[i] = bf_bit(bf, idx);
-    if (OP == OP_BF_INC) {
-        if (bf_bit(bf, idx)) atomicAdd(&bf.counts[bf_rank(bf, idx)], counters[i]);
-    }
-    if (OP == OP_BF_GET) ((uint16_t *)out)[i] = bf.counts && bf_bit(bf, idx) ? (uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-    if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts && bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-}
-
-// KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows
-// inserted by earlier calls (ids are global insertion rows).
-__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, BFView bf,
-                                                         u32 row0, u8 *irregular)
-{
-    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const u8 *row = rows + i * stride;
-    const int k = row_len(row, (int)stride);
-    CanonBytes<RowIn> can(RowIn{row}, k);
-    U128 key;
-    const bool regular = pack_regular(can, k, (int)map.klen, &key);
-    irregular[i] = regular ? 0 : 1;
-    if (!regular) return;
-    const u64 h = xxh3_bytes(can, k);
-    gate_set(bf, mod_size(h, bf.mod));
-    const u32 tag = map_tag(h);
-    const u64 mask = (1ULL << map.cap_log2) - 1;
-    u64 s = map_slot(map, h);
-    const u32 my_id = row0 + (u32)i;
-    bool done = false;
-    // every lane retries inside one common loop, so a lane that owns a slot in
-    // the "being written" state always finishes its publish before anyone spins on it
-    for (int guard = 0; !done && guard < (1 << 30); ++guard) {
-        u32 t = __hip_atomic_load(&map.slots[s].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 0) {
-            t = atomicCAS(&map.slots[s].tag, 0u, 1u);
-            if (t == 0) {
-                map.slots[s].klo = key.lo;
-                map.slots[s].khi = key.hi;
-                atomicMin(&map.slots[s].id, my_id);
-                __threadfence();
-                __hip_atomic_store(&map.slots[s].tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                done = true;
-                continue;
-            }
-        }
-        if (t == 1) continue; // owner is publishing: look again
-        if (t == tag) {
-            __threadfence();
-            const u64 a = __hip_atomic_load(&map.slots[s].klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 b = __hip_atomic_load(&map.slots[s].khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a == key.lo && b == key.hi) {
-                const u32 old = atomicMin(&map.slots[s].id, my_id);
-                if (old < row0) map.vals[old] = 0; // kmers[ckmer] = 0 on a key from an earlier call
-                done = true;
-                continue;
-            }
-        }
-        s = (s + 1) & mask;
-    }
-}
-
-__global__ void __launch_bounds__(TPB) map_clear_kernel(MapSlot *slots, u64 cap)
-{
-    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s < cap) slots[s] = MapSlot{0u, 0xFFFFFFFFu, 0, 0, 0};
-}
-// move every published entry of an old table into a new (larger, empty) one
-__global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm)
-{
-    const u64 s0 = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s0 >= (1ULL << oldm.cap_log2)) return;
-    if (oldm.slots[s0].tag < 2) return;
-    U128 key{oldm.slots[s0].klo, oldm.slots[s0].khi};
-    const u64 h = xxh3_lform(key, (int)oldm.klen);
-    const u64 mask = (1ULL << newm.cap_log2) - 1;
-    u64 s = map_slot(newm, h);
-    while (atomicCAS(&newm.slots[s].tag, 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
-    newm.slots[s].klo = key.lo;
-    newm.slots[s].khi = key.hi;
-    newm.slots[s].id = oldm.slots[s0].id;
-}
-// gate bits of every published key (after a filter import rebuilt the gate from the bits alone)
-__global__ void __launch_bounds__(TPB) map_gate_kernel(MapView m, BFView bf)
-{
-    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
-    gate_set(bf, mod_size(xxh3_lform(U128{m.slots[s].klo, m.slots[s].khi}, (int)m.klen), bf.mod));
-}
-
-// list of published (key, id) for export
-__global__ void __launch_bounds__(TPB) map_dump_kernel(MapView m, u64 *klo, u64 *khi, u32 *ids, unsigned long long *count)
-{
-    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
-    const unsigned long long j = atomicAdd(count, 1ULL);
-    klo[j] = m.slots[s].klo;
-    khi[j] = m.slots[s].khi;
-    ids[j] = m.slots[s].id;
-}
-
-// ---- finalize: rank directory, counters, summary ---------------------------
-
-// per 512-bit block popcount, exclusive scan inside a tile of TPB blocks
-__global__ void __launch_bounds__(TPB) blk_pop_kernel(const u64 *words, u64 nwords, u64 n_blk, u32 *blk, u32 *tile_sums)
-{
-    __shared__ u32 sh[TPB];
-    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
-    u32 pop = 0;
-    if (b < n_blk) {
-        const u64 w0 = b * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (w0 + j < nwords) pop += (u32)__popcll(words[w0 + j]);
-    }
-    sh[threadIdx.x] = pop;
-    __syncthreads();
-    for (int d = 1; d < TPB; d <<= 1) {
-        const u32 v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
-    }
-    if (b < n_blk) blk[b] = sh[threadIdx.x] - pop;
-    if (threadIdx.x == TPB - 1) tile_sums[blockIdx.x] = sh[TPB - 1];
-}
-// single workgroup: exclusive scan of tile sums in place; total to *total (u64)
-__global__ void __launch_bounds__(1024) tile_scan_kernel(u32 *tile_sums, u64 n_tiles, unsigned long long *total)
-{
-    __shared__ unsigned long long sh[1024];
-    const u64 per = (n_tiles + 1023) / 1024;
-    const u64 lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    unsigned long long s = 0;
-    for (u64 i = lo; i < hi; ++i) s += tile_sums[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned long long v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned long long run = sh[threadIdx.x] - s;
-    for (u64 i = lo; i < hi; ++i) {
-        const u32 v = tile_sums[i];
-        tile_sums[i] = (u32)run; // valid while the grand total fits 32 bits (checked by the host)
-        run += v;
-    }
-    if (threadIdx.x == 1023) *total = sh[1023];
-}
-__global__ void __launch_bounds__(TPB) blk_add_kernel(u32 *blk, u64 n_blk, const u32 *tile_sums, u32 total)
-{
-    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (b < n_blk) blk[b] += tile_sums[blockIdx.x];
-    if (b == n_blk) blk[b] = total; // rank(size) (bloom_filter.hpp:97)
-}
-// gate entries of every set filter bit (used when a filter is imported rather than built by inserts)
-__global__ void __launch_bounds__(TPB) gate_from_bits_kernel(BFView bf, u64 nwords)
-{
-    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (w >= nwords) return;
-    u64 x = bf.words[w];
-    while (x) {
-        const int b = __ffsll((unsigned long long)x) - 1;
-        gate_set(bf, w * 64 + b);
-        x &= x - 1;
-    }
-}
-// positions of the set bits in ascending (= counter) order; needs the rank directory
-__global__ void __launch_bounds__(TPB) bit_positions_kernel(BFView bf, u64 nwords, u64 *out)
-{
-    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (w >= nwords) return;
-    u64 x = bf.words[w];
-    if (!x) return;
-    u64 r = bf_rank(bf, w * 64);
-    while (x) {
-        out[r++] = w * 64 + (u64)(__ffsll((unsigned long long)x) - 1);
-        x &= x - 1;
-    }
-}
-__global__ void __launch_bounds__(TPB) set_bits_kernel(BFView bf, const u64 *pos, u64 n, u64 size, int *bad)
-{
-    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const u64 p = pos[i];
-    if (p >= size || (i && pos[i - 1] >= p)) {
-        *bad = 1; // out of range or not strictly ascending
-        return;
-    }
-    atomicOr((unsigned long long *)&bf.words[p >> 6], 1ULL << (p & 63));
-    gate_set(bf, p);
-}
-__global__ void __launch_bounds__(TPB) mask_u16_kernel(const u32 *in, uint16_t *out, u64 n)
-{
-    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (i < n) out[i] = (uint16_t)in[i];
-}
-__global__ void __launch_bounds__(TPB) widen_u16_kernel(const uint16_t *in, u32 *out, u64 n)
-{
-    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
-
-// ---- H11: reference-context scan (main.cpp:383-401) --------------------------
-// One thread per window start p; the workgroup stages its TPB + ref_k - 1 bytes
-// of the contig through LDS once.  Windows are full length (contigs shorter
-// than ref_k are handled by the host wrapper with the row kernels).
-struct LdsIn {
-    const u8 *p;
-    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
-};
-// The reference slides its centre k-mer by appending reference[p - (ref_k-k)/2]
-// (main.cpp:395-397).  When ref_k - k is odd that append runs one base ahead of a
-// true slide: window w >= 1 reads the centre at offset (ref_k-k) - (ref_k-k)/2,
-// and windows 1..k-1 still carry the tail of the first k-mer, i.e. a string with a
-// one-base gap.  CentreIn reproduces exactly that string (for even ref_k - k it is
-// the plain centred k-mer).
-struct CentreIn {
-    const u8 *p; // window start
-    int off_first, off_slide, keep; // keep = bytes still taken at the first window's offset
-    __device__ __forceinline__ u32 operator()(int i) const { return p[(i < keep ? off_first : off_slide) + i]; }
-};
-__global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0, u64 n_windows, int k, int ref_k, BFView bf,
-                                                       BFView ctx)
-{
-    __shared__ u8 sh[TPB + MG_MAX_KMER];
-    const u64 p0 = (u64)blockIdx.x * TPB;
-    const u64 avail = n_windows - p0 < TPB ? n_windows - p0 : TPB;
-    const int nbytes = (int)avail + ref_k - 1;
-    for (int i = threadIdx.x; i < nbytes; i += TPB) sh[i] = contig[p0 + i];
-    __syncthreads();
-    if (threadIdx.x >= avail) return;
-    const u64 w = w0 + p0 + threadIdx.x; // window index inside the contig
-    const int off = (ref_k - k) / 2;
-    const int keep = w < (u64)k ? k - (int)w : 0;
-    CanonBytes<CentreIn> ck(CentreIn{sh + threadIdx.x, off, (ref_k - k) - off, keep}, k);
-    const u64 idx = mod_size(xxh3_bytes(ck, k), bf.mod);
-    if (!gate_open(bf, idx) || !bf_bit(bf, idx)) return;
-    CanonBytes<LdsIn> cc(LdsIn{sh + threadIdx.x}, ref_k);
-    const u64 cidx = mod_size(xxh3_bytes(cc, ref_k), ctx.mod);
-    atomicOr((unsigned long long *)&ctx.words[cidx >> 6], 1ULL << (cidx & 63));
-}
-
-// ---- H10: KMC scan (main.cpp:482-500) -----------------------------------------
-// The scan is three kernels, each one dense in what it does:
-//
-//   scan_filter_kernel  every table row: canonicalise the centre k-mer, XXH3, slot,
-//                       ONE probe of the L2-resident gate.  Rows whose gate is open
-//                       (~3-4 %: true matches plus the gate's false positives) are
-//                       appended to the "open" list.  This kernel streams the table
-//                       and is the dominant one.
-//   scan_probe_kernel   open rows only: ref_bf.increment (tag walk in the exact map,
-//                       counter add) and the test of the real `bf` bit.  Rows whose
-//                       bf bit is set go to the "hit" list.
-//   scan_hits_kernel    hit rows only: context_bf.test_key on the ref_k-mer, then
-//                       bf.increment's rank + counter add.
-//
-// Doing the rare work inline instead (first versions) made nearly every wave walk
-// the rare path with 2-3 live lanes and eat its HBM latency: 2.0 ms vs 0.8 ms.
-// Order of operations vs the reference (main.cpp:495-499): `bf.increment` is a
-// no-op unless the bf bit is set, so testing bf before context_bf, and doing the map
-// increment in a different kernel, gives identical counters (all adds commute).
-//
-// List appends are staged per workgroup in LDS and flushed with ONE returning global
-// atomic per ~500+ entries: a returning atomic per appending wave on a single counter
-// word serialises at ~11 ns each (90 % of the first version's time, and still a third
-// of the filter kernel with per-wave staging at a 5 % append rate).
-//
-// A list entry IS the table row (hi, lo, count): the consumers never go back to the
-// table, which would cost two or three random 128-byte lines per entry.
-struct RowList {
-    u64 *hi, *lo;
-    u32 *cnt;
-};
-template <int CAP> struct BlockStage {
-    u64 *hi, *lo; // [CAP]
-    u32 *cnt;     // [CAP]
-    u32 *n;       // entries staged
-    unsigned long long *base;
-    // every lane of the wave must call this (it ballots)
-    __device__ __forceinline__ void push(bool take, U128 m, u32 count)
-    {
-        const u64 mask = __ballot(take);
-        if (!mask) return;
-        const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)mask) - 1;
-        u32 off = 0;
-        if (lane == leader) off = atomicAdd(n, (u32)__popcll(mask));
-        off = __shfl(off, leader, 64);
-        if (take) {
-            const u32 q = off + __popcll(mask & ((1ULL << lane) - 1));
-            lo[q] = m.lo;
-            hi[q] = m.hi;
-            cnt[q] = count;
-        }
-    }
-    // every thread of the workgroup must call this; flushes when more than `keep` entries are staged
-    __device__ __forceinline__ void flush_if_above(u32 keep, const RowList &g, unsigned long long *g_count)
-    {
-        __syncthreads();
-        const u32 c = *n;
-        if (c > keep) {
-            if (threadIdx.x == 0) *base = atomicAdd(g_count, (unsigned long long)c);
-            __syncthreads();
-            const unsigned long long b = *base;
-            for (u32 j = threadIdx.x; j < c; j += TPB) {
-                g.hi[b + j] = hi[j];
-                g.lo[b + j] = lo[j];
-                g.cnt[b + j] = cnt[j];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) *n = 0;
-        }
-        __syncthreads();
-    }
-};
-
-// The same per wave (no workgroup barrier anywhere): the four waves of a workgroup then never
-// wait for each other, which matters in the filter kernel where the barrier pair per iteration
-// made every wave run at the pace of the slowest.
-template <int WCAP> struct WaveStage {
-    u64 *hi, *lo; // this wave's [WCAP] slices
-    u32 *cnt;
-    int staged;   // wave-uniform
-    __device__ __forceinline__ void flush(const RowList &g, unsigned long long *g_count)
-    {
-        const int lane = threadIdx.x & 63;
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(g_count, (unsigned long long)staged);
-        b = __shfl(b, 0, 64);
-        for (int j = lane; j < staged; j += 64) {
-            g.hi[b + j] = hi[j];
-            g.lo[b + j] = lo[j];
-            g.cnt[b + j] = cnt[j];
-        }
-        staged = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // every lane of the wave must call this (it ballots)
-    __device__ __forceinline__ void push(bool take, U128 m, u32 count, const RowList &g, unsigned long long *g_count)
-    {
-        const u64 mask = __ballot(take);
-        if (!mask) return;
-        if (take) {
-            const int q = staged + __popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1));
-            lo[q] = m.lo;
-            hi[q] = m.hi;
-            cnt[q] = count;
-        }
-        staged += __popcll(mask);
-        __builtin_amdgcn_wave_barrier();
-        if (staged > WCAP - 64) flush(g, g_count);
-    }
-};
-
-// counters[0] = open rows, [1] = hit rows of the current chunk, [2] = hit rows of the whole call
-//
-// ROWS table rows per thread and iteration, in phases so that the memory operations of
-// one phase are all in flight together:
-//   A  load ROWS x (hi, lo, cnt)            -- coalesced, non-temporal: the only HBM stream
-//   B  canonicalise, XXH3, slot             -- pure VALU
-//   C  load ROWS gate words                 -- random 8-byte loads from a 4 MiB bitmap (L2)
-//   D  test, stage open rows
-// `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
-// 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
-// VAR bit 0: per-wave staging (no barriers) instead of per-workgroup; bit 1 (ROWS == 2 only): each
-// thread takes two ADJACENT rows with 16-byte loads instead of two rows TPB apart with 8-byte loads.
-template <int KC, int RC, int ROWS, int VAR>
-__global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
-                                                          const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt, BFView bf,
-                                                          RowList open, unsigned long long *counters, int ablate)
-{
-    constexpr bool WAVE = VAR & 1, VEC = (VAR & 2) && ROWS == 2;
-    constexpr int CAP = WAVE ? (TPB / 64) * 192 : TPB * ROWS + 256;
-    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
-    __shared__ u32 sh_cnt[CAP];
-    __shared__ u32 sh_n;
-    __shared__ unsigned long long sh_base;
-    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
-    const int wv = threadIdx.x >> 6;
-    WaveStage<192> ws{sh_hi + wv * 192, sh_lo + wv * 192, sh_cnt + wv * 192, 0};
-    if (!WAVE) {
-        if (threadIdx.x == 0) sh_n = 0;
-        __syncthreads();
-    }
-    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
-    const int off = (r - k) / 2;
-    const u64 step = (u64)gridDim.x * TPB * ROWS;
-    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
-        U128 m[ROWS];
-        u32 count[ROWS];
-        u64 idx[ROWS], gate[ROWS];
-        bool valid[ROWS];
-        if (VEC && base + (u64)TPB * 2 <= n) { // A, whole tile inside the table (table bases are 16-byte aligned)
-            typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
-            typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
-            const u64 i = base + 2 * (u64)threadIdx.x;
-            const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
-            const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
-            const v2u32 c2 = __builtin_nontemporal_load((const v2u32 *)(cnt + i));
-            m[0] = U128{l2.x, h2.x};
-            m[ROWS - 1] = U128{l2.y, h2.y};
-            count[0] = c2.x;
-            count[ROWS - 1] = c2.y;
-            valid[0] = valid[ROWS - 1] = true;
-        } else {
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j) { // A
-                const u64 i = VEC ? base + 2 * (u64)threadIdx.x + j : base + (u64)j * TPB + threadIdx.x;
-                valid[j] = i < n && (!VEC || i < base + (u64)TPB * 2);
-                m[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
-                m[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
-                count[j] = valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // B
-            U128 c = m[j];
-            if (!(ablate & 8)) c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
-            const u64 h = (ablate & 4) ? (c.lo ^ c.hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed_k<KC>(c, k);
-            idx[j] = mod_size(h, bf.mod);
-        }
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) // C
-            gate[j] = (ablate & 1) ? 0ULL : bf.use_gate ? bf.gate[gate_word(bf, idx[j])] : ~0ULL;
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // D
-            const u64 gm = gate_mask(bf, idx[j]);
-            const bool open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
-            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
-            if (WAVE) ws.push(open_j, m[j], count[j], open, &counters[0]);
-            else st.push(open_j, m[j], count[j]);
-        }
-        if (!WAVE) st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
-    }
-    if (WAVE) {
-        if (ws.staged) ws.flush(open, &counters[0]);
-    } else
-        st.flush_if_above(0, open, &counters[0]);
-}
-
-template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
-                                                         unsigned long long *counters)
-{
-    constexpr int CAP = TPB + 256;
-    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
-    __shared__ u32 sh_cnt[CAP];
-    __shared__ u32 sh_n;
-    __shared__ unsigned long long sh_base;
-    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
-    if (threadIdx.x == 0) sh_n = 0;
-    __syncthreads();
-    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
-    const int off = (r - k) / 2;
-    const u64 n_open = counters[0];
-    const u64 step = (u64)gridDim.x * TPB;
-    for (u64 base = (u64)blockIdx.x * TPB; base < n_open; base += step) {
-        const u64 j = base + threadIdx.x;
-        bool hit = false;
-        U128 m{0, 0};
-        u32 count = 0;
-        if (j < n_open) {
-            m = U128{open.lo[j], open.hi[j]};
-            count = open.cnt[j];
-            const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
-            const u64 h = xxh3_packed_k<KC>(c, k);
-            const u64 idx = mod_size(h, bf.mod);
-            const u64 word = bf.words[idx >> 6];
-            const long long s = map_find(map, c, h);
-            if (s >= 0) atomicAdd(&map.vals[map.slots[s].id], count); // ref_bf.increment (main.cpp:495)
-            hit = (word >> (idx & 63)) & 1;
-        }
-        st.push(hit, m, count);
-        st.flush_if_above(CAP - TPB, hits, &counters[1]);
-    }
-    st.flush_if_above(0, hits, &counters[1]);
-}
-
-template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFView bf, BFView ctx, RowList hits,
-                                                        unsigned long long *counters)
-{
-    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
-    const int off = (r - k) / 2;
-    const u64 nh = counters[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] += nh;
-    for (u64 j = (u64)blockIdx.x * TPB + threadIdx.x; j < nh; j += (u64)gridDim.x * TPB) {
-        const U128 m{hits.lo[j], hits.hi[j]};
-        const U128 l = mform_to_lform(m, r);
-        const U128 cc = canon_sub(m, l, r, 0, r);
-        const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
-        if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
-        const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
-        atomicAdd(&bf.counts[bf_rank(bf, idx)], hits.cnt[j]);             // bf.increment (main.cpp:498)
-    }
-}
-
-// debug: hash % size of packed k-mers (M-form, klen bases)
-__global__ void __launch_bounds__(TPB) packed_index_kernel(const u64 *hi, const u64 *lo, u64 n, int klen, ModDesc mod,
-                                                           u64 *out)
-{
-    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const U128 m{lo[i], hi[i]};
-    const U128 l = mform_to_lform(m, klen);
-    const U128 c = canon_sub(m, l, klen, 0, klen);
-    out[i] = mod_size(xxh3_packed(c, klen), mod);
-}
-
-// ---- V1: coverage reduction (main.cpp:159-181) -----------------------------------
-__global__ void __launch_bounds__(TPB) cover_kernel(const i32 *w, const u64 *sig_kmer_off, const u64 *allele_sig_off,
-                                                    u64 n_alleles, u32 *cov)
-{
-    const u64 a = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (a >= n_alleles) return;
-    u32 allele_cov = 0;
-    for (u64 s = allele_sig_off[a]; s < allele_sig_off[a + 1]; ++s) {
-        u32 curr = 0;
-        i32 n = 0;
-        for (u64 j = sig_kmer_off[s]; j < sig_kmer_off[s + 1]; ++j) {
-            const i32 wt = w[j];
-            if (wt > 0) {
-                curr = (curr * (u32)n + (u32)wt) / (u32)(n + 1);
-                ++n;
-            }
-        }
-        if (curr > allele_cov) allele_cov = curr;
-    }
-    cov[a] = (u32)(float)allele_cov; // through the float parameter of set_variant_coverage (var_block.hpp:84)
-}
-
-// ---- G1-G3 ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) genotype_kernel(const u32 *cov, const float *freq, const u32 *var_allele_off,
-                                                       u64 n_vars, GenoParams p, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
-                                                       double *probs, const u64 *var_gt_off)
-{
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (v >= n_vars) return;
-    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
-    genotype_one(cov + a0, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v,
-                 probs ? probs + var_gt_off[v] : nullptr);
-}
-
-// ---- fused isolated-variant path ---------------------------------------------------
-// The signature k-mer of allele a of a lone variant (var_block.hpp:145-200 with
-// comb = {v}):  ref[pos-mp, pos) + allele + ref[pos+ref_size, +ms),
-// mp = k/2 - len/2,  ms = ceil(k/2) - (len - len/2).
-struct SigIn {
-    const u8 *ref_left;  // reference + pos - mp
-    const u8 *allele;
-    const u8 *ref_right; // reference + pos + ref_size
-    int mp, alen;
-    __device__ __forceinline__ u32 operator()(int i) const
-    {
-        return i < mp ? ref_left[i] : (i < mp + alen ? allele[i - mp] : ref_right[i - mp - alen]);
-    }
-};
-// weight of one signature k-mer given as bytes: KMAP::get_count (allele 0) or BF::get_count
-template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, int k, bool is_ref, const BFView &bf, const MapView &map)
-{
-    CanonBytes<IN> can(in, k);
-    if (is_ref) {
-        U128 key;
-        if (pack_regular(can, k, (int)map.klen, &key)) {
-            const long long s = map_find(map, key, xxh3_bytes(can, k));
-            if (s >= 0) return (i32)map.vals[map.slots[s].id];
-        }
-        return 0;
-    }
-    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
-    return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-}
-// 2-bit code of an upper-case ACGT byte without a table: (b >> 1) & 3 gives A0 C1 G3 T2
-__device__ __forceinline__ u32 acgt_code(u32 b, bool *ok)
-{
-    *ok = b == 'A' || b == 'C' || b == 'G' || b == 'T';
-    const u32 c = (b >> 1) & 3;
-    return c ^ (c >> 1);
-}
-// n <= 32 bases starting at an arbitrary byte address -> 2-bit L-form, four bases per aligned
-// dword load.  *bad gets bit 4j set when dword j holds a byte outside ACGT (coarse on purpose:
-// a flagged span sends the allele down the exact byte-wise path).  Reads whole aligned dwords,
-// i.e. up to 3 bytes either side of the span: the reference buffer is padded for that.
-__device__ __forceinline__ void pack_span(const u8 *p, int n, u64 *codes, u64 *bad)
-{
-    const u64 addr = (u64)p;
-    const u32 *q = (const u32 *)(addr & ~3ULL);
-    const u32 sh = (u32)(addr & 3);
-    u64 c = 0, b = 0;
-    u32 prev = q[0];
-    for (int j = 0; 4 * j < n; ++j) {
-        const u32 next = q[j + 1];
-        const u32 d = sh ? __builtin_amdgcn_alignbyte(next, prev, sh) : prev;
-        u32 t = (d >> 1) & 0x03030303u; // per byte: A0 C1 G3 T2
-        t ^= (t >> 1) & 0x01010101u;    //           A0 C1 G2 T3
-        const u32 c8 = (t * 0x01041040u) >> 24;
-        const int left = n - 4 * j;
-        const u32 m = left >= 4 ? 0xFFFFFFFFu : ((1u << (8 * left)) - 1);
-        if ((expand4(c8) ^ d) & m) b |= 0xFULL << (4 * j);
-        c |= (u64)(left >= 4 ? c8 : (c8 & ((1u << (2 * left)) - 1))) << (8 * j);
-        prev = next;
-    }
-    *codes = c;
-    *bad = b;
-}
-__device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
-{
-    U128 r;
-    if (s == 0) return v;
-    if (s < 64) {
-        r.hi = (v.hi << s) | (v.lo >> (64 - s));
-        r.lo = v.lo << s;
-    } else {
-        r.hi = v.lo << (s - 64);
-        r.lo = 0;
-    }
-    return r;
-}
-// Fast path: both flanks and the allele are pure ACGT, so the signature is assembled in
-// 2-bit form from flanks packed once per variant (shared by its alleles), canonicalised
-// with integer compares and hashed with the register-resident XXH3 -- the same code the
-// scan uses.  Anything else (N / IUPAC in the window, k outside 17..64) takes weight_bytes.
-__global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference, u64 n_vars, const u64 *pos,
-                                                            const u32 *var_allele_off, const u32 *allele_off,
-                                                            const u8 *pool, const float *freq, const u64 *present_mask,
-                                                            const u8 *flags, int k, BFView bf, MapView map, GenoParams p,
-                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
-                                                            double *probs, const u64 *var_gt_off)
-{
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (v >= n_vars) return;
-    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
-    const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
-    u32 *cov = cov_out + a0;
-    for (u32 a = 0; a < A; ++a) cov[a] = 0;
-    if (flags[v] & 1) {
-        const u64 pm = present_mask[v];
-        const u8 *site = reference + pos[v];
-        const int lmax = k / 2, rmax = (k + 1) / 2;
-        const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
-        // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
-        u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
-        if (packed_ok) {
-            pack_span(site - lmax, lmax, &lf, &lbad);
-            pack_span(site + ref_size, rmax, &rf, &rbad);
-        }
-        for (u32 a = 0; a < A && a < 64; ++a) {
-            if (!((pm >> a) & 1)) continue;
-            const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
-            const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
-            if (mp < 0 || ms < 0) continue; // alleles >= k take the general path (host contract)
-            const u8 *al = pool + allele_off[a0 + a];
-            bool fast = packed_ok && (lbad >> (lmax - mp)) == 0 && (ms == 0 || (rbad & ((1ULL << ms) - 1)) == 0);
-            U128 L{0, 0};
-            if (fast) {
-                for (int i = 0; i < alen; ++i) {
-                    bool ok;
-                    const u64 code = acgt_code(al[i], &ok);
-                    fast &= ok;
-                    if (i < 32) L.lo |= code << (2 * i);
-                    else L.hi |= code << (2 * (i - 32));
-                }
-            }
-            i32 w;
-            if (fast) {
-                L = shl128(L, 2 * mp);
-                if (mp) L.lo |= lf >> (2 * (lmax - mp));                         // last mp bases of the left flank
-                if (ms) {
-                    const U128 r = shl128(U128{ms >= 32 ? rf : rf & ((1ULL << (2 * ms)) - 1), 0}, 2 * (mp + alen));
-                    L.lo |= r.lo;
-                    L.hi |= r.hi;
-                }
-                const U128 mk = mask128(2 * k);
-                const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - k)); // M-form of the k-mer
-                const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
-                const U128 key = lt128(L, rc) ? L : rc;
-                const u64 h = xxh3_packed(key, k);
-                if (a == 0) {
-                    const long long s = map_find(map, key, h);
-                    w = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
-                } else {
-                    const u64 idx = mod_size(h, bf.mod);
-                    w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-                }
-            } else {
-                w = weight_bytes(SigIn{site - mp, al, site + ref_size, mp, alen}, k, a == 0, bf, map);
-            }
-            if (w > 0) cov[a] = (u32)(float)(u32)w;
-        }
-    }
-    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
-}
-
-// ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
-// VB::extract_kmers (var_block.hpp:95-219) with get_combs_on_the_right/left (:436-624), combine_combs (:630-677),
-// get_ref_subs (:682-702) and build_alleles_combs / combine_haplotypes (:709-786), fused with set_coverages
-// (main.cpp:151-184).  One workgroup per variant.  The reference builds the SET of distinct haplotype picks per
-// chain and takes, per allele, the max over signatures; a max does not care about duplicates, so here every
-// (chain, panel sample, haplotype pick) is simply evaluated and max-reduced -- thousands of redundant hashes
-// are cheaper on this machine than a device-side set.
-// Fixed capacities (chains per side, chain length, unphased fan-out): a variant that exceeds one is flagged in
-// `overflow` and its block is redone by the host enumerator + mg_lookup_cover, so results never depend on them.
-struct BlockBatch {
-    const u8 *reference;      // concatenated contigs (mg_reference_upload)
-    const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
-    const u32 *blk_ref_len;   //            and its length
-    const u32 *blk_var_off;   // [n_blocks + 1]
-    const u32 *var_block;     // [n_vars] block of each variant
-    const i32 *pos;           // 0-based position in the contig
-    const u32 *ref_size, *min_size;
-    const u8 *present;
-    const u32 *var_allele_off; // [n_vars + 1] allele slots
-    const u32 *allele_off;     // [n_slots + 1] into pool
-    const u8 *pool;
-    const u8 *canon;           // [n_slots] first allele index of the variant with the same text
-    const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14
-    u32 n_samples;
-    int haploid, k;
-};
-constexpr int BK_MAXC = 8;   // chains per side
-constexpr int BK_MAXL = 12;  // members per chain
-constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
-constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
-
-struct BkChains {
-    int n;
-    int len[BK_MAXC];
-    int sum[BK_MAXC];
-    int mem[BK_MAXC][BK_MAXL];
-};
-
-// get_combs_on_the_right (step +1) / _left (step -1); indices are batch-global variant indices inside [b0, b1)
-__device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
-{
-    const int k = B.k;
-    auto ov = [&](int x, int y) { // overlapping(left, right) with (x, y) given in scan order
-        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
-        return B.pos[l] <= B.pos[r] && B.pos[r] < B.pos[l] + (int)B.ref_size[l];
-    };
-    auto nr = [&](int x, int y, int extra) {
-        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
-        return B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra + (k + 1) / 2 >= B.pos[r];
-    };
-    out->n = 0;
-    bool halt = false;
-    for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
-        if (!B.present[j]) continue;
-        if (ov(i, j)) continue;
-        const int gain = (int)B.ref_size[j] - (int)B.min_size[j];
-        if (out->n == 0) {
-            if (nr(i, j, 0)) {
-                out->mem[0][0] = j;
-                out->len[0] = 1;
-                out->sum[0] = gain;
-                out->n = 1;
-            }
-            continue;
-        }
-        bool added = false;
-        const int n0 = out->n;
-        for (int c = 0; c < n0; ++c) {
-            if (!ov(out->mem[c][out->len[c] - 1], j)) {
-                added = true;
-                if (nr(i, j, out->sum[c])) {
-                    if (out->len[c] >= BK_MAXL) return false;
-                    out->mem[c][out->len[c]++] = j;
-                    out->sum[c] += gain;
-                }
-            }
-        }
-        if (!added) {
-            for (int c = 0; c < n0; ++c) {
-                int len = out->len[c], ns = out->sum[c];
-                while (len > 0 && ov(out->mem[c][len - 1], j)) {
-                    const int m = out->mem[c][len - 1];
-                    ns -= (int)B.ref_size[m] - (int)B.min_size[m];
-                    --len;
-                }
-                if (nr(i, j, ns)) {
-                    added = true;
-                    if (out->n >= BK_MAXC || len + 1 > BK_MAXL) return false;
-                    const int d = out->n++;
-                    for (int q = 0; q < len; ++q) out->mem[d][q] = out->mem[c][q];
-                    out->mem[d][len] = j;
-                    out->len[d] = len + 1;
-                    out->sum[d] = ns + gain;
-                }
-            }
-            if (!added) halt = true;
-        }
-    }
-    return true;
-}
-
-struct LdsBytes {
-    const u8 *p;
-    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
-};
-// weight of the k-mer in buf[0, len): packed fast path when it is k pure-ACGT bases, byte-wise otherwise
-__device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, const BFView &bf, const MapView &map)
-{
-    if (len >= 17 && len <= MG_MAX_PACKED_K) {
-        U128 L{0, 0};
-        bool ok = true;
-        for (int i = 0; i < len; ++i) {
-            bool o;
-            const u64 code = acgt_code(buf[i], &o);
-            ok &= o;
-            if (i < 32) L.lo |= code << (2 * i);
-            else L.hi |= code << (2 * (i - 32));
-        }
-        if (ok) {
-            const U128 mk = mask128(2 * len);
-            const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - len));
-            const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
-            const U128 key = lt128(L, rc) ? L : rc;
-            const u64 h = xxh3_packed(key, len);
-            if (is_ref) {
-                if (len != (int)map.klen) return 0;
-                const long long s = map_find(map, key, h);
-                return s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
-            }
-            const u64 idx = mod_size(h, bf.mod);
-            return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-        }
-    }
-    return weight_bytes(LdsBytes{buf}, len, is_ref, bf, map);
-}
-
-__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow)
-{
-    __shared__ BkChains sh_left, sh_right;
-    __shared__ int sh_comb[BK_MAXC * BK_MAXC][BK_MAXCOMB];
-    __shared__ int sh_comb_len[BK_MAXC * BK_MAXC], sh_comb_mid[BK_MAXC * BK_MAXC];
-    __shared__ int sh_ncomb, sh_bad;
-    __shared__ u32 sh_cov[128];
-    __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
-    __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
-    const int g = blockIdx.x;
-    if ((u64)g >= n_vars) return;
-    const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
-    const u32 blk = B.var_block[g];
-    const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
-    const u8 *ref = B.reference + B.blk_ref_base[blk];
-    const i32 ref_len = (i32)B.blk_ref_len[blk];
-    const int k = B.k;
-    for (u32 a = threadIdx.x; a < 128; a += TPB) sh_cov[a] = 0;
-    if (threadIdx.x < 4) sh_slide[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        sh_bad = 0;
-        sh_ncomb = 0;
-        const bool eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
-        if (A > 127 || k > MG_MAX_PACKED_K) sh_bad = 1;
-        else if (eligible) {
-            if (!bk_chains(B, b0, b1, g, -1, &sh_left) || !bk_chains(B, b0, b1, g, +1, &sh_right)) sh_bad = 1;
-            else { // combine_combs
-                const int nl = sh_left.n ? sh_left.n : 1, nrr = sh_right.n ? sh_right.n : 1;
-                for (int l = 0; l < nl; ++l)
-                    for (int r = 0; r < nrr; ++r) {
-                        int *comb = sh_comb[sh_ncomb];
-                        int len = 0;
-                        if (sh_left.n)
-                            for (int q = sh_left.len[l] - 1; q >= 0; --q) comb[len++] = sh_left.mem[l][q];
-                        sh_comb_mid[sh_ncomb] = len;
-                        comb[len++] = g;
-                        if (sh_right.n)
-                            for (int q = 0; q < sh_right.len[r]; ++q) comb[len++] = sh_right.mem[r][q];
-                        sh_comb_len[sh_ncomb++] = len;
-                    }
-            }
-        }
-    }
-    __syncthreads();
-    if (sh_bad) {
-        if (threadIdx.x == 0) overflow[g] = 1;
-        for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
-        return;
-    }
-    u8 *buf = sh_buf[threadIdx.x];
-    bool bad = false;
-    for (int c = 0; c < sh_ncomb; ++c) {
-        const int *comb = sh_comb[c];
-        const int m = sh_comb_len[c], jm = sh_comb_mid[c];
-        const int first_pos = B.pos[comb[0]];
-        const int last_end = B.pos[comb[m - 1]] + (int)B.ref_size[comb[m - 1]];
-        for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
-            bool phased = true;
-            if (!B.haploid)
-                for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
-            u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
-            if (!B.haploid && !phased && m > BK_MAXU) {
-                bad = true;
-                continue;
-            }
-            for (u32 pick = 0; pick < npick; ++pick) {
-                // allele of member j under this pick
-                auto allele_of = [&](int j) -> u32 {
-                    const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
-                    const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
-                    if (B.haploid) return a1;
-                    if (phased) return pick ? a2 : a1;
-                    return (pick >> j) & 1 ? a2 : a1;
-                };
-                // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
-                int len_v = 0, mid_pos = 0, mid_len = 0;
-                u32 mid_allele = 0;
-                for (int j = 0; j < m; ++j) {
-                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
-                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
-                    if (j == jm) {
-                        mid_pos = len_v;
-                        mid_len = al;
-                        mid_allele = allele_of(j);
-                    }
-                    len_v += al;
-                    if (j + 1 < m) len_v += B.pos[comb[j + 1]] - (B.pos[comb[j]] + (int)B.ref_size[comb[j]]);
-                }
-                const u32 mid_canon = B.canon[a0 + mid_allele];
-                if (m == 1 && mid_len >= k) { // the whole allele is the signature: sliding k-mers, done below
-                    atomicOr(&sh_slide[mid_canon >> 5], 1u << (mid_canon & 31));
-                    continue;
-                }
-                const int first_part = mid_pos + mid_len / 2;
-                const int mp = k / 2 - first_part;                  // missing_prefix (negative: cut)
-                const int ms = (k + 1) / 2 - (len_v - first_part);  // missing_suffix
-                if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
-                    bad = true; // the reference clips or throws here: leave it to the host path
-                    continue;
-                }
-                // W[x] = Vext[x - mp] for x in [0, k), where Vext is V with the reference continuing on both sides:
-                // a piece that covers v in [vs, vs + L) lands at x in [vs + mp, vs + L + mp), clipped to the window
-                for (int x = 0; x < mp && x < k; ++x) buf[x] = ref[first_pos - mp + x];
-                int vs = 0;
-                for (int j = 0; j < m; ++j) {
-                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
-                    const u8 *ap = B.pool + B.allele_off[slot];
-                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
-                    for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) buf[x] = ap[x - mp - vs];
-                    vs += al;
-                    if (j + 1 < m) {
-                        const int gs = B.pos[comb[j]] + (int)B.ref_size[comb[j]];
-                        const int gl = B.pos[comb[j + 1]] - gs;
-                        for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) buf[x] = ref[gs + (x - mp - vs)];
-                        vs += gl;
-                    }
-                }
-                for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
-                const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
-                if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
-            }
-        }
-    }
-    if (bad) sh_bad = 1;
-    __syncthreads();
-    // sliding signatures of lone long alleles (var_block.hpp:130-144): truncating running mean over the allele's k-mers
-    for (u32 a = threadIdx.x; a < A; a += TPB) {
-        if (!((sh_slide[a >> 5] >> (a & 31)) & 1)) continue;
-        const u8 *ap = B.pool + B.allele_off[a0 + a];
-        const int al = (int)(B.allele_off[a0 + a + 1] - B.allele_off[a0 + a]);
-        u32 curr = 0;
-        i32 n = 0;
-        for (int p = 0; p + k <= al; ++p) {
-            for (int x = 0; x < k; ++x) buf[x] = ap[p + x];
-            const i32 w = bk_weight(buf, k, a == 0, bf, map);
-            if (w > 0) {
-                curr = (curr * (u32)n + (u32)w) / (u32)(n + 1);
-                ++n;
-            }
-        }
-        atomicMax(&sh_cov[a], curr);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) overflow[g] = sh_bad ? 1 : 0;
-    for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
-}
+#include "store_kernels.h"
+#include "scan_kernels.h"
+#include "variant_kernels.h"
 
 } // namespace
 

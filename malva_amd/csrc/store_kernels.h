@@ -1,0 +1,272 @@
+// store_kernels.h -- batch forms of every BF / KMAP call on ASCII rows, exact-map insert / rehash / dump, and the finalize pass (rank directory, gate rebuild)
+// Part of the malva_hip translation unit: included by malva_hip.hip inside its anonymous namespace, after
+// geno_dev.h (which brings xxh3_dev.h and kmer_dev.h).  See DESIGN.md section 4 for the kernels' rooflines.
+#pragma once
+
+// ---- ASCII rows -------------------------------------------------------------
+
+struct RowIn {
+    const u8 *p;
+    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
+};
+__device__ __forceinline__ int row_len(const u8 *row, int stride)
+{
+    const int lim = stride < MG_MAX_KMER + 1 ? stride : MG_MAX_KMER + 1;
+    int n = 0;
+    while (n < lim && row[n]) ++n;
+    return n;
+}
+
+// canonical form of an ASCII k-mer as the exact map keys it: regular (pure
+// upper-case ACGT, no NUL => never truncated) keys pack to an L-form;
+// anything else is "irregular" and is kept by the host-side overflow list.
+template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, int k, int klen, U128 *out)
+{
+    U128 v{0, 0};
+    if (k != klen || k > MG_MAX_PACKED_K) return false;
+    for (int i = 0; i < k; ++i) {
+        const u32 code = code_of(c(i));
+        if (code > 3) return false;
+        if (i < 32) v.lo |= (u64)code << (2 * i);
+        else v.hi |= (u64)code << (2 * (i - 32));
+    }
+    *out = v;
+    return true;
+}
+
+enum RowOp { OP_BF_INSERT, OP_BF_TEST, OP_BF_INC, OP_BF_GET, OP_BF_INDEX, OP_MAP_TEST, OP_MAP_INC, OP_MAP_GET, OP_WEIGHT };
+
+// One thread per row.  H4/H5/H7/H8 (bloom_filter.hpp:81-125) and H9
+// (kmap.hpp:99-131) in batch form, plus the mixed lookup of set_coverages
+// (main.cpp:166-170).  out type depends on the op.
+template <int OP>
+__global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride, size_t n, BFView bf, MapView map,
+                                                   const u32 *counters, const u8 *is_ref, void *out, u8 *irregular)
+{
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u8 *row = rows + i * stride;
+    const int k = row_len(row, (int)stride);
+    CanonBytes<RowIn> can(RowIn{row}, k);
+    bool want_map = OP == OP_MAP_TEST || OP == OP_MAP_INC || OP == OP_MAP_GET;
+    if (OP == OP_WEIGHT) want_map = is_ref[i] != 0;
+    if (want_map) {
+        U128 key;
+        long long s = -1;
+        const bool regular = pack_regular(can, k, (int)map.klen, &key);
+        if (regular) s = map_find(map, key, xxh3_bytes(can, k));
+        if (irregular) irregular[i] = regular ? 0 : 1;
+        if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
+        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.slots[s].id], counters[i]);
+        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+        return;
+    }
+    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
+    if (OP == OP_BF_INDEX) ((u64 *)out)[i] = idx;
+    if (OP == OP_BF_INSERT) {
+        atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
+        gate_set(bf, idx);
+    }
+    if (OP == OP_BF_TEST) ((u8 *)out)[i] = bf_bit(bf, idx);
+    if (OP == OP_BF_INC) {
+        if (bf_bit(bf, idx)) atomicAdd(&bf.counts[bf_rank(bf, idx)], counters[i]);
+    }
+    if (OP == OP_BF_GET) ((uint16_t *)out)[i] = bf.counts && bf_bit(bf, idx) ? (uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+    if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts && bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+}
+
+// KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows
+// inserted by earlier calls (ids are global insertion rows).
+__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, BFView bf,
+                                                         u32 row0, u8 *irregular)
+{
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u8 *row = rows + i * stride;
+    const int k = row_len(row, (int)stride);
+    CanonBytes<RowIn> can(RowIn{row}, k);
+    U128 key;
+    const bool regular = pack_regular(can, k, (int)map.klen, &key);
+    irregular[i] = regular ? 0 : 1;
+    if (!regular) return;
+    const u64 h = xxh3_bytes(can, k);
+    gate_set(bf, mod_size(h, bf.mod));
+    const u32 tag = map_tag(h);
+    const u64 mask = (1ULL << map.cap_log2) - 1;
+    u64 s = map_slot(map, h);
+    const u32 my_id = row0 + (u32)i;
+    bool done = false;
+    // every lane retries inside one common loop, so a lane that owns a slot in
+    // the "being written" state always finishes its publish before anyone spins on it
+    for (int guard = 0; !done && guard < (1 << 30); ++guard) {
+        u32 t = __hip_atomic_load(&map.slots[s].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) {
+            t = atomicCAS(&map.slots[s].tag, 0u, 1u);
+            if (t == 0) {
+                map.slots[s].klo = key.lo;
+                map.slots[s].khi = key.hi;
+                atomicMin(&map.slots[s].id, my_id);
+                __threadfence();
+                __hip_atomic_store(&map.slots[s].tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+                continue;
+            }
+        }
+        if (t == 1) continue; // owner is publishing: look again
+        if (t == tag) {
+            __threadfence();
+            const u64 a = __hip_atomic_load(&map.slots[s].klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 b = __hip_atomic_load(&map.slots[s].khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a == key.lo && b == key.hi) {
+                const u32 old = atomicMin(&map.slots[s].id, my_id);
+                if (old < row0) map.vals[old] = 0; // kmers[ckmer] = 0 on a key from an earlier call
+                done = true;
+                continue;
+            }
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ void __launch_bounds__(TPB) map_clear_kernel(MapSlot *slots, u64 cap)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s < cap) slots[s] = MapSlot{0u, 0xFFFFFFFFu, 0, 0, 0};
+}
+// move every published entry of an old table into a new (larger, empty) one
+__global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm)
+{
+    const u64 s0 = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s0 >= (1ULL << oldm.cap_log2)) return;
+    if (oldm.slots[s0].tag < 2) return;
+    U128 key{oldm.slots[s0].klo, oldm.slots[s0].khi};
+    const u64 h = xxh3_lform(key, (int)oldm.klen);
+    const u64 mask = (1ULL << newm.cap_log2) - 1;
+    u64 s = map_slot(newm, h);
+    while (atomicCAS(&newm.slots[s].tag, 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
+    newm.slots[s].klo = key.lo;
+    newm.slots[s].khi = key.hi;
+    newm.slots[s].id = oldm.slots[s0].id;
+}
+// gate bits of every published key (after a filter import rebuilt the gate from the bits alone)
+__global__ void __launch_bounds__(TPB) map_gate_kernel(MapView m, BFView bf)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
+    gate_set(bf, mod_size(xxh3_lform(U128{m.slots[s].klo, m.slots[s].khi}, (int)m.klen), bf.mod));
+}
+
+// list of published (key, id) for export
+__global__ void __launch_bounds__(TPB) map_dump_kernel(MapView m, u64 *klo, u64 *khi, u32 *ids, unsigned long long *count)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s >= (1ULL << m.cap_log2) || m.slots[s].tag < 2) return;
+    const unsigned long long j = atomicAdd(count, 1ULL);
+    klo[j] = m.slots[s].klo;
+    khi[j] = m.slots[s].khi;
+    ids[j] = m.slots[s].id;
+}
+
+// ---- finalize: rank directory, counters, summary ---------------------------
+
+// per 512-bit block popcount, exclusive scan inside a tile of TPB blocks
+__global__ void __launch_bounds__(TPB) blk_pop_kernel(const u64 *words, u64 nwords, u64 n_blk, u32 *blk, u32 *tile_sums)
+{
+    __shared__ u32 sh[TPB];
+    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
+    u32 pop = 0;
+    if (b < n_blk) {
+        const u64 w0 = b * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w0 + j < nwords) pop += (u32)__popcll(words[w0 + j]);
+    }
+    sh[threadIdx.x] = pop;
+    __syncthreads();
+    for (int d = 1; d < TPB; d <<= 1) {
+        const u32 v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (b < n_blk) blk[b] = sh[threadIdx.x] - pop;
+    if (threadIdx.x == TPB - 1) tile_sums[blockIdx.x] = sh[TPB - 1];
+}
+// single workgroup: exclusive scan of tile sums in place; total to *total (u64)
+__global__ void __launch_bounds__(1024) tile_scan_kernel(u32 *tile_sums, u64 n_tiles, unsigned long long *total)
+{
+    __shared__ unsigned long long sh[1024];
+    const u64 per = (n_tiles + 1023) / 1024;
+    const u64 lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    unsigned long long s = 0;
+    for (u64 i = lo; i < hi; ++i) s += tile_sums[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = sh[threadIdx.x] - s;
+    for (u64 i = lo; i < hi; ++i) {
+        const u32 v = tile_sums[i];
+        tile_sums[i] = (u32)run; // valid while the grand total fits 32 bits (checked by the host)
+        run += v;
+    }
+    if (threadIdx.x == 1023) *total = sh[1023];
+}
+__global__ void __launch_bounds__(TPB) blk_add_kernel(u32 *blk, u64 n_blk, const u32 *tile_sums, u32 total)
+{
+    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (b < n_blk) blk[b] += tile_sums[blockIdx.x];
+    if (b == n_blk) blk[b] = total; // rank(size) (bloom_filter.hpp:97)
+}
+// gate entries of every set filter bit (used when a filter is imported rather than built by inserts)
+__global__ void __launch_bounds__(TPB) gate_from_bits_kernel(BFView bf, u64 nwords)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 x = bf.words[w];
+    while (x) {
+        const int b = __ffsll((unsigned long long)x) - 1;
+        gate_set(bf, w * 64 + b);
+        x &= x - 1;
+    }
+}
+// positions of the set bits in ascending (= counter) order; needs the rank directory
+__global__ void __launch_bounds__(TPB) bit_positions_kernel(BFView bf, u64 nwords, u64 *out)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 x = bf.words[w];
+    if (!x) return;
+    u64 r = bf_rank(bf, w * 64);
+    while (x) {
+        out[r++] = w * 64 + (u64)(__ffsll((unsigned long long)x) - 1);
+        x &= x - 1;
+    }
+}
+__global__ void __launch_bounds__(TPB) set_bits_kernel(BFView bf, const u64 *pos, u64 n, u64 size, int *bad)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u64 p = pos[i];
+    if (p >= size || (i && pos[i - 1] >= p)) {
+        *bad = 1; // out of range or not strictly ascending
+        return;
+    }
+    atomicOr((unsigned long long *)&bf.words[p >> 6], 1ULL << (p & 63));
+    gate_set(bf, p);
+}
+__global__ void __launch_bounds__(TPB) mask_u16_kernel(const u32 *in, uint16_t *out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = (uint16_t)in[i];
+}
+__global__ void __launch_bounds__(TPB) widen_u16_kernel(const uint16_t *in, u32 *out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+

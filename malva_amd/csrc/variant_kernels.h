@@ -1,0 +1,472 @@
+// variant_kernels.h -- coverage reduction, likelihoods, the fused lone-variant kernel and the device-side block enumerator
+// Part of the malva_hip translation unit: included by malva_hip.hip inside its anonymous namespace, after
+// geno_dev.h (which brings xxh3_dev.h and kmer_dev.h).  See DESIGN.md section 4 for the kernels' rooflines.
+#pragma once
+
+// ---- V1: coverage reduction (main.cpp:159-181) -----------------------------------
+__global__ void __launch_bounds__(TPB) cover_kernel(const i32 *w, const u64 *sig_kmer_off, const u64 *allele_sig_off,
+                                                    u64 n_alleles, u32 *cov)
+{
+    const u64 a = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (a >= n_alleles) return;
+    u32 allele_cov = 0;
+    for (u64 s = allele_sig_off[a]; s < allele_sig_off[a + 1]; ++s) {
+        u32 curr = 0;
+        i32 n = 0;
+        for (u64 j = sig_kmer_off[s]; j < sig_kmer_off[s + 1]; ++j) {
+            const i32 wt = w[j];
+            if (wt > 0) {
+                curr = (curr * (u32)n + (u32)wt) / (u32)(n + 1);
+                ++n;
+            }
+        }
+        if (curr > allele_cov) allele_cov = curr;
+    }
+    cov[a] = (u32)(float)allele_cov; // through the float parameter of set_variant_coverage (var_block.hpp:84)
+}
+
+// ---- G1-G3 ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) genotype_kernel(const u32 *cov, const float *freq, const u32 *var_allele_off,
+                                                       u64 n_vars, GenoParams p, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
+                                                       double *probs, const u64 *var_gt_off)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    genotype_one(cov + a0, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v,
+                 probs ? probs + var_gt_off[v] : nullptr);
+}
+
+// ---- fused isolated-variant path ---------------------------------------------------
+// The signature k-mer of allele a of a lone variant (var_block.hpp:145-200 with
+// comb = {v}):  ref[pos-mp, pos) + allele + ref[pos+ref_size, +ms),
+// mp = k/2 - len/2,  ms = ceil(k/2) - (len - len/2).
+struct SigIn {
+    const u8 *ref_left;  // reference + pos - mp
+    const u8 *allele;
+    const u8 *ref_right; // reference + pos + ref_size
+    int mp, alen;
+    __device__ __forceinline__ u32 operator()(int i) const
+    {
+        return i < mp ? ref_left[i] : (i < mp + alen ? allele[i - mp] : ref_right[i - mp - alen]);
+    }
+};
+// weight of one signature k-mer given as bytes: KMAP::get_count (allele 0) or BF::get_count
+template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, int k, bool is_ref, const BFView &bf, const MapView &map)
+{
+    CanonBytes<IN> can(in, k);
+    if (is_ref) {
+        U128 key;
+        if (pack_regular(can, k, (int)map.klen, &key)) {
+            const long long s = map_find(map, key, xxh3_bytes(can, k));
+            if (s >= 0) return (i32)map.vals[map.slots[s].id];
+        }
+        return 0;
+    }
+    const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
+    return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+}
+// 2-bit code of an upper-case ACGT byte without a table: (b >> 1) & 3 gives A0 C1 G3 T2
+__device__ __forceinline__ u32 acgt_code(u32 b, bool *ok)
+{
+    *ok = b == 'A' || b == 'C' || b == 'G' || b == 'T';
+    const u32 c = (b >> 1) & 3;
+    return c ^ (c >> 1);
+}
+// n <= 32 bases starting at an arbitrary byte address -> 2-bit L-form, four bases per aligned
+// dword load.  *bad gets bit 4j set when dword j holds a byte outside ACGT (coarse on purpose:
+// a flagged span sends the allele down the exact byte-wise path).  Reads whole aligned dwords,
+// i.e. up to 3 bytes either side of the span: the reference buffer is padded for that.
+__device__ __forceinline__ void pack_span(const u8 *p, int n, u64 *codes, u64 *bad)
+{
+    const u64 addr = (u64)p;
+    const u32 *q = (const u32 *)(addr & ~3ULL);
+    const u32 sh = (u32)(addr & 3);
+    u64 c = 0, b = 0;
+    u32 prev = q[0];
+    for (int j = 0; 4 * j < n; ++j) {
+        const u32 next = q[j + 1];
+        const u32 d = sh ? __builtin_amdgcn_alignbyte(next, prev, sh) : prev;
+        u32 t = (d >> 1) & 0x03030303u; // per byte: A0 C1 G3 T2
+        t ^= (t >> 1) & 0x01010101u;    //           A0 C1 G2 T3
+        const u32 c8 = (t * 0x01041040u) >> 24;
+        const int left = n - 4 * j;
+        const u32 m = left >= 4 ? 0xFFFFFFFFu : ((1u << (8 * left)) - 1);
+        if ((expand4(c8) ^ d) & m) b |= 0xFULL << (4 * j);
+        c |= (u64)(left >= 4 ? c8 : (c8 & ((1u << (2 * left)) - 1))) << (8 * j);
+        prev = next;
+    }
+    *codes = c;
+    *bad = b;
+}
+__device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
+{
+    U128 r;
+    if (s == 0) return v;
+    if (s < 64) {
+        r.hi = (v.hi << s) | (v.lo >> (64 - s));
+        r.lo = v.lo << s;
+    } else {
+        r.hi = v.lo << (s - 64);
+        r.lo = 0;
+    }
+    return r;
+}
+// Fast path: both flanks and the allele are pure ACGT, so the signature is assembled in
+// 2-bit form from flanks packed once per variant (shared by its alleles), canonicalised
+// with integer compares and hashed with the register-resident XXH3 -- the same code the
+// scan uses.  Anything else (N / IUPAC in the window, k outside 17..64) takes weight_bytes.
+__global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference, u64 n_vars, const u64 *pos,
+                                                            const u32 *var_allele_off, const u32 *allele_off,
+                                                            const u8 *pool, const float *freq, const u64 *present_mask,
+                                                            const u8 *flags, int k, BFView bf, MapView map, GenoParams p,
+                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
+                                                            double *probs, const u64 *var_gt_off)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
+    u32 *cov = cov_out + a0;
+    for (u32 a = 0; a < A; ++a) cov[a] = 0;
+    if (flags[v] & 1) {
+        const u64 pm = present_mask[v];
+        const u8 *site = reference + pos[v];
+        const int lmax = k / 2, rmax = (k + 1) / 2;
+        const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
+        // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
+        u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
+        if (packed_ok) {
+            pack_span(site - lmax, lmax, &lf, &lbad);
+            pack_span(site + ref_size, rmax, &rf, &rbad);
+        }
+        for (u32 a = 0; a < A && a < 64; ++a) {
+            if (!((pm >> a) & 1)) continue;
+            const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
+            const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
+            if (mp < 0 || ms < 0) continue; // alleles >= k take the general path (host contract)
+            const u8 *al = pool + allele_off[a0 + a];
+            bool fast = packed_ok && (lbad >> (lmax - mp)) == 0 && (ms == 0 || (rbad & ((1ULL << ms) - 1)) == 0);
+            U128 L{0, 0};
+            if (fast) {
+                for (int i = 0; i < alen; ++i) {
+                    bool ok;
+                    const u64 code = acgt_code(al[i], &ok);
+                    fast &= ok;
+                    if (i < 32) L.lo |= code << (2 * i);
+                    else L.hi |= code << (2 * (i - 32));
+                }
+            }
+            i32 w;
+            if (fast) {
+                L = shl128(L, 2 * mp);
+                if (mp) L.lo |= lf >> (2 * (lmax - mp));                         // last mp bases of the left flank
+                if (ms) {
+                    const U128 r = shl128(U128{ms >= 32 ? rf : rf & ((1ULL << (2 * ms)) - 1), 0}, 2 * (mp + alen));
+                    L.lo |= r.lo;
+                    L.hi |= r.hi;
+                }
+                const U128 mk = mask128(2 * k);
+                const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - k)); // M-form of the k-mer
+                const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
+                const U128 key = lt128(L, rc) ? L : rc;
+                const u64 h = xxh3_packed(key, k);
+                if (a == 0) {
+                    const long long s = map_find(map, key, h);
+                    w = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+                } else {
+                    const u64 idx = mod_size(h, bf.mod);
+                    w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+                }
+            } else {
+                w = weight_bytes(SigIn{site - mp, al, site + ref_size, mp, alen}, k, a == 0, bf, map);
+            }
+            if (w > 0) cov[a] = (u32)(float)(u32)w;
+        }
+    }
+    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
+}
+
+// ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
+// VB::extract_kmers (var_block.hpp:95-219) with get_combs_on_the_right/left (:436-624), combine_combs (:630-677),
+// get_ref_subs (:682-702) and build_alleles_combs / combine_haplotypes (:709-786), fused with set_coverages
+// (main.cpp:151-184).  One workgroup per variant.  The reference builds the SET of distinct haplotype picks per
+// chain and takes, per allele, the max over signatures; a max does not care about duplicates, so here every
+// (chain, panel sample, haplotype pick) is simply evaluated and max-reduced -- thousands of redundant hashes
+// are cheaper on this machine than a device-side set.
+// Fixed capacities (chains per side, chain length, unphased fan-out): a variant that exceeds one is flagged in
+// `overflow` and its block is redone by the host enumerator + mg_lookup_cover, so results never depend on them.
+struct BlockBatch {
+    const u8 *reference;      // concatenated contigs (mg_reference_upload)
+    const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
+    const u32 *blk_ref_len;   //            and its length
+    const u32 *blk_var_off;   // [n_blocks + 1]
+    const u32 *var_block;     // [n_vars] block of each variant
+    const i32 *pos;           // 0-based position in the contig
+    const u32 *ref_size, *min_size;
+    const u8 *present;
+    const u32 *var_allele_off; // [n_vars + 1] allele slots
+    const u32 *allele_off;     // [n_slots + 1] into pool
+    const u8 *pool;
+    const u8 *canon;           // [n_slots] first allele index of the variant with the same text
+    const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14
+    u32 n_samples;
+    int haploid, k;
+};
+constexpr int BK_MAXC = 8;   // chains per side
+constexpr int BK_MAXL = 12;  // members per chain
+constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
+constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
+
+struct BkChains {
+    int n;
+    int len[BK_MAXC];
+    int sum[BK_MAXC];
+    int mem[BK_MAXC][BK_MAXL];
+};
+
+// get_combs_on_the_right (step +1) / _left (step -1); indices are batch-global variant indices inside [b0, b1)
+__device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
+{
+    const int k = B.k;
+    auto ov = [&](int x, int y) { // overlapping(left, right) with (x, y) given in scan order
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return B.pos[l] <= B.pos[r] && B.pos[r] < B.pos[l] + (int)B.ref_size[l];
+    };
+    auto nr = [&](int x, int y, int extra) {
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra + (k + 1) / 2 >= B.pos[r];
+    };
+    out->n = 0;
+    bool halt = false;
+    for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
+        if (!B.present[j]) continue;
+        if (ov(i, j)) continue;
+        const int gain = (int)B.ref_size[j] - (int)B.min_size[j];
+        if (out->n == 0) {
+            if (nr(i, j, 0)) {
+                out->mem[0][0] = j;
+                out->len[0] = 1;
+                out->sum[0] = gain;
+                out->n = 1;
+            }
+            continue;
+        }
+        bool added = false;
+        const int n0 = out->n;
+        for (int c = 0; c < n0; ++c) {
+            if (!ov(out->mem[c][out->len[c] - 1], j)) {
+                added = true;
+                if (nr(i, j, out->sum[c])) {
+                    if (out->len[c] >= BK_MAXL) return false;
+                    out->mem[c][out->len[c]++] = j;
+                    out->sum[c] += gain;
+                }
+            }
+        }
+        if (!added) {
+            for (int c = 0; c < n0; ++c) {
+                int len = out->len[c], ns = out->sum[c];
+                while (len > 0 && ov(out->mem[c][len - 1], j)) {
+                    const int m = out->mem[c][len - 1];
+                    ns -= (int)B.ref_size[m] - (int)B.min_size[m];
+                    --len;
+                }
+                if (nr(i, j, ns)) {
+                    added = true;
+                    if (out->n >= BK_MAXC || len + 1 > BK_MAXL) return false;
+                    const int d = out->n++;
+                    for (int q = 0; q < len; ++q) out->mem[d][q] = out->mem[c][q];
+                    out->mem[d][len] = j;
+                    out->len[d] = len + 1;
+                    out->sum[d] = ns + gain;
+                }
+            }
+            if (!added) halt = true;
+        }
+    }
+    return true;
+}
+
+struct LdsBytes {
+    const u8 *p;
+    __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
+};
+// weight of the k-mer in buf[0, len): packed fast path when it is k pure-ACGT bases, byte-wise otherwise
+__device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, const BFView &bf, const MapView &map)
+{
+    if (len >= 17 && len <= MG_MAX_PACKED_K) {
+        U128 L{0, 0};
+        bool ok = true;
+        for (int i = 0; i < len; ++i) {
+            bool o;
+            const u64 code = acgt_code(buf[i], &o);
+            ok &= o;
+            if (i < 32) L.lo |= code << (2 * i);
+            else L.hi |= code << (2 * (i - 32));
+        }
+        if (ok) {
+            const U128 mk = mask128(2 * len);
+            const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - len));
+            const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+            const U128 key = lt128(L, rc) ? L : rc;
+            const u64 h = xxh3_packed(key, len);
+            if (is_ref) {
+                if (len != (int)map.klen) return 0;
+                const long long s = map_find(map, key, h);
+                return s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+            }
+            const u64 idx = mod_size(h, bf.mod);
+            return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+        }
+    }
+    return weight_bytes(LdsBytes{buf}, len, is_ref, bf, map);
+}
+
+__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow)
+{
+    __shared__ BkChains sh_left, sh_right;
+    __shared__ int sh_comb[BK_MAXC * BK_MAXC][BK_MAXCOMB];
+    __shared__ int sh_comb_len[BK_MAXC * BK_MAXC], sh_comb_mid[BK_MAXC * BK_MAXC];
+    __shared__ int sh_ncomb, sh_bad;
+    __shared__ u32 sh_cov[128];
+    __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
+    __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
+    const int g = blockIdx.x;
+    if ((u64)g >= n_vars) return;
+    const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
+    const u32 blk = B.var_block[g];
+    const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
+    const u8 *ref = B.reference + B.blk_ref_base[blk];
+    const i32 ref_len = (i32)B.blk_ref_len[blk];
+    const int k = B.k;
+    for (u32 a = threadIdx.x; a < 128; a += TPB) sh_cov[a] = 0;
+    if (threadIdx.x < 4) sh_slide[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        sh_bad = 0;
+        sh_ncomb = 0;
+        const bool eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
+        if (A > 127 || k > MG_MAX_PACKED_K) sh_bad = 1;
+        else if (eligible) {
+            if (!bk_chains(B, b0, b1, g, -1, &sh_left) || !bk_chains(B, b0, b1, g, +1, &sh_right)) sh_bad = 1;
+            else { // combine_combs
+                const int nl = sh_left.n ? sh_left.n : 1, nrr = sh_right.n ? sh_right.n : 1;
+                for (int l = 0; l < nl; ++l)
+                    for (int r = 0; r < nrr; ++r) {
+                        int *comb = sh_comb[sh_ncomb];
+                        int len = 0;
+                        if (sh_left.n)
+                            for (int q = sh_left.len[l] - 1; q >= 0; --q) comb[len++] = sh_left.mem[l][q];
+                        sh_comb_mid[sh_ncomb] = len;
+                        comb[len++] = g;
+                        if (sh_right.n)
+                            for (int q = 0; q < sh_right.len[r]; ++q) comb[len++] = sh_right.mem[r][q];
+                        sh_comb_len[sh_ncomb++] = len;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (sh_bad) {
+        if (threadIdx.x == 0) overflow[g] = 1;
+        for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
+        return;
+    }
+    u8 *buf = sh_buf[threadIdx.x];
+    bool bad = false;
+    for (int c = 0; c < sh_ncomb; ++c) {
+        const int *comb = sh_comb[c];
+        const int m = sh_comb_len[c], jm = sh_comb_mid[c];
+        const int first_pos = B.pos[comb[0]];
+        const int last_end = B.pos[comb[m - 1]] + (int)B.ref_size[comb[m - 1]];
+        for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
+            bool phased = true;
+            if (!B.haploid)
+                for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
+            u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
+            if (!B.haploid && !phased && m > BK_MAXU) {
+                bad = true;
+                continue;
+            }
+            for (u32 pick = 0; pick < npick; ++pick) {
+                // allele of member j under this pick
+                auto allele_of = [&](int j) -> u32 {
+                    const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
+                    const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
+                    if (B.haploid) return a1;
+                    if (phased) return pick ? a2 : a1;
+                    return (pick >> j) & 1 ? a2 : a1;
+                };
+                // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
+                int len_v = 0, mid_pos = 0, mid_len = 0;
+                u32 mid_allele = 0;
+                for (int j = 0; j < m; ++j) {
+                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                    if (j == jm) {
+                        mid_pos = len_v;
+                        mid_len = al;
+                        mid_allele = allele_of(j);
+                    }
+                    len_v += al;
+                    if (j + 1 < m) len_v += B.pos[comb[j + 1]] - (B.pos[comb[j]] + (int)B.ref_size[comb[j]]);
+                }
+                const u32 mid_canon = B.canon[a0 + mid_allele];
+                if (m == 1 && mid_len >= k) { // the whole allele is the signature: sliding k-mers, done below
+                    atomicOr(&sh_slide[mid_canon >> 5], 1u << (mid_canon & 31));
+                    continue;
+                }
+                const int first_part = mid_pos + mid_len / 2;
+                const int mp = k / 2 - first_part;                  // missing_prefix (negative: cut)
+                const int ms = (k + 1) / 2 - (len_v - first_part);  // missing_suffix
+                if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
+                    bad = true; // the reference clips or throws here: leave it to the host path
+                    continue;
+                }
+                // W[x] = Vext[x - mp] for x in [0, k), where Vext is V with the reference continuing on both sides:
+                // a piece that covers v in [vs, vs + L) lands at x in [vs + mp, vs + L + mp), clipped to the window
+                for (int x = 0; x < mp && x < k; ++x) buf[x] = ref[first_pos - mp + x];
+                int vs = 0;
+                for (int j = 0; j < m; ++j) {
+                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                    const u8 *ap = B.pool + B.allele_off[slot];
+                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                    for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) buf[x] = ap[x - mp - vs];
+                    vs += al;
+                    if (j + 1 < m) {
+                        const int gs = B.pos[comb[j]] + (int)B.ref_size[comb[j]];
+                        const int gl = B.pos[comb[j + 1]] - gs;
+                        for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) buf[x] = ref[gs + (x - mp - vs)];
+                        vs += gl;
+                    }
+                }
+                for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
+                const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
+                if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+            }
+        }
+    }
+    if (bad) sh_bad = 1;
+    __syncthreads();
+    // sliding signatures of lone long alleles (var_block.hpp:130-144): truncating running mean over the allele's k-mers
+    for (u32 a = threadIdx.x; a < A; a += TPB) {
+        if (!((sh_slide[a >> 5] >> (a & 31)) & 1)) continue;
+        const u8 *ap = B.pool + B.allele_off[a0 + a];
+        const int al = (int)(B.allele_off[a0 + a + 1] - B.allele_off[a0 + a]);
+        u32 curr = 0;
+        i32 n = 0;
+        for (int p = 0; p + k <= al; ++p) {
+            for (int x = 0; x < k; ++x) buf[x] = ap[p + x];
+            const i32 w = bk_weight(buf, k, a == 0, bf, map);
+            if (w > 0) {
+                curr = (curr * (u32)n + (u32)w) / (u32)(n + 1);
+                ++n;
+            }
+        }
+        atomicMax(&sh_cov[a], curr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) overflow[g] = sh_bad ? 1 : 0;
+    for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
+}
+
