@@ -8,9 +8,14 @@ already resident in HBM (BASELINE.json config C3 per GPU):
     2. exchange: one sum all-reduce of the counter vector over RCCL (N > 1 only)
     3. per-variant path (main.cpp:556-559) on this rank's slice of the variants
 
-Weak scaling: every rank scans `--kmers` rows and genotypes `--variants`
-variants; the index (both filters + exact map) covers all N * variants and is
-replicated on every GPU, as SURVEY 8(e) prescribes.
+Scaling with N GPUs: the KMC table is what shards (north_star: "the KMC k-mer table
+shards naturally across the 8 GPUs ... with RCCL all-reduce of per-allele counts").
+Every rank scans `--kmers` rows of a table N times as large (weak scaling of the
+metric's unit); the panel (`--variants` SNPs) is the fixed database: its index
+(both filters + exact map) is replicated on every GPU as SURVEY 8(e) prescribes, its
+per-allele counters are all-reduced, and its genotyping is split N ways with no
+collective.  `--grow-panel` makes the panel N times as large instead (every rank then
+genotypes `--variants` SNPs and the replicated index, gate included, grows with N).
 
 Launch:  python bench.py --gpus 1            (default, single process)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -49,7 +54,9 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
-    ap.add_argument("--pack16-from", type=int, default=4, help="world size from which the counter all-reduce tries the 16-bit packed form")
+    ap.add_argument("--grow-panel", action="store_true", help="panel of N x --variants SNPs instead of a fixed one (see module docstring)")
+    ap.add_argument("--pack16-min-mb", type=float, default=32.0,
+                    help="counter vectors of at least this size try the 16-bit packed all-reduce (smaller ones: the guard costs more than it saves)")
     ap.add_argument("--scan-ablate", type=int, default=0,
                     help="profiling only (results invalid): filter-kernel ablation mask, see scan_filter_kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -79,8 +86,10 @@ def main():
 
     K, R = 35, 43
     n_rows = int(args.kmers)
-    n_vars = int(args.variants)
-    n_vars_total = n_vars * world
+    n_vars_total = int(args.variants) * (world if args.grow_panel else 1)
+    from malva_amd.dist import shard_range
+    v0, v1 = shard_range(n_vars_total, rank, world)
+    n_vars = v1 - v0                                    # variants this rank genotypes
     bf_bits = args.b << 33
 
     # ---- setup (untimed): synthetic panel, index build on the device ------------------
@@ -113,7 +122,6 @@ def main():
 
     # this rank's shard of the table and of the variants
     t0 = time.time()
-    v0, v1 = rank * n_vars, (rank + 1) * n_vars
     sub = synth.Panel(genome=panel.genome, pos=panel.pos[v0:v1], var_allele_off=(panel.var_allele_off[v0:v1 + 1] - panel.var_allele_off[v0]),
                       allele_off=panel.allele_off[2 * v0:2 * v1 + 1] - panel.allele_off[2 * v0], pool=panel.pool[2 * v0:2 * v1],
                       freq=panel.freq[2 * v0:2 * v1], present_mask=panel.present_mask[v0:v1], flags=panel.flags[v0:v1],
@@ -152,9 +160,8 @@ def main():
         ctx.counters_reset()
         ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
         if world > 1:
-            # from 4 ranks up the vector (8 MB per rank's variants) is worth halving on the wire; below that the
-            # guard's extra round trip costs more than it saves
-            if world >= args.pack16_from:
+            # a large vector is worth halving on the wire; for a small one the guard's extra round trip costs more
+            if 4.0 * d_counters.numel() >= args.pack16_min_mb * (1 << 20):
                 packed_steps.append(allreduce_counters_packed_(d_counters))
             else:
                 allreduce_counters_(d_counters)
@@ -263,7 +270,7 @@ def main():
             traffic = t["hbm_bytes_per_launch"]
     if rank == 0:
         total_kmers = n_rows * world * args.steps
-        total_vars = n_vars * world * args.steps
+        total_vars = n_vars_total * args.steps
         rows_per_launch = min(n_rows, 1 << 27)      # mg_kmc_scan_device walks the table in chunks of 2^27 rows; the first is timed
         achieved = SCAN_BYTES_PER_KMER * rows_per_launch / (filt_ms * 1e-3) / 1e9
         out = {
@@ -280,9 +287,11 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "C3 per GPU: %.3g KMC k-mers + %.3g isolated biallelic SNPs, k=35 r=43 b=%d, table resident in HBM"
-                                   % (n_rows, n_vars, args.b),
-                       "kmers_per_gpu": n_rows, "variants_per_gpu": n_vars, "bf_bits": bf_bits, "parallelism": "table rows x%d, variants x%d" % (world, world),
+            "config": {"workload": "C3%s: %.3g KMC k-mers per GPU (table of %.3g rows sharded by rows) against a panel of %.3g isolated biallelic SNPs, "
+                                   "k=35 r=43 b=%d, table resident in HBM" % (" per GPU" if args.grow_panel or world == 1 else " table x N, fixed panel",
+                                                                               n_rows, n_rows * world, n_vars_total, args.b),
+                       "kmers_per_gpu": n_rows, "kmers_total": n_rows * world, "panel_variants": n_vars_total, "variants_genotyped_per_gpu": n_vars,
+                       "bf_bits": bf_bits, "parallelism": "table rows x%d (weak), panel genotyping split x%d, index replicated" % (world, world),
                        "summary_bitmaps": not args.no_summary,
                        "exchange": ("none" if world == 1 else "all_reduce(sum,int32) over %d counters, in place%s" % (
                            n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
