@@ -133,12 +133,21 @@ class Context:
         self.k, self.ref_k, self.bf_bits = k, ref_k, bf_bits
 
     def close(self):
-        if getattr(self, "h", None):
-            self._L.mg_destroy(self.h)
-            self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self._L.mg_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
 
     def _ck(self, rc):
         if rc != 0:
