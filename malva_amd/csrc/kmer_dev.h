@@ -161,25 +161,38 @@ struct BFView {
     // ref_bf.increment can do anything, so ~97 % of table rows finish after one
     // L2-resident probe.  Only the `bf` view carries it.
     u64 *gate;
+    // When the index is too large for the gate to stay in L2 (> 4 MiB), a second, coarse gate of the L2-resident
+    // size sits in front of it: same construction over the same idx, fewer bits per entry.  Only rows that pass
+    // the coarse gate pay the (HBM / Infinity Cache) line of the fine one.
+    u64 *pregate;
     ModDesc mod;
     u32 gate_shift;
     u32 gate_k;   // bits per entry, 1..4
+    u32 pre_shift;
+    u32 pre_k;
     u32 use_gate;
 };
 __device__ __forceinline__ bool bf_bit(const BFView &b, u64 idx) { return (b.words[idx >> 6] >> (idx & 63)) & 1; }
-__device__ __forceinline__ u64 gate_word(const BFView &b, u64 idx) { return idx >> (b.gate_shift + 6); }
-__device__ __forceinline__ u64 gate_mask(const BFView &b, u64 idx)
+__device__ __forceinline__ u64 gate_mask_sk(u64 idx, u32 shift, u32 k)
 {
-    u64 m = 1ULL << ((idx >> b.gate_shift) & 63);
-    const u32 t = (u32)(idx & ((1ULL << b.gate_shift) - 1));
-    if (b.gate_k > 1) m |= 1ULL << ((t * 0x9E3779B1u) >> 26);
-    if (b.gate_k > 2) m |= 1ULL << ((t * 0x85EBCA77u) >> 26);
-    if (b.gate_k > 3) m |= 1ULL << ((t * 0xC2B2AE3Du) >> 26);
+    u64 m = 1ULL << ((idx >> shift) & 63);
+    const u32 t = (u32)(idx & ((1ULL << shift) - 1));
+    if (k > 1) m |= 1ULL << ((t * 0x9E3779B1u) >> 26);
+    if (k > 2) m |= 1ULL << ((t * 0x85EBCA77u) >> 26);
+    if (k > 3) m |= 1ULL << ((t * 0xC2B2AE3Du) >> 26);
     return m;
 }
+__device__ __forceinline__ u64 gate_word(const BFView &b, u64 idx) { return idx >> (b.gate_shift + 6); }
+__device__ __forceinline__ u64 gate_mask(const BFView &b, u64 idx) { return gate_mask_sk(idx, b.gate_shift, b.gate_k); }
+__device__ __forceinline__ u64 pre_word(const BFView &b, u64 idx) { return idx >> (b.pre_shift + 6); }
+__device__ __forceinline__ u64 pre_mask(const BFView &b, u64 idx) { return gate_mask_sk(idx, b.pre_shift, b.pre_k); }
 __device__ __forceinline__ bool gate_open(const BFView &b, u64 idx)
 {
     if (!b.use_gate) return true;
+    if (b.pregate) {
+        const u64 pm = pre_mask(b, idx);
+        if ((b.pregate[pre_word(b, idx)] & pm) != pm) return false;
+    }
     const u64 m = gate_mask(b, idx);
     return (b.gate[gate_word(b, idx)] & m) == m;
 }
@@ -187,6 +200,7 @@ __device__ __forceinline__ void gate_set(const BFView &b, u64 idx)
 {
     if (!b.gate) return;
     atomicOr((unsigned long long *)&b.gate[gate_word(b, idx)], gate_mask(b, idx));
+    if (b.pregate) atomicOr((unsigned long long *)&b.pregate[pre_word(b, idx)], pre_mask(b, idx));
 }
 // rank(idx) = ones in [0, idx)   (rank_support_v<1>, bloom_filter.hpp:108)
 __device__ __forceinline__ u32 bf_rank(const BFView &b, u64 idx)

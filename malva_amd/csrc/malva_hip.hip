@@ -45,6 +45,8 @@ struct BFState {
     u64 *gate = nullptr; // only `bf` (MG_BF_ALT) owns one
     u64 n_gate_bits = 0;
     u32 gate_shift = 6;
+    u64 *pregate = nullptr; // coarse L2-sized gate in front of a gate that outgrew L2
+    u32 pre_shift = 6;
     int mode = 0;
     ModDesc mod{};
 };
@@ -84,6 +86,8 @@ struct mg_ctx {
     int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
     int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
+    int pre_k = 1;      // bits per entry of the coarse gate (chosen at finalize from the load)
+    int use_pregate = 1;
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
     int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
     std::string err;
@@ -166,6 +170,9 @@ BFView view(const mg_ctx *c, int which)
     v.mod = b.mod;
     v.gate_shift = b.gate_shift;
     v.gate_k = (u32)c->gate_k;
+    v.pregate = c->use_pregate ? b.pregate : nullptr;
+    v.pre_shift = b.pre_shift;
+    v.pre_k = (u32)c->pre_k;
     v.use_gate = (c->use_summary && b.gate) ? 1 : 0;
     return v;
 }
@@ -199,6 +206,8 @@ int unjoin(mg_ctx *c)
     return MG_OK;
 }
 
+constexpr int PREGATE_LOG2 = 25; // 4 MiB: what stays resident in an XCD's L2 next to the table stream
+
 // (re)allocate the gate of `bf`: at most 2^gate_log2 bits, one per 2^gate_shift filter bits
 int alloc_gate(mg_ctx *c)
 {
@@ -212,6 +221,16 @@ int alloc_gate(mg_ctx *c)
     const size_t bytes = ((b.n_gate_bits + 63) / 64) * 8;
     HIP_TRY(c, hipMalloc(&b.gate, bytes));
     HIP_TRY(c, hipMemsetAsync(b.gate, 0, bytes, c->stream));
+    if (b.pregate) HIP_TRY(c, hipFree(b.pregate));
+    b.pregate = nullptr;
+    if (c->gate_log2 > PREGATE_LOG2) { // the gate no longer fits L2: coarse gate of the L2-resident size in front of it
+        u32 S1 = 6;
+        while (((b.size + (1ULL << S1) - 1) >> S1) > (1ULL << PREGATE_LOG2)) ++S1;
+        b.pre_shift = S1;
+        const size_t pbytes = ((((b.size + (1ULL << S1) - 1) >> S1) + 63) / 64) * 8;
+        HIP_TRY(c, hipMalloc(&b.pregate, pbytes));
+        HIP_TRY(c, hipMemsetAsync(b.pregate, 0, pbytes, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }
@@ -418,6 +437,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
         hipFree(b.blk);
         hipFree(b.counts);
         hipFree(b.gate);
+        hipFree(b.pregate);
     }
     map_free_table(c->map);
     hipFree(c->map.vals);
@@ -457,6 +477,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
+    else if (!strcmp(name, "use_pregate")) c->use_pregate = value != 0;
     else if (!strcmp(name, "scan_variant")) c->scan_variant = (int)value & 3;
     else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 8192;
     else if (!strcmp(name, "gate_log2") || !strcmp(name, "gate_k")) {
@@ -539,8 +560,12 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
         int want = 25;
         while (want < 34 && (1ULL << want) < 12 * entries) ++want;
         while (want > 6 && (1ULL << want) > b.size) --want;
-        if (want != c->gate_log2) {
+        // coarse gate: the bits per entry that minimise its false-positive rate at this load (ln 2 * bits / entries)
+        int pk = entries ? (int)std::lround(0.6931 * (double)(1ULL << PREGATE_LOG2) / (double)entries) : 4;
+        pk = pk < 1 ? 1 : pk > 4 ? 4 : pk;
+        if (want != c->gate_log2 || (want > PREGATE_LOG2 && pk != c->pre_k)) {
             c->gate_log2 = want;
+            c->pre_k = pk;
             TRY(alloc_gate(c));
             hipLaunchKernelGGL(gate_from_bits_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), b.nwords);
             if (c->map.slots)

@@ -160,7 +160,8 @@ template <int WCAP> struct WaveStage {
 // one phase are all in flight together:
 //   A  load ROWS x (hi, lo, cnt)            -- coalesced, non-temporal: the only HBM stream
 //   B  canonicalise, XXH3, slot             -- pure VALU
-//   C  load ROWS gate words                 -- random 8-byte loads from a 4 MiB bitmap (L2)
+//   C  load ROWS gate words                 -- random 8-byte loads from a 4 MiB bitmap (L2): the gate, or the
+//                                              coarse gate in front of it when the index is large
 //   D  test, stage open rows
 // `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
 // 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
@@ -223,11 +224,22 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) // C
-            gate[j] = (ablate & 1) ? 0ULL : bf.use_gate ? bf.gate[gate_word(bf, idx[j])] : ~0ULL;
+            gate[j] = (ablate & 1) ? 0ULL : !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // D
-            const u64 gm = gate_mask(bf, idx[j]);
-            const bool open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
+            bool open_j;
+            if (bf.pregate && bf.use_gate) { // coarse gate first; the fine gate's line only for the rows that pass it
+                const u64 pm = pre_mask(bf, idx[j]);
+                open_j = valid[j] && (gate[j] & pm) == pm;
+                if (open_j) {
+                    const u64 gm = gate_mask(bf, idx[j]);
+                    open_j = (bf.gate[gate_word(bf, idx[j])] & gm) == gm;
+                }
+                open_j = open_j && !(ablate & 2);
+            } else {
+                const u64 gm = gate_mask(bf, idx[j]);
+                open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
+            }
             if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
             if (WAVE) ws.push(open_j, m[j], count[j], open, &counters[0]);
             else st.push(open_j, m[j], count[j]);
