@@ -225,24 +225,26 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) // C
             gate[j] = (ablate & 1) ? 0ULL : !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
+        bool open_j[ROWS];
+        if (bf.pregate && bf.use_gate) { // coarse gate first; the fine gate's line only for the rows that pass it,
+#pragma unroll                           // and all of those loads in flight together
+            for (int j = 0; j < ROWS; ++j) {
+                const u64 pm = pre_mask(bf, idx[j]);
+                open_j[j] = valid[j] && (gate[j] & pm) == pm;
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) gate[j] = open_j[j] ? bf.gate[gate_word(bf, idx[j])] : 0ULL;
+        } else {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) open_j[j] = valid[j];
+        }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // D
-            bool open_j;
-            if (bf.pregate && bf.use_gate) { // coarse gate first; the fine gate's line only for the rows that pass it
-                const u64 pm = pre_mask(bf, idx[j]);
-                open_j = valid[j] && (gate[j] & pm) == pm;
-                if (open_j) {
-                    const u64 gm = gate_mask(bf, idx[j]);
-                    open_j = (bf.gate[gate_word(bf, idx[j])] & gm) == gm;
-                }
-                open_j = open_j && !(ablate & 2);
-            } else {
-                const u64 gm = gate_mask(bf, idx[j]);
-                open_j = valid[j] && !(ablate & 2) && (gate[j] & gm) == gm;
-            }
+            const u64 gm = gate_mask(bf, idx[j]);
+            const bool take = open_j[j] && !(ablate & 2) && (gate[j] & gm) == gm;
             if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
-            if (WAVE) ws.push(open_j, m[j], count[j], open, &counters[0]);
-            else st.push(open_j, m[j], count[j]);
+            if (WAVE) ws.push(take, m[j], count[j], open, &counters[0]);
+            else st.push(take, m[j], count[j]);
         }
         if (!WAVE) st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
     }
