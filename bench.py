@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--grow-panel", action="store_true", help="panel of N x --variants SNPs instead of a fixed one (see module docstring)")
     ap.add_argument("--pack16-min-mb", type=float, default=32.0,
                     help="counter vectors of at least this size try the 16-bit packed all-reduce (smaller ones: the guard costs more than it saves)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: mg_set_option before the index is built (use_partition=0, gate_log2=26, ...)")
     ap.add_argument("--scan-ablate", type=int, default=0,
                     help="profiling only (results invalid): filter-kernel ablation mask, see scan_filter_kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -102,6 +104,9 @@ def main():
         ctx.set_option("use_summary", 0)
     if args.scan_ablate:
         ctx.set_option("scan_ablate", args.scan_ablate)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        ctx.set_option(name, int(value))
     t0 = time.time()
     sig, _ = synth.snp_signature_rows(panel, K)
     stride = 40
@@ -295,7 +300,8 @@ def main():
                        "summary_bitmaps": not args.no_summary,
                        "exchange": ("none" if world == 1 else "all_reduce(sum,int32) over %d counters, in place%s" % (
                            n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
-            "roofline": {"kernel": "scan_filter_kernel<35,43,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": ("scan_bin_kernel<35,43,4> + scan_bin_gate_kernel<35,43> (partitioned second level, %d slices)" % ctx.get_option("scan_bins")
+                                    if ctx.get_option("scan_bins") else "scan_filter_kernel<35,43,2>"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": rows_per_launch, "avg_launch_ms": filt_ms},

@@ -75,6 +75,7 @@ def lib():
         "mg_debug_packed_index": [vp, it, vp, vp, sz, u32, vp],
         "mg_scan_stats": [vp, vp, vp],
         "mg_set_option": [vp, cp, i64],
+        "mg_get_option": [vp, cp, C.POINTER(C.c_int64)],
     }
     for name, args in sig.items():
         f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
@@ -92,7 +93,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_lookup_cover", "mg_cover_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
-            "mg_debug_packed_index", "mg_scan_stats", "mg_set_option"]
+            "mg_debug_packed_index", "mg_scan_stats", "mg_set_option", "mg_get_option"]
 
 
 def _p(a):
@@ -162,6 +163,11 @@ class Context:
 
     def set_option(self, name, value):
         self._ck(self._L.mg_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._ck(self._L.mg_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     # BF
     def bf_insert(self, which, rows):

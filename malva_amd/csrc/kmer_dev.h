@@ -68,10 +68,13 @@ struct U128 {
     u64 lo, hi;
 };
 
+// order of the 32 two-bit codes reversed: bit reversal (v_bfrev_b32 per half), then the two bits of every code
+// swapped back, per 32-bit half so that it is two shifts and one v_bfi_b32 each
+__device__ __forceinline__ u32 pairswap32(u32 v) { return ((v >> 1) & 0x55555555u) | ((v << 1) & ~0x55555555u); }
 __device__ __forceinline__ u64 pairrev64(u64 x)
 {
-    const u64 r = __brevll(x);
-    return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+    const u32 lo = pairswap32(__brev((u32)(x >> 32))), hi = pairswap32(__brev((u32)x));
+    return (u64)lo | ((u64)hi << 32);
 }
 __device__ __forceinline__ U128 shr128(U128 v, int s) // 0 <= s < 128
 {
@@ -126,6 +129,12 @@ template <int LEN> __device__ __forceinline__ u64 xxh3_packed_k(U128 c, int len_
     if constexpr (LEN >= 33 && LEN <= 64) return xxh3_packed_fixed<LEN>(c.lo, c.hi);
     else return xxh3_packed(c, len_rt);
 }
+// the same with the ASCII table of ascii_lut_fill in LDS (used where LEN is fixed; ignored otherwise)
+template <int LEN> __device__ __forceinline__ u64 xxh3_packed_k(U128 c, int len_rt, const u32 *lut)
+{
+    if constexpr (LEN >= 33 && LEN <= 64) return xxh3_packed_fixed<LEN, true>(c.lo, c.hi, lut);
+    else return xxh3_packed(c, len_rt);
+}
 
 // ---- hash -> bit index (hash % _size, bloom_filter.hpp:84) --------------------
 // size = odd * 2^shift.  x mod size = ((x >> shift) mod odd) << shift | (x & (2^shift - 1)).
@@ -173,13 +182,22 @@ struct BFView {
     u32 use_gate;
 };
 __device__ __forceinline__ bool bf_bit(const BFView &b, u64 idx) { return (b.words[idx >> 6] >> (idx & 63)) & 1; }
+// low 32 bits of the product of the low 24 bits of a and c (full rate; the compiler keeps v_mul_lo_u32 for
+// __umul24 when it cannot see the operand's width)
+__device__ __forceinline__ u32 mul24(u32 a, u32 c)
+{
+    u32 r;
+    asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "s"(c), "v"(a));
+    return r;
+}
 __device__ __forceinline__ u64 gate_mask_sk(u64 idx, u32 shift, u32 k)
 {
     u64 m = 1ULL << ((idx >> shift) & 63);
-    const u32 t = (u32)(idx & ((1ULL << shift) - 1));
-    if (k > 1) m |= 1ULL << ((t * 0x9E3779B1u) >> 26);
-    if (k > 2) m |= 1ULL << ((t * 0x85EBCA77u) >> 26);
-    if (k > 3) m |= 1ULL << ((t * 0xC2B2AE3Du) >> 26);
+    // the other positions: bits 26..31 of 24-bit products (v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter)
+    const u32 t = (u32)idx & (u32)((1ULL << (shift < 24 ? shift : 24)) - 1);
+    if (k > 1) m |= 1ULL << (mul24(t, 0x9E3779u) >> 26);
+    if (k > 2) m |= 1ULL << (mul24(t, 0xEBCA77u) >> 26);
+    if (k > 3) m |= 1ULL << (mul24(t, 0xB2AE3Du) >> 26);
     return m;
 }
 __device__ __forceinline__ u64 gate_word(const BFView &b, u64 idx) { return idx >> (b.gate_shift + 6); }

@@ -25,6 +25,7 @@ using namespace mg;
 
 namespace {
 
+constexpr int BIN_SEGS = 2048; // workgroups of the binning kernel = segments per bin
 constexpr int TPB = 256;
 
 #include "store_kernels.h"
@@ -88,6 +89,13 @@ struct mg_ctx {
     int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
     int pre_k = 1;      // bits per entry of the coarse gate (chosen at finalize from the load)
     int use_pregate = 1;
+    int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
+    int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
+    int bin_ring = 0, bin_rows = 4; // A/B: staging ring per bin (0 = as large as LDS allows), rows per thread of the binning kernel
+    u64 bin_cap = 0;       // rows per bin segment; 0 = 1.5x an even share of the chunk (tests set it small to reach the spill path)
+    int last_bins = 0;     // bins used by the most recent scan (0: direct form)
+    Scratch s_bin[3], s_spill[3];
+    unsigned long long *d_bin_meta = nullptr; // spill count, then u32 [BIN_MAXP][BIN_SEGS] segment fills
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
     int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
     std::string err;
@@ -206,8 +214,6 @@ int unjoin(mg_ctx *c)
     return MG_OK;
 }
 
-constexpr int PREGATE_LOG2 = 25; // 4 MiB: what stays resident in an XCD's L2 next to the table stream
-
 // (re)allocate the gate of `bf`: at most 2^gate_log2 bits, one per 2^gate_shift filter bits
 int alloc_gate(mg_ctx *c)
 {
@@ -223,9 +229,9 @@ int alloc_gate(mg_ctx *c)
     HIP_TRY(c, hipMemsetAsync(b.gate, 0, bytes, c->stream));
     if (b.pregate) HIP_TRY(c, hipFree(b.pregate));
     b.pregate = nullptr;
-    if (c->gate_log2 > PREGATE_LOG2) { // the gate no longer fits L2: coarse gate of the L2-resident size in front of it
+    if (c->gate_log2 > c->pregate_log2) { // the gate no longer fits L2: coarse gate of the L2-resident size in front of it
         u32 S1 = 6;
-        while (((b.size + (1ULL << S1) - 1) >> S1) > (1ULL << PREGATE_LOG2)) ++S1;
+        while (((b.size + (1ULL << S1) - 1) >> S1) > (1ULL << c->pregate_log2)) ++S1;
         b.pre_shift = S1;
         const size_t pbytes = ((((b.size + (1ULL << S1) - 1) >> S1) + 63) / 64) * 8;
         HIP_TRY(c, hipMalloc(&b.pregate, pbytes));
@@ -443,6 +449,9 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipFree(c->map.vals);
     for (Scratch *s : {&c->s_rows, &c->s_aux, &c->s_out, &c->s_irr}) hipFree(s->p);
     for (auto &s : c->s_open) hipFree(s.p);
+    for (auto &s : c->s_bin) hipFree(s.p);
+    for (auto &s : c->s_spill) hipFree(s.p);
+    hipFree(c->d_bin_meta);
     for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
     hipFree(c->d_hit_count);
@@ -478,7 +487,20 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value != 0;
-    else if (!strcmp(name, "scan_variant")) c->scan_variant = (int)value & 3;
+    else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
+    else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
+    else if (!strcmp(name, "scan_bin_ring")) {
+        if (value != 0 && value != 64 && value != 128 && value != 256) return fail(c, MG_ERR_ARG, "scan_bin_ring must be 0, 64, 128 or 256");
+        c->bin_ring = (int)value;
+    }
+    else if (!strcmp(name, "scan_bin_rows")) c->bin_rows = value == 2 ? 2 : 4;
+    else if (!strcmp(name, "pregate_log2")) {
+        if (c->map.rows_total || c->gate_dirty) return fail(c, MG_ERR_STATE, "pregate_log2 must be set before the first insert");
+        if (value < 8 || value > 30) return fail(c, MG_ERR_ARG, "pregate_log2 must be 8..30");
+        c->pregate_log2 = (int)value;
+        return alloc_gate(c);
+    }
+    else if (!strcmp(name, "scan_variant")) c->scan_variant = (int)value & 2;
     else if (!strcmp(name, "scan_grid")) c->scan_grid = value > 0 ? (int)value : 8192;
     else if (!strcmp(name, "gate_log2") || !strcmp(name, "gate_k")) {
         if (c->map.rows_total || c->gate_dirty) return fail(c, MG_ERR_STATE, "%s must be set before the first insert", name);
@@ -490,6 +512,29 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
             c->gate_fixed = true;
         }
         return alloc_gate(c);
+    }
+    else return fail(c, MG_ERR_ARG, "unknown option %s", name);
+    return MG_OK;
+}
+
+MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
+{
+    if (!c || !name || !value) return MG_ERR_ARG;
+    if (!strcmp(name, "use_summary")) *value = c->use_summary;
+    else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
+    else if (!strcmp(name, "use_partition")) *value = c->use_partition;
+    else if (!strcmp(name, "gate_log2")) *value = c->gate_log2;
+    else if (!strcmp(name, "gate_k")) *value = c->gate_k;
+    else if (!strcmp(name, "pregate_log2")) *value = c->pregate_log2;
+    else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate ? c->pre_k : 0;
+    else if (!strcmp(name, "scan_bins")) *value = c->last_bins;
+    else if (!strcmp(name, "scan_spilled")) { // rows of the last chunk that took the spill list
+        unsigned long long t = 0;
+        if (c->last_bins) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(&t, c->d_bin_meta, 8, hipMemcpyDeviceToHost));
+        }
+        *value = (int64_t)t;
     }
     else return fail(c, MG_ERR_ARG, "unknown option %s", name);
     return MG_OK;
@@ -561,9 +606,9 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
         while (want < 34 && (1ULL << want) < 12 * entries) ++want;
         while (want > 6 && (1ULL << want) > b.size) --want;
         // coarse gate: the bits per entry that minimise its false-positive rate at this load (ln 2 * bits / entries)
-        int pk = entries ? (int)std::lround(0.6931 * (double)(1ULL << PREGATE_LOG2) / (double)entries) : 4;
+        int pk = entries ? (int)std::lround(0.6931 * (double)(1ULL << c->pregate_log2) / (double)entries) : 4;
         pk = pk < 1 ? 1 : pk > 4 ? 4 : pk;
-        if (want != c->gate_log2 || (want > PREGATE_LOG2 && pk != c->pre_k)) {
+        if (want != c->gate_log2 || (want > c->pregate_log2 && pk != c->pre_k)) {
             c->gate_log2 = want;
             c->pre_k = pk;
             TRY(alloc_gate(c));
@@ -768,22 +813,34 @@ void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *
 {
     // 16-byte loads need 16-byte aligned table bases (chunk offsets are multiples of 2^27 rows, so only the caller's bases matter)
     const bool vec_ok = ROWS == 2 && ((((uintptr_t)d_hi | (uintptr_t)d_lo) & 15) == 0) && (((uintptr_t)d_cnt & 7) == 0);
-    switch ((c->scan_variant & 1) | ((c->scan_variant & 2) && vec_ok ? 2 : 0)) {
-    case 1: launch_filter_var<KC, RC, ROWS, 1>(c, d_hi, d_lo, d_cnt, n, open); break;
+    switch ((c->scan_variant & 2) && vec_ok ? 2 : 0) {
     case 2: launch_filter_var<KC, RC, ROWS, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
-    case 3: launch_filter_var<KC, RC, ROWS, 3>(c, d_hi, d_lo, d_cnt, n, open); break;
     default: launch_filter_var<KC, RC, ROWS, 0>(c, d_hi, d_lo, d_cnt, n, open); break;
     }
 }
 template <int KC, int RC>
-void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed)
+void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed,
+                       const BinSet *bins)
 {
     if (timed) hipEventRecord(c->ev[0], c->stream);
-    switch (c->scan_rows) {
-    case 1: launch_filter_rows<KC, RC, 1>(c, d_hi, d_lo, d_cnt, n, open); break;
-    case 4: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, d_cnt, n, open); break;
-    default: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
-    }
+    if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
+        BinSet bs = *bins; // the last chunk may need fewer workgroups than segments were laid out for
+        bs.nseg = (u32)std::min<u64>((n + 2 * TPB - 1) / (2 * TPB), bins->nseg);
+        bins = &bs;
+        if (c->bin_rows == 4)
+            hipLaunchKernelGGL((scan_bin_kernel<KC, RC, 4>), dim3(bs.nseg), dim3(TPB), (size_t)bs.nbins * bs.ring * 20, c->stream, d_hi, d_lo, d_cnt, n,
+                               (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), *bins, c->scan_ablate);
+        else
+            hipLaunchKernelGGL((scan_bin_kernel<KC, RC, 2>), dim3(bs.nseg), dim3(TPB), (size_t)bs.nbins * bs.ring * 20, c->stream, d_hi, d_lo, d_cnt, n,
+                               (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), *bins, c->scan_ablate);
+        hipLaunchKernelGGL((scan_bin_gate_kernel<KC, RC>), dim3(2048), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
+                           *bins, open, c->d_hit_count);
+    } else
+        switch (c->scan_rows) {
+        case 1: launch_filter_rows<KC, RC, 1>(c, d_hi, d_lo, d_cnt, n, open); break;
+        case 4: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, d_cnt, n, open); break;
+        default: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
+        }
     if (timed) hipEventRecord(c->ev[1], c->stream);
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 2048u);
@@ -813,16 +870,42 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
     const bool d35_43 = c->k == 35 && c->ref_k == 43;
     c->stats_valid = false;
+    // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
+    BinSet bins{};
+    const BFState &alt = c->bf[MG_BF_ALT];
+    const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6);
+    const u64 P = alt.pregate ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
+    const bool partition = c->use_summary && c->use_pregate && c->use_partition && P >= 2 && P <= BIN_MAXP;
+    if (partition) {
+        bins.nbins = (u32)P;
+        bins.word_shift = word_shift;
+        bins.nseg = (u32)std::min<u64>((cap + 2 * TPB - 1) / (2 * TPB), BIN_SEGS);
+        // 1.5x an even share of the worst case (every row passes the coarse gate)
+        bins.segcap = c->bin_cap ? c->bin_cap : ((cap / P / bins.nseg) * 3 / 2 + 256 + 63) / 64 * 64; // line-aligned segments
+        bins.ring = 64;
+        while (bins.ring < 256 && bins.ring * 2 * P <= BIN_LDS_ROWS) bins.ring *= 2;
+        if (c->bin_ring && (u64)c->bin_ring * P <= BIN_LDS_ROWS) bins.ring = (u32)c->bin_ring;
+        void *q[6];
+        for (int i = 0; i < 3; ++i) TRY(scratch(c, c->s_bin[i], P * bins.nseg * bins.segcap * (i == 2 ? 4 : 8), &q[i]));
+        for (int i = 0; i < 3; ++i) TRY(scratch(c, c->s_spill[i], cap * (i == 2 ? 4 : 8), &q[3 + i]));
+        bins.rows = RowList{(u64 *)q[0], (u64 *)q[1], (u32 *)q[2]};
+        bins.spill = RowList{(u64 *)q[3], (u64 *)q[4], (u32 *)q[5]};
+        if (!c->d_bin_meta) HIP_TRY(c, hipMalloc(&c->d_bin_meta, 8 + (size_t)BIN_MAXP * BIN_SEGS * 4));
+        bins.spill_count = c->d_bin_meta;
+        bins.counts = (u32 *)(c->d_bin_meta + 1);
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
     for (u64 r0 = 0; r0 < n; r0 += chunk) {
         const u64 nr = n - r0 < chunk ? n - r0 : chunk;
         const u64 *ph = (const u64 *)d_hi + r0, *pl = (const u64 *)d_lo + r0;
         const u32 *pc = (const u32 *)d_cnt + r0;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
-        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0);
-        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0);
+        if (partition) HIP_TRY(c, hipMemsetAsync(c->d_bin_meta, 0, 8, c->stream));
+        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
+        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
+    c->last_bins = partition ? (int)P : 0;
     c->stats_valid = true;
     return MG_OK;
 }

@@ -116,47 +116,9 @@ template <int CAP> struct BlockStage {
     }
 };
 
-// The same per wave (no workgroup barrier anywhere): the four waves of a workgroup then never
-// wait for each other, which matters in the filter kernel where the barrier pair per iteration
-// made every wave run at the pace of the slowest.
-template <int WCAP> struct WaveStage {
-    u64 *hi, *lo; // this wave's [WCAP] slices
-    u32 *cnt;
-    int staged;   // wave-uniform
-    __device__ __forceinline__ void flush(const RowList &g, unsigned long long *g_count)
-    {
-        const int lane = threadIdx.x & 63;
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(g_count, (unsigned long long)staged);
-        b = __shfl(b, 0, 64);
-        for (int j = lane; j < staged; j += 64) {
-            g.hi[b + j] = hi[j];
-            g.lo[b + j] = lo[j];
-            g.cnt[b + j] = cnt[j];
-        }
-        staged = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // every lane of the wave must call this (it ballots)
-    __device__ __forceinline__ void push(bool take, U128 m, u32 count, const RowList &g, unsigned long long *g_count)
-    {
-        const u64 mask = __ballot(take);
-        if (!mask) return;
-        if (take) {
-            const int q = staged + __popcll(mask & ((1ULL << (threadIdx.x & 63)) - 1));
-            lo[q] = m.lo;
-            hi[q] = m.hi;
-            cnt[q] = count;
-        }
-        staged += __popcll(mask);
-        __builtin_amdgcn_wave_barrier();
-        if (staged > WCAP - 64) flush(g, g_count);
-    }
-};
-
 // counters[0] = open rows, [1] = hit rows of the current chunk, [2] = hit rows of the whole call
 //
-// ROWS table rows per thread and iteration, in phases so that the memory operations of
+// ROWS table rows per thread and tile, in phases so that the memory operations of
 // one phase are all in flight together:
 //   A  load ROWS x (hi, lo, cnt)            -- coalesced, non-temporal: the only HBM stream
 //   B  canonicalise, XXH3, slot             -- pure VALU
@@ -165,94 +127,294 @@ template <int WCAP> struct WaveStage {
 //   D  test, stage open rows
 // `ablate` is a timing-only diagnostic (results are wrong when it is non-zero):
 // 1 = no gate load, 2 = gate load but nothing passes, 4 = no XXH3, 8 = no canonicalisation.
-// VAR bit 0: per-wave staging (no barriers) instead of per-workgroup; bit 1 (ROWS == 2 only): each
-// thread takes two ADJACENT rows with 16-byte loads instead of two rows TPB apart with 8-byte loads.
+// VAR bit 1 (ROWS == 2 only): each thread takes two ADJACENT rows with 16-byte loads instead of two rows TPB
+// apart with 8-byte loads (measured 4 % faster).  Per-wave staging without barriers was tried as VAR bit 0 and
+// was 10 % slower (four times the flush atomics).
 template <int KC, int RC, int ROWS, int VAR>
 __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
                                                           const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt, BFView bf,
                                                           RowList open, unsigned long long *counters, int ablate)
 {
-    constexpr bool WAVE = VAR & 1, VEC = (VAR & 2) && ROWS == 2;
-    constexpr int CAP = WAVE ? (TPB / 64) * 192 : TPB * ROWS + 256;
+    constexpr bool VEC = (VAR & 2) && ROWS == 2;
+    constexpr int CAP = TPB * ROWS + 256;
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
     __shared__ u32 sh_cnt[CAP];
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
     BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
-    const int wv = threadIdx.x >> 6;
-    WaveStage<192> ws{sh_hi + wv * 192, sh_lo + wv * 192, sh_cnt + wv * 192, 0};
-    if (!WAVE) {
-        if (threadIdx.x == 0) sh_n = 0;
-        __syncthreads();
-    }
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
-    const u64 step = (u64)gridDim.x * TPB * ROWS;
-    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
+    struct Tile {
         U128 m[ROWS];
         u32 count[ROWS];
         u64 idx[ROWS], gate[ROWS];
         bool valid[ROWS];
-        if (VEC && base + (u64)TPB * 2 <= n) { // A, whole tile inside the table (table bases are 16-byte aligned)
+    };
+    auto load_rows = [&](u64 base, Tile &t) { // A (block-uniform base; nothing is loaded past the table)
+        if (VEC && base + (u64)TPB * 2 <= n) { // whole tile inside the table (table bases are 16-byte aligned)
             typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
             typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
             const u64 i = base + 2 * (u64)threadIdx.x;
             const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
             const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
             const v2u32 c2 = __builtin_nontemporal_load((const v2u32 *)(cnt + i));
-            m[0] = U128{l2.x, h2.x};
-            m[ROWS - 1] = U128{l2.y, h2.y};
-            count[0] = c2.x;
-            count[ROWS - 1] = c2.y;
-            valid[0] = valid[ROWS - 1] = true;
+            t.m[0] = U128{l2.x, h2.x};
+            t.m[ROWS - 1] = U128{l2.y, h2.y};
+            t.count[0] = c2.x;
+            t.count[ROWS - 1] = c2.y;
+            t.valid[0] = t.valid[ROWS - 1] = true;
         } else {
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) { // A
+            for (int j = 0; j < ROWS; ++j) {
                 const u64 i = VEC ? base + 2 * (u64)threadIdx.x + j : base + (u64)j * TPB + threadIdx.x;
-                valid[j] = i < n && (!VEC || i < base + (u64)TPB * 2);
-                m[j].lo = valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
-                m[j].hi = valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
-                count[j] = valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
+                t.valid[j] = base < n && i < n && (!VEC || i < base + (u64)TPB * 2);
+                t.m[j].lo = t.valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
+                t.m[j].hi = t.valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
+                t.count[j] = t.valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
             }
         }
+    };
+    auto hash_and_probe = [&](Tile &t) { // B, C
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // B
-            U128 c = m[j];
-            if (!(ablate & 8)) c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
-            const u64 h = (ablate & 4) ? (c.lo ^ c.hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed_k<KC>(c, k);
-            idx[j] = mod_size(h, bf.mod);
+        for (int j = 0; j < ROWS; ++j) {
+            U128 c = t.m[j];
+            if (!(ablate & 8)) c = canon_sub(t.m[j], mform_to_lform(t.m[j], r), r, off, k);
+            const u64 h = (ablate & 4) ? (c.lo ^ c.hi) * 0x9E3779B97F4A7C15ULL : xxh3_packed_k<KC>(c, k, sh_lut);
+            t.idx[j] = mod_size(h, bf.mod);
         }
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) // C
-            gate[j] = (ablate & 1) ? 0ULL : !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
+        for (int j = 0; j < ROWS; ++j)
+            t.gate[j] = (ablate & 1) ? 0ULL : !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, t.idx[j])] : bf.gate[gate_word(bf, t.idx[j])];
+    };
+    auto finish = [&](Tile &t) { // D
         bool open_j[ROWS];
         if (bf.pregate && bf.use_gate) { // coarse gate first; the fine gate's line only for the rows that pass it,
 #pragma unroll                           // and all of those loads in flight together
             for (int j = 0; j < ROWS; ++j) {
-                const u64 pm = pre_mask(bf, idx[j]);
-                open_j[j] = valid[j] && (gate[j] & pm) == pm;
+                const u64 pm = pre_mask(bf, t.idx[j]);
+                open_j[j] = t.valid[j] && (t.gate[j] & pm) == pm;
             }
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) gate[j] = open_j[j] ? bf.gate[gate_word(bf, idx[j])] : 0ULL;
+            for (int j = 0; j < ROWS; ++j) t.gate[j] = open_j[j] ? bf.gate[gate_word(bf, t.idx[j])] : 0ULL;
         } else {
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) open_j[j] = valid[j];
+            for (int j = 0; j < ROWS; ++j) open_j[j] = t.valid[j];
         }
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // D
-            const u64 gm = gate_mask(bf, idx[j]);
-            const bool take = open_j[j] && !(ablate & 2) && (gate[j] & gm) == gm;
-            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
-            if (WAVE) ws.push(take, m[j], count[j], open, &counters[0]);
-            else st.push(take, m[j], count[j]);
+        for (int j = 0; j < ROWS; ++j) {
+            const u64 gm = gate_mask(bf, t.idx[j]);
+            const bool take = open_j[j] && !(ablate & 2) && (t.gate[j] & gm) == gm;
+            if (ablate) asm volatile("" ::"v"((u32)t.idx[j]), "v"((u32)t.m[j].hi));
+            st.push(take, t.m[j], t.count[j]);
         }
-        if (!WAVE) st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
+        st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
+    };
+    // (A software pipeline over the tiles -- tile i+1 hashed while tile i waits for its gate words -- was tried and
+    // changed nothing: with the gate loads present the kernel takes ~0.75 ms per 1e8 rows whatever the hashing
+    // costs; the 1e8 random 8-byte L2 reads are the bound, see DESIGN.md.)
+    const u64 step = (u64)gridDim.x * TPB * ROWS;
+    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
+        Tile t;
+        load_rows(base, t);
+        hash_and_probe(t);
+        finish(t);
     }
-    if (WAVE) {
-        if (ws.staged) ws.flush(open, &counters[0]);
-    } else
-        st.flush_if_above(0, open, &counters[0]);
+    st.flush_if_above(0, open, &counters[0]);
 }
+
+// ---- partitioned second level -------------------------------------------------------------------------------
+// For an index whose gate is far beyond L2 (tens of MiB) the direct form above pays one random HBM line per row
+// that passes the coarse gate -- at whole-genome scale that is nearly every second row, and the kernel drops to
+// ~0.3 of the roofline.  Here the coarse gate's survivors are instead BINNED by the slice of the fine gate they
+// will probe (slices of half the L2-resident size), and a second kernel walks the bins in order, so the slice in
+// use stays in L2: the random HBM lines become two extra sequential passes over the survivors only.
+constexpr int BIN_MAXP = 32; // bins (fine gate up to 32 slices = 64 MiB)
+constexpr int BIN_LDS_ROWS = 2048; // LDS staging rows per workgroup over all bins (40 KB): a ring of 64..256 rows per bin
+// Each workgroup of the binning kernel owns one segment of every bin's region, so appending needs no global
+// atomic at all (one shared counter per bin was tried first: 2e6 returning atomics on 16 addresses made the
+// kernel six times slower than the direct form).
+struct BinSet {
+    RowList rows;               // [nbins][nseg] segments of `segcap` rows
+    u32 *counts;                // [nbins][nseg] rows in each segment
+    RowList spill;              // rows that did not fit their segment
+    unsigned long long *spill_count;
+    u64 segcap;
+    u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift, < nbins <= BIN_MAXP; nseg = binning grid
+    u32 ring;                    // staging rows per bin: BIN_LDS_ROWS / nbins rounded down to a power of two, at most 256
+};
+
+template <int KC, int RC, int ROWS>
+__global__ void __launch_bounds__(TPB) scan_bin_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo,
+                                                       const u32 *__restrict__ cnt, u64 n, int k_rt, int r_rt, BFView bf, BinSet bins,
+                                                       int ablate) // timing-only diagnostic: 16 no stores, 32 no staging, 64 no barriers
+{
+    extern __shared__ u64 sh_rows[]; // nbins * ring rows: hi, lo, cnt (the launch sizes it: 20 B per row)
+    __shared__ u32 sh_n[BIN_MAXP], sh_head[BIN_MAXP], sh_pos[BIN_MAXP]; // rows staged so far / flushed so far / rows in the segment
+    const int P = (int)bins.nbins;
+    const u32 ring = bins.ring, unit = ring / 2;
+    u64 *const sh_hi = sh_rows, *const sh_lo = sh_rows + P * ring;
+    u32 *const sh_cnt = (u32 *)(sh_rows + 2 * P * ring); // rows leave in units of half a ring: whole cache lines at line-aligned addresses
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
+    if (threadIdx.x < BIN_MAXP) sh_n[threadIdx.x] = sh_head[threadIdx.x] = sh_pos[threadIdx.x] = 0;
+    __syncthreads();
+    // every thread of the workgroup calls this, between barriers; `all`: also the last partial unit of every bin
+    auto flush_bins = [&](bool all) {
+        for (int b = wave; b < P; b += TPB / 64) {
+            const u32 head = sh_head[b];
+            const u32 staged = min(sh_n[b], head + ring); // lanes that found the ring full bumped the counter past it
+            const u32 c = all ? staged - head : (staged - head) / unit * unit;
+            if (lane == 0) sh_n[b] = staged;
+            if (c == 0) continue;
+            const u32 pos = sh_pos[b];
+            RowList dst = bins.rows;
+            unsigned long long at = ((unsigned long long)b * bins.nseg + blockIdx.x) * bins.segcap + pos;
+            const bool fits = pos + c <= bins.segcap;
+            if (!fits) { // the segment is full: this flush goes to the spill list
+                if (lane == 0) at = atomicAdd(bins.spill_count, (unsigned long long)c);
+                at = __shfl(at, 0, 64);
+                dst = bins.spill;
+            }
+            for (u32 o = lane; o < c && !(ablate & 16); o += 64) {
+                const u32 src = b * ring + ((head + o) & (ring - 1));
+                dst.hi[at + o] = sh_hi[src];
+                dst.lo[at + o] = sh_lo[src];
+                dst.cnt[at + o] = sh_cnt[src];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                sh_head[b] = head + c;
+                if (fits) sh_pos[b] = pos + c;
+            }
+        }
+    };
+    const u64 step = (u64)gridDim.x * TPB * ROWS;
+    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
+        U128 m[ROWS];
+        u32 count[ROWS];
+        u64 idx[ROWS], gate[ROWS];
+        bool pending[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // A
+            const u64 i = base + (u64)j * TPB + threadIdx.x;
+            pending[j] = i < n;
+            m[j].lo = pending[j] ? __builtin_nontemporal_load(lo + i) : 0;
+            m[j].hi = pending[j] ? __builtin_nontemporal_load(hi + i) : 0;
+            count[j] = pending[j] ? __builtin_nontemporal_load(cnt + i) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // B
+            const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+            idx[j] = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) gate[j] = bf.pregate[pre_word(bf, idx[j])]; // C: coarse gate, L2-resident
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u64 pm = pre_mask(bf, idx[j]);
+            pending[j] = pending[j] && (gate[j] & pm) == pm;
+            if (ablate & 32) {
+                asm volatile("" ::"v"((u32)pending[j]));
+                pending[j] = false;
+            }
+        }
+        if (ablate & 64) continue;
+        // D: survivors into their bin's ring; a full ring defers the lane until the flush that follows
+        bool again;
+        do {
+            bool mine = false;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                if (pending[j]) {
+                    const u32 b = (u32)(gate_word(bf, idx[j]) >> bins.word_shift);
+                    const u32 slot = atomicAdd(&sh_n[b], 1u);
+                    if (slot - sh_head[b] < ring) {
+                        const u32 at = b * ring + (slot & (ring - 1));
+                        sh_hi[at] = m[j].hi;
+                        sh_lo[at] = m[j].lo;
+                        sh_cnt[at] = count[j];
+                        pending[j] = false;
+                    } else
+                        mine = true;
+                }
+            again = __syncthreads_or(mine);
+            flush_bins(false);
+            __syncthreads();
+        } while (again);
+    }
+    flush_bins(true);
+    __syncthreads();
+    if ((int)threadIdx.x < P) bins.counts[threadIdx.x * bins.nseg + blockIdx.x] = sh_pos[threadIdx.x];
+}
+
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_bin_gate_kernel(int k_rt, int r_rt, BFView bf, BinSet bins, RowList open,
+                                                            unsigned long long *counters)
+{
+    constexpr int CAP = 2 * TPB + 256;
+    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
+    __shared__ u32 sh_cnt[CAP];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const int P = (int)bins.nbins;
+    auto take_rows = [&](const RowList &src, u64 first, u64 np) { // block-uniform arguments
+        for (u64 base = 0; base < np; base += 2 * TPB) {
+            bool take[2];
+            U128 m[2];
+            u32 count[2];
+            u64 word[2], idx[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u64 j = base + q * TPB + threadIdx.x;
+                take[q] = j < np;
+                m[q] = take[q] ? U128{__builtin_nontemporal_load(src.lo + first + j), __builtin_nontemporal_load(src.hi + first + j)} : U128{0, 0};
+                count[q] = take[q] ? __builtin_nontemporal_load(src.cnt + first + j) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const U128 c = canon_sub(m[q], mform_to_lform(m[q], r), r, off, k);
+                idx[q] = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) word[q] = bf.gate[gate_word(bf, idx[q])];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u64 gm = gate_mask(bf, idx[q]);
+                st.push(take[q] && (word[q] & gm) == gm, m[q], count[q]);
+            }
+            st.flush_if_above(CAP - 2 * TPB, open, &counters[0]);
+        }
+    };
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch), and each XCD has its own L2: XCD x takes bins x,
+    // x + 8, ... so that its L2 holds one slice of the fine gate for as long as its workgroups need it.  (All
+    // workgroups walking all bins in the same order was tried first: they drift apart by several bins within
+    // microseconds, and 3 of 4 gate loads missed L2.)  Placement only decides speed, never the result.
+    const u32 xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3; // the grid is a multiple of 8
+    for (int p = (int)xcd; p < P; p += 8)
+        for (u32 w = local; w < bins.nseg; w += nlocal)
+            take_rows(bins.rows, ((u64)p * bins.nseg + w) * bins.segcap, bins.counts[p * bins.nseg + w]);
+    {
+        const u64 ns = *bins.spill_count, chunk = (ns + gridDim.x - 1) / gridDim.x;
+        const u64 lo_ = min(ns, chunk * blockIdx.x), hi_ = min(ns, lo_ + chunk);
+        take_rows(bins.spill, lo_, hi_ - lo_);
+    }
+    st.flush_if_above(0, open, &counters[0]);
+}
+
 
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
@@ -264,6 +426,8 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
     BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
     if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
@@ -279,7 +443,7 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             m = U128{open.lo[j], open.hi[j]};
             count = open.cnt[j];
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
-            const u64 h = xxh3_packed_k<KC>(c, k);
+            const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
             const u64 word = bf.words[idx >> 6];
             const long long s = map_find(map, c, h);

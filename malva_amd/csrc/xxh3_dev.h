@@ -196,12 +196,22 @@ __device__ __forceinline__ u64 xxh3_packed_33to64(u64 lo, u64 hi, int len)
 // ceil(LEN/4) dwords (one v_perm_b32 each) and the eight overlapping 8-byte reads of
 // XXH3's 33..64-byte path are cut out of them with v_alignbyte_b32, instead of expanding
 // sixteen dwords (the two read sets overlap almost entirely).
-template <int LEN> __device__ __forceinline__ u64 xxh3_packed_fixed(u64 lo, u64 hi)
+// LUT == true: `lut` is a 256-entry table in LDS, lut[c8] = expand4(c8) (ascii_lut_fill).  The table-streaming
+// kernels are bound by VALU issue, not by HBM: an expansion costs four VALU operations per dword in arithmetic
+// and one (the byte select) plus an LDS read, which issues beside the VALU, through the table.
+__device__ __forceinline__ void ascii_lut_fill(u32 *lut) // every thread of a >= 256-thread workgroup; barrier after
+{
+    if (threadIdx.x < 256) lut[threadIdx.x] = expand4(threadIdx.x);
+}
+template <int LEN, bool LUT = false> __device__ __forceinline__ u64 xxh3_packed_fixed(u64 lo, u64 hi, const u32 *lut = nullptr)
 {
     constexpr int NW = (LEN + 3) / 4;
     u32 w[NW + 1];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) w[j] = expand4((u32)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFF));
+    for (int j = 0; j < NW; ++j) {
+        const u32 c8 = (u32)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFF);
+        w[j] = LUT ? lut[c8] : expand4(c8);
+    }
     w[NW] = 0;
     auto rd = [&](int o) -> u64 { // little-endian u64 at byte offset o of the ASCII string
         const int i = o >> 2, s = o & 3;

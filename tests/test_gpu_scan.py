@@ -12,12 +12,14 @@ from oracle import capi as ocapi
 pytestmark = pytest.mark.gpu
 
 
-def _scan_case(k, ref_k, bf_bits, n_vars, n_rows, seed, use_summary=1, genome_edit=None):
+def _scan_case(k, ref_k, bf_bits, n_vars, n_rows, seed, use_summary=1, genome_edit=None, options=(), after=None):
     panel = synth.snp_panel(n_vars, seed)
     if genome_edit:
         genome_edit(panel.genome)
     ctx = Context(k, ref_k, bf_bits)
     ctx.set_option("use_summary", use_summary)
+    for name, value in options:
+        ctx.set_option(name, value)
     obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bf_bits)
     # index parity first: same bits in both filters
     _, _, words, _ = ctx.bf_export(BF_ALT)
@@ -31,6 +33,8 @@ def _scan_case(k, ref_k, bf_bits, n_vars, n_rows, seed, use_summary=1, genome_ed
     assert np.array_equal(counts, obf.counts())
     assert map_values_by_key(ctx) == dict(omap.items())
     _, _, _, n_open, n_hits = ctx.scan_stats()
+    if after:
+        after(ctx)
     ctx.close()
     return obf, octx, n_hits
 
@@ -49,6 +53,23 @@ def test_scan_tiny_filter_forces_collisions_and_context_hits():
 
 def test_scan_without_summaries_is_identical():
     _scan_case(35, 43, 1 << 17, 2000, 80000, 13, use_summary=0)
+
+
+@pytest.mark.parametrize("k,ref_k,bits,n_bins,bin_cap", [(35, 43, 1 << 33, 32, 0), (35, 43, 1 << 17, 4, 0), (31, 41, (1 << 18) + 77, 9, 0),
+                                                         (35, 43, 1 << 33, 32, 4), (35, 43, 1 << 17, 4, 1)])
+def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
+    """whole-genome-sized indexes bin the coarse gate's survivors by fine-gate slice; forced here with a 2^10-bit
+    coarse gate in front of a fine one of up to 2^14 bits (slices of 2^9 bits).  bin_cap > 0 shrinks the bin segments so that most
+    rows overflow them and take the spill list."""
+    def check(ctx):
+        assert ctx.get_option("pregate_k") > 0 and ctx.get_option("scan_bins") == n_bins
+        assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
+    _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
+               options=[("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
+    def direct(ctx):
+        assert ctx.get_option("scan_bins") == 0
+    _scan_case(k, ref_k, bits, 3000, 150000, 31, after=direct,
+               options=[("pregate_log2", 10), ("gate_log2", 14), ("use_partition", 0)])
 
 
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17)])
