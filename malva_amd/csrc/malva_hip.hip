@@ -89,6 +89,7 @@ struct mg_ctx {
     int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
     int pre_k = 1;      // bits per entry of the coarse gate (chosen at finalize from the load)
     int use_pregate = 1;
+    bool pre_skip = false; // the coarse gate is saturated at this index size (decided at finalize): scans go straight to the fine gate
     int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
     int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
     int bin_ring = 0, bin_rows = 4; // A/B: staging ring per bin (0 = as large as LDS allows), rows per thread of the binning kernel
@@ -167,6 +168,9 @@ ModDesc make_mod(u64 size)
     return m;
 }
 
+// use_pregate: 0 never, 1 unless saturated (pre_skip), 2 always (tests)
+bool pregate_on(const mg_ctx *c) { return c->use_pregate == 2 || (c->use_pregate == 1 && !c->pre_skip); }
+
 BFView view(const mg_ctx *c, int which)
 {
     const BFState &b = c->bf[which];
@@ -178,7 +182,7 @@ BFView view(const mg_ctx *c, int which)
     v.mod = b.mod;
     v.gate_shift = b.gate_shift;
     v.gate_k = (u32)c->gate_k;
-    v.pregate = c->use_pregate ? b.pregate : nullptr;
+    v.pregate = pregate_on(c) ? b.pregate : nullptr;
     v.pre_shift = b.pre_shift;
     v.pre_k = (u32)c->pre_k;
     v.use_gate = (c->use_summary && b.gate) ? 1 : 0;
@@ -486,7 +490,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
-    else if (!strcmp(name, "use_pregate")) c->use_pregate = value != 0;
+    else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
     else if (!strcmp(name, "scan_bin_ring")) {
@@ -526,7 +530,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "gate_log2")) *value = c->gate_log2;
     else if (!strcmp(name, "gate_k")) *value = c->gate_k;
     else if (!strcmp(name, "pregate_log2")) *value = c->pregate_log2;
-    else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate ? c->pre_k : 0;
+    else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate && pregate_on(c) ? c->pre_k : 0;
     else if (!strcmp(name, "scan_bins")) *value = c->last_bins;
     else if (!strcmp(name, "scan_spilled")) { // rows of the last chunk that took the spill list
         unsigned long long t = 0;
@@ -608,6 +612,8 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
         // coarse gate: the bits per entry that minimise its false-positive rate at this load (ln 2 * bits / entries)
         int pk = entries ? (int)std::lround(0.6931 * (double)(1ULL << c->pregate_log2) / (double)entries) : 4;
         pk = pk < 1 ? 1 : pk > 4 ? 4 : pk;
+        // a coarse gate that would let more than 3 of 4 rows through costs an L2 probe per row and saves little
+        c->pre_skip = std::pow(1.0 - std::exp(-(double)pk * (double)entries / (double)(1ULL << c->pregate_log2)), pk) > 0.75;
         if (want != c->gate_log2 || (want > c->pregate_log2 && pk != c->pre_k)) {
             c->gate_log2 = want;
             c->pre_k = pk;
@@ -874,7 +880,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     BinSet bins{};
     const BFState &alt = c->bf[MG_BF_ALT];
     const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6);
-    const u64 P = alt.pregate ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
+    const u64 P = alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
     const bool partition = c->use_summary && c->use_pregate && c->use_partition && P >= 2 && P <= BIN_MAXP;
     if (partition) {
         bins.nbins = (u32)P;
@@ -1179,11 +1185,17 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
     if (!c->map.slots) TRY(map_reserve(c, 0));
     GenoParams p;
     TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
-    hipLaunchKernelGGL(call_isolated_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
+    u32 *need_slow = (u32 *)(c->d_hit_count + 3); // a spare word of the scan's counter block
+    HIP_TRY(c, hipMemsetAsync(need_slow, 0, 4, c->stream));
+    hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
-                       (const float *)d_freq, (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT),
-                       view(c), p, (u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status, (double *)d_probs,
-                       (const u64 *)d_var_gt_off);
+                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow);
+    hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
+                       (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
+                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow);
+    hipLaunchKernelGGL(iso_genotype_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (u64)n_vars, (const u32 *)d_var_allele_off,
+                       (const float *)d_freq, p, (const u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status,
+                       (double *)d_probs, (const u64 *)d_var_gt_off);
     HIP_TRY(c, hipGetLastError());
     return MG_OK;
 }

@@ -116,35 +116,54 @@ __device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
 // 2-bit form from flanks packed once per variant (shared by its alleles), canonicalised
 // with integer compares and hashed with the register-resident XXH3 -- the same code the
 // scan uses.  Anything else (N / IUPAC in the window, k outside 17..64) takes weight_bytes.
-__global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference, u64 n_vars, const u64 *pos,
-                                                            const u32 *var_allele_off, const u32 *allele_off,
-                                                            const u8 *pool, const float *freq, const u64 *present_mask,
-                                                            const u8 *flags, int k, BFView bf, MapView map, GenoParams p,
-                                                            u32 *cov_out, i32 *gt1, i32 *gt2, i32 *gq, u8 *status,
-                                                            double *probs, const u64 *var_gt_off)
+//
+// Two kernels.  The lookups are chains of dependent random reads (map slot -> value; filter word -> rank block ->
+// counter) and want many waves in flight; the likelihoods are f64 arithmetic over a dozen live doubles and want
+// registers.  Fused in one kernel (the first form) the likelihoods' 193 VGPRs left 2 waves per SIMD to hide the
+// lookups' latency.  The coverage words written by the first kernel and read by the second are 8 B per SNP.
+//   iso_cover_kernel<false>: TWO threads per variant, alleles split by parity (a biallelic SNP: REF on one, ALT on
+//       the other); a signature with a non-ACGT base is only marked (ISO_SLOW) and `*need_slow` raised
+//   iso_cover_kernel<true>: the same grid, returns at once unless `*need_slow`; redoes the marked alleles byte-wise
+//       (kept out of the first kernel because its generic XXH3 alone needs 190 VGPRs)
+//   iso_genotype_kernel: one thread per variant
+constexpr u32 ISO_SLOW = 0xFFFFFFFFu; // never a coverage: those are float-rounded counts below 2^31
+template <bool SLOW>
+__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off,
+                                                        const u32 *allele_off, const u8 *pool, const u64 *present_mask,
+                                                        const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow)
 {
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (SLOW && *need_slow == 0) return;
+    const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 v = t >> 1;
     if (v >= n_vars) return;
     const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
     const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
     u32 *cov = cov_out + a0;
-    for (u32 a = 0; a < A; ++a) cov[a] = 0;
-    if (flags[v] & 1) {
-        const u64 pm = present_mask[v];
-        const u8 *site = reference + pos[v];
-        const int lmax = k / 2, rmax = (k + 1) / 2;
-        const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
-        // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
-        u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
-        if (packed_ok) {
-            pack_span(site - lmax, lmax, &lf, &lbad);
-            pack_span(site + ref_size, rmax, &rf, &rbad);
-        }
-        for (u32 a = 0; a < A && a < 64; ++a) {
-            if (!((pm >> a) & 1)) continue;
+    const bool live = flags[v] & 1;
+    const u64 pm = live ? present_mask[v] : 0;
+    const u8 *site = reference + pos[v];
+    const int lmax = k / 2, rmax = (k + 1) / 2;
+    const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
+    // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
+    u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
+    if (!SLOW && packed_ok && live) {
+        pack_span(site - lmax, lmax, &lf, &lbad);
+        pack_span(site + ref_size, rmax, &rf, &rbad);
+    }
+    for (u32 a = (u32)(t & 1); a < A; a += 2) {
+        if (SLOW) {
+            if (cov[a] != ISO_SLOW) continue;
             const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
-            const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
-            if (mp < 0 || ms < 0) continue; // alleles >= k take the general path (host contract)
+            const int mp = k / 2 - alen / 2;
+            const i32 w = weight_bytes(SigIn{site - mp, pool + allele_off[a0 + a], site + ref_size, mp, alen}, k, a == 0, bf, map);
+            cov[a] = w > 0 ? (u32)(float)(u32)w : 0;
+            continue;
+        }
+        u32 out = 0;
+        const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
+        const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
+        // alleles >= k take the general path (host contract); alleles past the 64-bit presence mask are not looked up
+        if (a < 64 && ((pm >> a) & 1) && mp >= 0 && ms >= 0) {
             const u8 *al = pool + allele_off[a0 + a];
             bool fast = packed_ok && (lbad >> (lmax - mp)) == 0 && (ms == 0 || (rbad & ((1ULL << ms) - 1)) == 0);
             U128 L{0, 0};
@@ -157,8 +176,11 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
                     else L.hi |= code << (2 * (i - 32));
                 }
             }
-            i32 w;
-            if (fast) {
+            i32 w = 0;
+            if (!fast) {
+                out = ISO_SLOW;
+                *need_slow = 1;
+            } else {
                 L = shl128(L, 2 * mp);
                 if (mp) L.lo |= lf >> (2 * (lmax - mp));                         // last mp bases of the left flank
                 if (ms) {
@@ -170,7 +192,7 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
                 const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - k)); // M-form of the k-mer
                 const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
                 const U128 key = lt128(L, rc) ? L : rc;
-                const u64 h = xxh3_packed(key, k);
+                const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
                 if (a == 0) {
                     const long long s = map_find(map, key, h);
                     w = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
@@ -178,13 +200,21 @@ __global__ void __launch_bounds__(TPB) call_isolated_kernel(const u8 *reference,
                     const u64 idx = mod_size(h, bf.mod);
                     w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
                 }
-            } else {
-                w = weight_bytes(SigIn{site - mp, al, site + ref_size, mp, alen}, k, a == 0, bf, map);
+                if (w > 0) out = (u32)(float)(u32)w;
             }
-            if (w > 0) cov[a] = (u32)(float)(u32)w;
         }
+        cov[a] = out;
     }
-    genotype_one(cov, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
+}
+
+__global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32 *var_allele_off, const float *freq, GenoParams p,
+                                                           const u32 *cov, i32 *gt1, i32 *gt2, i32 *gq, u8 *status, double *probs,
+                                                           const u64 *var_gt_off)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    genotype_one(cov + a0, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
 }
 
 // ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------

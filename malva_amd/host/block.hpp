@@ -6,6 +6,7 @@
 // blocks that hold one short-allele variant bypass it (mg_call_isolated).
 #pragma once
 #include <set>
+#include <unordered_map>
 
 #include "io.hpp"
 
@@ -140,7 +141,44 @@ class Block {
 
     // build_alleles_combs + combine_haplotypes, var_block.hpp:709-786.  A set of allele picks along the
     // chain; picks are compared by allele TEXT in the reference, i.e. by first index with that text.
-    std::set<std::vector<int>> allele_picks(const std::vector<int> &comb, int central, bool haploid) const
+    // What allele_picks needs from the panel, gathered once per block.  A panel has tens of thousands of samples
+    // (C1: 27,934) and nearly all of them carry the reference allele at any given variant: a sample that is
+    // all-reference along a chain picks allele 0 everywhere whatever its phasing, so only the samples that are
+    // non-reference at some member of the chain have to be walked.
+    struct PanelIndex {
+        std::vector<std::vector<int>> nonref;  // per variant: samples with a non-reference allele (either haplotype)
+        std::vector<std::vector<int>> canon;   // per variant, per allele: first allele index with the same text
+        std::vector<uint8_t> any_unphased;     // per variant: some sample is unphased there
+        std::vector<uint8_t> regular;          // per variant: genotypes and phasing both hold n_samples entries
+        size_t n_samples = 0;
+    };
+    PanelIndex panel_index() const
+    {
+        PanelIndex px;
+        const size_t B = vars.size();
+        px.nonref.resize(B);
+        px.canon.resize(B);
+        px.any_unphased.assign(B, 0);
+        px.regular.assign(B, 0);
+        for (const Variant &v : vars)
+            if (v.is_present) px.n_samples = std::max(px.n_samples, v.genotypes.size());
+        for (size_t j = 0; j < B; ++j) {
+            const Variant &v = vars[j];
+            if (!v.is_present) continue;
+            px.regular[j] = v.genotypes.size() == px.n_samples && v.phasing.size() == px.n_samples;
+            px.canon[j].resize((size_t)v.n_alleles());
+            for (int a = 0; a < v.n_alleles(); ++a) px.canon[j][(size_t)a] = v.allele_index(v.allele(a));
+            for (size_t g = 0; g < v.genotypes.size(); ++g) {
+                if (v.genotypes[g].first != 0 || v.genotypes[g].second != 0) px.nonref[j].push_back((int)g);
+                if (g < v.phasing.size() && !v.phasing[g]) px.any_unphased[j] = 1;
+            }
+        }
+        return px;
+    }
+
+    // build_alleles_combs + combine_haplotypes, var_block.hpp:709-786.  A set of allele picks along the
+    // chain; picks are compared by allele TEXT in the reference, i.e. by first index with that text.
+    std::set<std::vector<int>> allele_picks(const std::vector<int> &comb, int central, bool haploid, const PanelIndex *px = nullptr) const
     {
         std::set<std::vector<int>> out;
         auto canon = [&](int var, int allele) {
@@ -148,7 +186,26 @@ class Block {
             return v.allele_index(v.allele(allele)); // .at() throws if the GT names a dropped symbolic allele
         };
         const size_t n = comb.size();
-        for (size_t g = 0; g < vars[(size_t)central].genotypes.size(); ++g) {
+        // the samples to walk: all of them, or (sparse form) those non-reference somewhere on the chain
+        std::vector<int> walk;
+        bool sparse = px != nullptr;
+        if (sparse)
+            for (int m : comb) sparse = sparse && px->regular[(size_t)m];
+        if (sparse) {
+            bool unphased_somewhere = false;
+            for (int m : comb) {
+                walk.insert(walk.end(), px->nonref[(size_t)m].begin(), px->nonref[(size_t)m].end());
+                unphased_somewhere = unphased_somewhere || px->any_unphased[(size_t)m];
+            }
+            std::sort(walk.begin(), walk.end());
+            walk.erase(std::unique(walk.begin(), walk.end()), walk.end());
+            // the dense walk throws on the first unphased sample of a chain longer than 24, all-reference or not
+            if (!haploid && n > 24 && unphased_somewhere) throw std::runtime_error("unphased chain of more than 24 variants (2^n haplotypes)");
+            if (walk.size() < px->n_samples) out.insert(std::vector<int>(n, 0)); // some sample is all-reference here
+        }
+        const size_t n_walk = sparse ? walk.size() : vars[(size_t)central].genotypes.size();
+        for (size_t w = 0; w < n_walk; ++w) {
+            const size_t g = sparse ? (size_t)walk[w] : w;
             std::vector<int> h1(n), h2(n);
             bool phased = true;
             for (size_t j = 0; j < n; ++j) {
@@ -180,6 +237,7 @@ class Block {
     std::vector<AlleleSignatures> extract(const std::string &reference, bool haploid) const
     {
         std::vector<AlleleSignatures> result(vars.size());
+        const PanelIndex panel = panel_index();
         for (int vi = 0; vi < (int)vars.size(); ++vi) {
             const Variant &v = vars[(size_t)vi];
             if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) continue;
@@ -193,7 +251,7 @@ class Block {
                     if (last_end != -1) rsubs.push_back(substr_clip(reference, last_end, cv.ref_pos - last_end));
                     last_end = cv.ref_pos + cv.ref_size;
                 }
-                for (const auto &pick : allele_picks(comb, vi, haploid)) {
+                for (const auto &pick : allele_picks(comb, vi, haploid, &panel)) {
                     std::vector<std::string> sig;
                     std::string mid_allele;
                     if (pick.size() == 1 && (int)vars[(size_t)comb[0]].allele(pick[0]).size() >= k) {

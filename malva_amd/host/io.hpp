@@ -151,6 +151,10 @@ class VcfReader {
     std::string pending;
     bool have_pending = false;
     std::vector<std::string_view> cols, fmt, fld, vals;
+    std::vector<int> tok_allele;      // GT tokens of the current record, all kept samples
+    std::vector<uint8_t> tok_phased;  // separator in front of each token was '|'
+    std::vector<uint32_t> tok_off;    // per kept sample: its first token
+    std::vector<uint8_t> keep_mask;   // per sample column: kept
 
   public:
     std::vector<std::string> header_lines; // the ## lines
@@ -214,7 +218,20 @@ class VcfReader {
                 return false;
             if (!line.empty() && line[0] != '#') break;
         }
-        split(line, '\t', cols);
+        // the nine fixed columns; the sample columns (tens of thousands on a panel) are walked in place below
+        cols.clear();
+        const char *const line_end = line.data() + line.size();
+        const char *samples_at = nullptr;
+        for (const char *p = line.data();;) {
+            const char *t = (const char *)memchr(p, '\t', (size_t)(line_end - p));
+            cols.emplace_back(p, (size_t)((t ? t : line_end) - p));
+            if (!t) break;
+            p = t + 1;
+            if (cols.size() == 9) {
+                samples_at = p;
+                break;
+            }
+        }
         if (cols.size() < 8) throw std::runtime_error("malformed VCF record: " + line.substr(0, 60));
         v = Variant();
         v.seq_name = std::string(cols[0]);
@@ -284,40 +301,107 @@ class VcfReader {
             v.has_alts = false; // variant.hpp:169-174
             return true;
         }
-        // what bcf_get_genotypes returns: per sample `ploidy` values, short samples padded with vector_end
+        // what bcf_get_genotypes returns: per sample `ploidy` values, short samples padded with vector_end.
+        // One flat token list for the record (panels carry tens of thousands of samples: no per-sample allocation).
         struct G {
             int allele; // -1 missing, -2 vector_end
             bool phased;
         };
-        std::vector<std::vector<G>> per(keep.size());
-        size_t ploidy = 0;
-        for (size_t s = 0; s < keep.size(); ++s) {
-            const size_t col = 9 + (size_t)keep[s];
-            std::string_view gt = ".";
-            if (col < cols.size()) {
-                split(cols[col], ':', fld);
-                if ((size_t)gi < fld.size()) gt = fld[(size_t)gi];
-            }
-            bool ph = false;
-            size_t a = 0;
-            for (size_t i = 0; i <= gt.size(); ++i)
-                if (i == gt.size() || gt[i] == '/' || gt[i] == '|') {
-                    const std::string_view tok = gt.substr(a, i - a);
-                    per[s].push_back({(tok.empty() || tok == ".") ? -1 : atoi(std::string(tok).c_str()), ph});
-                    if (i < gt.size()) ph = gt[i] == '|';
-                    a = i + 1;
-                }
-            ploidy = std::max(ploidy, per[s].size());
+        if (keep_mask.size() != samples.size()) {
+            keep_mask.assign(samples.size(), 0);
+            for (int i : keep) keep_mask[(size_t)i] = 1;
         }
-        std::vector<G> flat;
-        flat.reserve(keep.size() * ploidy);
-        for (auto &p : per)
-            for (size_t j = 0; j < ploidy; ++j) flat.push_back(j < p.size() ? p[j] : G{-2, false});
+        // Token arrays are written by index (two slots per kept sample to start with; the general path grows them).
+        size_t cap = std::max(tok_allele.size(), 2 * keep.size() + 16);
+        tok_allele.resize(cap);
+        tok_phased.resize(cap);
+        tok_off.resize(keep.size() + 1);
+        tok_off[0] = 0;
+        size_t nt = 0, ns = 0, ploidy = 0;
+        auto put = [&](int val, bool ph) {
+            if (nt == cap) {
+                cap *= 2;
+                tok_allele.resize(cap);
+                tok_phased.resize(cap);
+            }
+            tok_allele[nt] = val;
+            tok_phased[nt++] = ph ? 1 : 0;
+        };
+        auto close_sample = [&]() {
+            tok_off[++ns] = (uint32_t)nt;
+            ploidy = std::max(ploidy, (size_t)(tok_off[ns] - tok_off[ns - 1]));
+        };
+        auto one_char = [](char t) { return t >= '0' && t <= '9' ? t - '0' : t == '.' ? -1 : 0; }; // atoi of a 1-char token
+        auto ends_gt = [](char t) { return t == '\t' || t == ':' || t == '\0'; };                  // the line is NUL-terminated
+        const char *c = samples_at;
+        for (size_t col = 0; col < samples.size(); ++col) {
+            if (!c) { // record with fewer sample columns than the header: GT "."
+                if (keep_mask[col]) {
+                    put(-1, false);
+                    close_sample();
+                }
+                continue;
+            }
+            if (keep_mask[col]) {
+                if (gi == 0 && c[0] != '\t' && c[0] != '\0' && ends_gt(c[1])) { // "0"
+                    put(one_char(c[0]), false);
+                    c += 1;
+                } else if (gi == 0 && c[0] != '\t' && c[0] != '\0' && c[0] != ':' && (c[1] == '|' || c[1] == '/') && !ends_gt(c[2]) && c[2] != '|' &&
+                           c[2] != '/' && ends_gt(c[3])) { // "0|1"
+                    put(one_char(c[0]), false);
+                    put(one_char(c[2]), c[1] == '|');
+                    c += 3;
+                } else {
+                    int sub = 0;
+                    while (sub < gi && c < line_end && *c != '\t') { // the gi-th ':'-separated sub-field
+                        if (*c == ':') ++sub;
+                        ++c;
+                    }
+                    if (sub < gi) put(-1, false); // sub-field absent: GT "."
+                    else {
+                        bool ph = false;
+                        for (;;) { // tokens separated by '/' or '|'; each read as atoi would (sign, leading digits)
+                            const char *a = c;
+                            while (c < line_end && *c != '/' && *c != '|' && *c != ':' && *c != '\t') ++c;
+                            int val = -1;
+                            if (c > a && !(c == a + 1 && *a == '.')) {
+                                const char *q = a;
+                                bool neg = false;
+                                if (*q == '-' || *q == '+') neg = *q++ == '-';
+                                long acc = 0;
+                                while (q < c && *q >= '0' && *q <= '9') acc = acc * 10 + (*q++ - '0');
+                                val = (int)(neg ? -acc : acc);
+                            }
+                            put(val, ph);
+                            if (c < line_end && (*c == '/' || *c == '|')) {
+                                ph = *c == '|';
+                                ++c;
+                                continue;
+                            }
+                            break;
+                        }
+                    }
+                }
+                close_sample();
+            }
+            while (c < line_end && *c != '\t') ++c; // the rest of the column (nothing, when it holds only GT)
+            c = c < line_end ? c + 1 : nullptr;
+        }
+        const size_t n_flat = keep.size() * ploidy;
+        const bool uniform_ploidy = nt == n_flat; // every sample has `ploidy` tokens: the padded array IS the token list
+        auto flat_at = [&](size_t idx) -> G { // element idx of the padded [sample][ploidy] array
+            if (uniform_ploidy) return G{tok_allele[idx], tok_phased[idx] != 0};
+            const size_t smp = idx / ploidy, j = idx % ploidy;
+            const uint32_t o = tok_off[smp], cnt = tok_off[smp + 1] - o;
+            return j < cnt ? G{tok_allele[o + j], tok_phased[o + j] != 0} : G{-2, false};
+        };
+        v.genotypes.resize(keep.size());
+        v.phasing.resize(keep.size());
         for (size_t i = 0; i < keep.size(); ++i) {
-            const G first = flat[i * ploidy];
+            const G first = flat_at(i * ploidy);
             // curr_gt[1]: with ploidy 1 this is the NEXT sample's value (variant.hpp:184); past the last
             // sample the reference reads beyond the array -- treated as vector_end here.
-            const G second = i * ploidy + 1 < flat.size() ? flat[i * ploidy + 1] : G{-2, false};
+            const G second = i * ploidy + 1 < n_flat ? flat_at(i * ploidy + 1) : G{-2, false};
             int a1, a2;
             bool is_ph;
             if (second.allele == -2) {
@@ -328,8 +412,8 @@ class VcfReader {
                 a2 = second.allele;
                 is_ph = second.phased;
             }
-            v.genotypes.emplace_back(a1 < 0 ? 0 : a1, a2 < 0 ? 0 : a2);
-            v.phasing.push_back(is_ph ? 1 : 0);
+            v.genotypes[i] = {a1 < 0 ? 0 : a1, a2 < 0 ? 0 : a2};
+            v.phasing[i] = is_ph ? 1 : 0;
         }
         return true;
     }

@@ -20,6 +20,9 @@ def run_cli(args, **kw):
         pytest.fail("bin/malva-geno not built: run `make cli`")
     r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=900, **kw)
     assert r.returncode == 0, r.stderr[-3000:]
+    if os.environ.get("MALVA_CLI_LOG"):            # phase timings of the CLI (stderr), for tools/ and DESIGN.md
+        with open(os.environ["MALVA_CLI_LOG"], "a") as fh:
+            fh.write("== malva-geno %s\n%s\n" % (" ".join(args[:1]), r.stderr))
     return r.stdout
 
 

@@ -65,11 +65,11 @@ def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
         assert ctx.get_option("pregate_k") > 0 and ctx.get_option("scan_bins") == n_bins
         assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
-               options=[("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
+               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
     def direct(ctx):
         assert ctx.get_option("scan_bins") == 0
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=direct,
-               options=[("pregate_log2", 10), ("gate_log2", 14), ("use_partition", 0)])
+               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("use_partition", 0)])
 
 
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17)])
