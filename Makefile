@@ -30,7 +30,7 @@ malva_amd/lib/libmalva_hip.so: $(CSRC) $(CHDR)
 cli: bin/malva-geno
 bin/malva-geno: $(HOSTSRC) $(HOSTHDR) malva_amd/lib/libmalva_hip.so
 	@mkdir -p bin
-	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Imalva_amd/host -o $@ $(HOSTSRC) \
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Imalva_amd/host -o $@ $(HOSTSRC) \
 	    -Lmalva_amd/lib -lmalva_hip -lz -Wl,-rpath,'$$ORIGIN/../malva_amd/lib'
 
 oracle: oracle/libmalva_oracle.so

@@ -5,14 +5,22 @@
 // every k-mer store operation, both scans, coverage and likelihoods to
 // libmalva_hip.so through include/malva_hip.h.  There is no CPU implementation of
 // those in this program: without a GPU it stops at mg_create.
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
 #include <iostream>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "block.hpp"
 extern "C" {
@@ -364,66 +372,178 @@ struct TablePiece {
     }
 };
 
+// Rows with a symbol outside ACGT (KMC never lists any) go through the exact ASCII calls at the end.
+struct OddRows {
+    Rows ctx, kmer;
+    std::vector<uint32_t> cnt;
+};
+// One line of the dump, [p, e) without its terminator: `KMER<ws>count`.  main.cpp:491 upper-cases the k-mer.
+inline void parse_table_line(const char *p, const char *e, const Options &o, TablePiece &t, OddRows &odd)
+{
+    static const struct Lut {
+        int8_t code[256];
+        Lut()
+        {
+            for (int i = 0; i < 256; ++i) code[i] = -1;
+            code['A'] = code['a'] = 0;
+            code['C'] = code['c'] = 1;
+            code['G'] = code['g'] = 2;
+            code['T'] = code['t'] = 3;
+        }
+    } lut;
+    if (e > p && e[-1] == '\r') --e;
+    if (p == e) return;
+    const char *q = p;
+    uint64_t hi = 0, lo = 0;
+    bool acgt = true;
+    while (q < e && !isspace((unsigned char)*q)) {
+        const int c = lut.code[(unsigned char)*q++];
+        acgt = acgt && c >= 0;
+        hi = (hi << 2) | (lo >> 62);
+        lo = (lo << 2) | (uint64_t)(c & 3);
+    }
+    const size_t len = (size_t)(q - p);
+    if (len != o.ref_k) throw std::runtime_error("k-mer table holds a " + std::to_string(len) + "-mer, expected -r " + std::to_string(o.ref_k));
+    while (q < e && isspace((unsigned char)*q)) ++q;
+    uint64_t count = 0; // strtoul: leading digits
+    while (q < e && *q >= '0' && *q <= '9') count = count * 10 + (uint64_t)(*q++ - '0');
+    if (!acgt) {
+        std::string ctx(p, len);
+        upper_inplace(ctx);
+        odd.ctx.add(ctx);
+        odd.kmer.add(ctx.substr((o.ref_k - o.k) / 2, o.k));
+        odd.cnt.push_back((uint32_t)count);
+        return;
+    }
+    t.hi.push_back(hi);
+    t.lo.push_back(lo);
+    t.cnt.push_back((uint32_t)count);
+}
+
+// The dump of a whole-genome sample is >100 GB of text: a plain (uncompressed) file is mapped and parsed by all
+// host cores, 64 MiB of text per task (a line belongs to the task that holds its first byte), and the parsed
+// pieces are scanned by THIS thread in whatever order they complete -- the counter updates commute.  A
+// compressed dump is inflated and parsed by one thread.
 void scan_table(Device &dev, const Options &o, const std::string &path)
 {
-    LineReader in(path);
-    if (!in.ok()) throw std::runtime_error("cannot open " + path);
-    TablePiece t;
-    Rows odd_ctx, odd_kmer; // rows with a non-ACGT symbol (KMC never lists any): exact ASCII path
-    std::vector<uint32_t> odd_cnt;
-    std::string line;
-    const size_t piece = 1u << 24;
     uint64_t total = 0;
-    auto flush = [&]() {
+    OddRows odd;
+    auto scan_piece = [&](TablePiece &t) {
         if (!t.cnt.empty()) dev.check(mg_kmc_scan(dev.ctx, t.hi.data(), t.lo.data(), t.cnt.data(), t.cnt.size()), "mg_kmc_scan");
+        total += t.cnt.size();
         t.clear();
     };
-    while (in.next(line)) {
-        if (line.empty()) continue;
-        size_t e = 0;
-        while (e < line.size() && !isspace((unsigned char)line[e])) ++e;
-        if (e != o.ref_k) throw std::runtime_error("k-mer table holds a " + std::to_string(e) + "-mer, expected -r " + std::to_string(o.ref_k));
-        const uint32_t count = (uint32_t)strtoul(line.c_str() + e, nullptr, 10);
-        uint64_t hi = 0, lo = 0;
-        bool acgt = true;
-        for (size_t i = 0; i < e; ++i) {
-            uint64_t code;
-            switch (toupper((unsigned char)line[i])) { // main.cpp:491 toupper
-            case 'A': code = 0; break;
-            case 'C': code = 1; break;
-            case 'G': code = 2; break;
-            case 'T': code = 3; break;
-            default: code = 0; acgt = false;
-            }
-            hi = (hi << 2) | (lo >> 62);
-            lo = (lo << 2) | code;
-        }
-        ++total;
-        if (!acgt) {
-            std::string ctx = line.substr(0, e);
-            upper_inplace(ctx);
-            odd_ctx.add(ctx);
-            odd_kmer.add(ctx.substr((o.ref_k - o.k) / 2, o.k));
-            odd_cnt.push_back(count);
-            continue;
-        }
-        t.hi.push_back(hi);
-        t.lo.push_back(lo);
-        t.cnt.push_back(count);
-        if (t.cnt.size() == piece) flush();
+    bool gz = false;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        unsigned char m[2] = {0, 0};
+        gz = fread(m, 1, 2, f) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+        fclose(f);
     }
-    flush();
-    if (odd_cnt.size()) { // main.cpp:495-499 through the ASCII batch calls
-        std::vector<int32_t> ic(odd_cnt.begin(), odd_cnt.end());
-        dev.check(mg_map_increment(dev.ctx, odd_kmer.data.data(), STRIDE, odd_kmer.n, ic.data()), "mg_map_increment");
-        std::vector<uint8_t> in_ctx(odd_cnt.size());
-        dev.check(mg_bf_test(dev.ctx, MG_BF_CTX, odd_ctx.data.data(), STRIDE, odd_ctx.n, in_ctx.data()), "mg_bf_test");
+    struct stat st;
+    if (!gz && stat(path.c_str(), &st) == 0 && st.st_size > 0) {
+        const size_t size = (size_t)st.st_size;
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        const char *base = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+        madvise((void *)base, size, MADV_SEQUENTIAL);
+        const char *tb = getenv("MALVA_GENO_TABLE_TASK"); // bytes of text per parsing task (tests shrink it to cross many boundaries)
+        const size_t task_bytes = tb && atol(tb) > 0 ? (size_t)atol(tb) : (64u << 20), n_tasks = (size + task_bytes - 1) / task_bytes;
+        const unsigned n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, n_tasks}));
+        std::atomic<size_t> next_task{0};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<TablePiece> done;   // parsed, waiting for the device
+        size_t finished_threads = 0;
+        std::string error;
+        auto worker = [&]() {
+            TablePiece t;
+            OddRows mine;
+            try {
+                for (;;) {
+                    const size_t task = next_task.fetch_add(1);
+                    if (task >= n_tasks) break;
+                    const char *lim = base + std::min(size, (task + 1) * task_bytes), *end = base + size;
+                    const char *p = base + task * task_bytes;
+                    if (task) { // skip the line that started in the previous task
+                        const char *nl = (const char *)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+                        p = nl ? nl + 1 : end;
+                    }
+                    while (p < lim) {
+                        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                        const char *e = nl ? nl : end;
+                        parse_table_line(p, e, o, t, mine);
+                        p = e + 1;
+                    }
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return done.size() < 2 * n_threads || !error.empty(); }); // bound what is in flight
+                    done.emplace_back(std::move(t));
+                    t = TablePiece();
+                    cv.notify_all();
+                }
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (error.empty()) error = e.what();
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < mine.cnt.size(); ++i) {
+                odd.ctx.add(std::string(&mine.ctx.data[i * STRIDE]));
+                odd.kmer.add(std::string(&mine.kmer.data[i * STRIDE]));
+                odd.cnt.push_back(mine.cnt[i]);
+            }
+            ++finished_threads;
+            cv.notify_all();
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < n_threads; ++i) pool.emplace_back(worker);
+        for (;;) {
+            TablePiece t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !done.empty() || finished_threads == n_threads; });
+                if (done.empty()) break;
+                t = std::move(done.front());
+                done.pop_front();
+                cv.notify_all();
+            }
+            try {
+                if (error.empty()) scan_piece(t);
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (error.empty()) error = e.what();
+                cv.notify_all();
+            }
+        }
+        for (auto &th : pool) th.join();
+        munmap((void *)base, size);
+        if (!error.empty()) throw std::runtime_error(error);
+    } else {
+        LineReader in(path);
+        if (!in.ok()) throw std::runtime_error("cannot open " + path);
+        TablePiece t;
+        std::string line;
+        const size_t piece = 1u << 24;
+        while (in.next(line)) {
+            parse_table_line(line.data(), line.data() + line.size(), o, t, odd);
+            if (t.cnt.size() == piece) scan_piece(t);
+        }
+        scan_piece(t);
+    }
+    total += odd.cnt.size();
+    if (odd.cnt.size()) { // main.cpp:495-499 through the ASCII batch calls
+        std::vector<int32_t> ic(odd.cnt.begin(), odd.cnt.end());
+        dev.check(mg_map_increment(dev.ctx, odd.kmer.data.data(), STRIDE, odd.kmer.n, ic.data()), "mg_map_increment");
+        std::vector<uint8_t> in_ctx(odd.cnt.size());
+        dev.check(mg_bf_test(dev.ctx, MG_BF_CTX, odd.ctx.data.data(), STRIDE, odd.ctx.n, in_ctx.data()), "mg_bf_test");
         Rows pass;
         std::vector<uint32_t> pc;
-        for (size_t i = 0; i < odd_cnt.size(); ++i)
+        for (size_t i = 0; i < odd.cnt.size(); ++i)
             if (!in_ctx[i]) {
-                pass.add(std::string(&odd_kmer.data[i * STRIDE]));
-                pc.push_back(odd_cnt[i]);
+                pass.add(std::string(&odd.kmer.data[i * STRIDE]));
+                pc.push_back(odd.cnt[i]);
             }
         if (pass.n) dev.check(mg_bf_increment(dev.ctx, MG_BF_ALT, pass.data.data(), STRIDE, pass.n, pc.data()), "mg_bf_increment");
     }

@@ -66,6 +66,20 @@ def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref
                 fb = [float(x.split(":")[1]) for x in b.split("GTS=")[1].split("\t")[0].split(",")]
                 assert all(abs(x - y) <= 1.000001e-6 or (x != x and y != y) for x, y in zip(fa, fb)), (a, b)
     assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
+    # the k-mer dump parsed by many threads in 700-byte tasks (a line belongs to the task holding its first byte),
+    # with Windows line ends and blank lines thrown in, and through the gzip reader: same output, byte for byte
+    env = dict(os.environ, MALVA_GENO_TABLE_TASK="700")
+    assert run_cli(["call"] + args, env=env) == got
+    lines = open(table + ".txt").read().split("\n")
+    with open(table + ".txt", "w") as fh:
+        fh.write("\r\n".join(lines[:50]) + "\r\n\n\n" + "\n".join(lines[50:]))
+    assert run_cli(["call"] + args, env=env) == got
+    import gzip
+    with open(table + ".txt", "rb") as src:
+        data = src.read()
+    with gzip.open(table + ".txt", "wb") as dst:
+        dst.write(data)
+    assert run_cli(["call"] + args) == got
 
 
 def test_sars_cov2_panel_config_c1(tmp_path, golden_dir):
