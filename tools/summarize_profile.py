@@ -11,10 +11,11 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key in ("scan_filter_kernel", "scan_hits_kernel", "call_isolated_kernel", "ref_scan_kernel", "rows_kernel",
-                "map_insert_kernel", "genotype_kernel", "cover_kernel", "blk_pop_kernel", "summary_kernel"):
+    for key in ("scan_filter_kernel", "scan_probe_kernel", "scan_hits_kernel", "scan_bin_gate_kernel", "scan_bin_kernel", "iso_cover_kernel<false>",
+                "iso_cover_kernel<true>", "iso_genotype_kernel", "ref_scan_kernel", "rows_kernel", "map_insert_kernel", "genotype_kernel",
+                "cover_kernel", "blk_pop_kernel", "summary_kernel"):
         if key in name:
-            return key + ("<35,43>" if "ILi35ELi43E" in name else "")
+            return key + ("<35,43>" if ("ILi35ELi43E" in name or "<35, 43" in name) else "")
     return name[:60]
 
 
@@ -33,7 +34,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
     for r in csv.DictReader(open(f)):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
-    if not any(s in k for s in ("scan_filter", "scan_hits", "call_isolated")):
+    if not any(s in k for s in ("scan_filter", "scan_probe", "scan_hits", "scan_bin", "iso_cover_kernel<false>", "iso_genotype")):
         continue
     print(k)
     for c in sorted(acc[k]):
@@ -48,7 +49,7 @@ for f in glob.glob(os.path.join(out, "cal_FETCH_SIZE", "**", "*counter_collectio
     for r in csv.DictReader(open(f)):
         if "scan_filter" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             cal.append(float(r["Counter_Value"]))
-k = "scan_filter_kernel"
+k = next((x for x in acc if x.startswith("scan_filter_kernel")), "scan_filter_kernel")
 if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
     rows = None
     try:
@@ -67,6 +68,6 @@ if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         print("== filter-kernel HBM traffic per launch ==")
         print("stream-only FETCH_SIZE %.6g KB for a known %.6g B stream -> calibration factor %.3f" % (fetch_cal_kb, stream, factor))
         print("FETCH_SIZE %.6g KB, WRITE_SIZE %.6g KB -> %.4g B per launch (algorithmic %.4g B)" % (fetch_kb, write_kb, traffic, 44.0 * rows))
-        json.dump({"kernel": k, "units_per_launch": rows, "bf_bits": bf_bits, "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb,
+        json.dump({"kernel": "scan_filter_kernel", "units_per_launch": rows, "bf_bits": bf_bits, "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb,
                    "write_size_kb": write_kb, "fetch_calibration_factor": factor, "calibration": "FETCH_SIZE of the same kernel with only its 20 B/row stream (scan_ablate=3)",
                    "algorithmic_bytes_per_launch": 44.0 * rows}, open(os.path.join(out, "traffic_scan_filter.json"), "w"), indent=1)
