@@ -66,3 +66,73 @@ def test_clustered_variants(tmp_path, seed, haploid, k, strip):
     assert "SIG 2 " in want and " lone" in want          # multi-allelic and lone blocks occur in every case
     if seed in (1, 4):
         assert "," in want.split("SIG", 1)[1]            # ... and so does the sliding (allele >= k) signature
+
+
+def _write_case(tmp_path, gt_rows, samples, fmt="GT", seed=7, spacing=9):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    seq = "".join(rng.choice(list("ACGT"), size=400 + spacing * len(gt_rows)))
+    fa, vcf = str(tmp_path / "g.fa"), str(tmp_path / "g.vcf")
+    with open(fa, "w") as fh:
+        fh.write(">1\n%s\n" % seq)
+    with open(vcf, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"af\">\n"
+                 "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##contig=<ID=1,length=%d>\n" % len(seq))
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n")
+        for i, cols in enumerate(gt_rows):
+            pos = 200 + spacing * i
+            ref = seq[pos]
+            alts = [b for b in "ACGT" if b != ref][:2]
+            fh.write("1\t%d\t.\t%s\t%s\t.\t.\tAF=0.2,0.1\t%s\t%s\n" % (pos + 1, ref, ",".join(alts), fmt, "\t".join(cols)))
+    return fa, vcf
+
+
+@pytest.mark.parametrize("haploid", [False, True])
+def test_gt_column_forms(tmp_path, haploid):
+    """What the one-pass GT reader has to take: missing alleles, mixed ploidy inside a record (the padded array the
+    reference gets from htslib), multi-digit and signed tokens, extra sub-fields, GT not first in FORMAT."""
+    samples = ["S%d" % i for i in range(6)]
+    rows = [
+        ["0|1", "1|0", "0/1", "./.", ".", "2|1"],
+        ["0", "1", "2", ".", "0", "1"],                        # haploid columns: the reference pairs each with the NEXT sample's value
+        ["0|1", "1", "0/0", "1|2", "2", "0"],                  # mixed ploidy: padded with vector_end
+        ["0|1:9:x", "1|1:3", "0/2:.", ".:.", "1|0", "0|0:7"],  # extra sub-fields
+        ["00|1", "+1|0", "1|02", "0|0", "0|1", "2|2"],         # atoi forms
+        ["0|1|1", "1|0|0", "0|0|0", "0|0|1", "1|1|1", "0|2|0"],  # triploid: only the first two are used
+    ]
+    fa, vcf = _write_case(tmp_path, rows, samples)
+    opt = pipeline.Options(haploid=haploid, k=21, ref_k=29)
+    for for_index in (True, False):
+        assert cli_dump(fa, vcf, opt, for_index) == oracle_dump(fa, vcf, opt, for_index)
+    # GT as the second FORMAT key
+    rows2 = [["5:" + c.split(":")[0] for c in r] for r in rows[:3]]
+    fa, vcf = _write_case(tmp_path, rows2, samples, fmt="DP:GT")
+    assert cli_dump(fa, vcf, opt, False) == oracle_dump(fa, vcf, opt, False)
+
+
+@pytest.mark.parametrize("haploid,phased", [(True, True), (False, True), (False, False)])
+def test_large_panel_sparse_sample_walk(tmp_path, haploid, phased):
+    """A panel of 3,000 samples where most are all-reference: the enumerator walks only the samples that carry a
+    non-reference allele on the chain, and must still find every pick the reference's all-samples loop finds
+    (including the all-reference pick, and picks that exist only through unphased mixing)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n_s, n_v = 3000, 60
+    samples = ["P%d" % i for i in range(n_s)]
+    sep = "|" if phased else "/"
+    rows = []
+    for v in range(n_v):
+        carriers = set(rng.choice(n_s, size=int(rng.integers(0, 12)), replace=False).tolist())
+        if v % 17 == 3:
+            carriers = set(range(n_s)) - set(rng.choice(n_s, size=5, replace=False).tolist())   # a common variant
+        cols = []
+        for s in range(n_s):
+            if s in carriers:
+                a, b = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+                cols.append(str(b) if haploid else "%d%s%d" % (a, sep, b))
+            else:
+                cols.append("0" if haploid else "0%s0" % sep)
+        rows.append(cols)
+    fa, vcf = _write_case(tmp_path, rows, samples, spacing=7)
+    opt = pipeline.Options(haploid=haploid, k=21, ref_k=29)
+    assert cli_dump(fa, vcf, opt, True) == oracle_dump(fa, vcf, opt, True)

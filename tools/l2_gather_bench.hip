@@ -1,5 +1,5 @@
 // Microbenchmark behind DESIGN.md's bound for the scan's filter kernel: how many independent, uniformly random
-// 8-byte reads per second one MI355X sustains from a table of F bytes (F = 256 KiB .. 64 MiB: L2-resident up to
+// 8-byte reads per second one MI355X sustains from a table of F bytes (F = 16 KiB .. 1 GiB: L2-resident up to
 // 4 MiB per XCD), alone and beside a non-temporal 20-byte-per-lane stream shaped like the k-mer table.
 //   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/l2_gather_bench tools/l2_gather_bench.hip && gpurun_out/l2_gather_bench
 #include <hip/hip_runtime.h>
@@ -71,12 +71,12 @@ int main()
     CK(hipMalloc(&hi, n * 8));
     CK(hipMalloc(&lo, n * 8));
     CK(hipMalloc(&cnt, n * 4));
-    CK(hipMalloc(&table, 64ULL << 20));
+    CK(hipMalloc(&table, 1ULL << 30));
     CK(hipMalloc(&sink, 8));
     CK(hipMemset(hi, 1, n * 8));
     CK(hipMemset(lo, 2, n * 8));
     CK(hipMemset(cnt, 3, n * 4));
-    CK(hipMemset(table, 5, 64ULL << 20));
+    CK(hipMemset(table, 5, 1ULL << 30));
     CK(hipMemset(sink, 0, 8));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -108,7 +108,7 @@ int main()
                time(bench<true, false, 16>, 0), time(bench<true, true, 16>, m4), time(bench<true, false, 17>, 0), time(bench<true, true, 17>, m4),
                time(bench<true, false, 18>, 0), time(bench<true, true, 18>, m4), time(bench<true, false, 19>, 0), time(bench<true, true, 19>, m4));
     }
-    for (int lg = 14; lg <= 26; lg += 2) {
+    for (int lg = 14; lg <= 30; lg += (lg < 26 ? 2 : 1)) {
         const uint64_t words = (1ULL << lg) / 8;
         const float g = time(bench<false, true>, words - 1), sg = time(bench<true, true>, words - 1);
         printf("table %6llu KiB: gather only %.3f ms = %.3g reads/s | stream + gather %.3f ms = %.3g rows/s (stream only + gather only = %.3f)\n",
