@@ -233,6 +233,42 @@ class Block {
         return out;
     }
 
+    // extract() of a block for which is_lone_short() holds, without its containers: the only chain is the variant
+    // itself, each allele carried by a panel haplotype has one signature of one k-mer (the allele centred at k/2
+    // between its reference flanks); emit(allele, kmer) once per such allele.  Same clipping and the same
+    // exceptions as the general form.
+    template <class F> void extract_lone(const std::string &reference, bool haploid, F emit) const
+    {
+        const Variant &v = vars[0];
+        if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) return;
+        uint64_t carried = 0;
+        for (size_t g = 0; g < v.genotypes.size(); ++g) { // build_alleles_combs on a chain of one
+            carried |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
+            if (!haploid) {
+                carried |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
+                (void)v.phasing.at(g);
+            }
+        }
+        for (int a = 0; a < v.n_alleles(); ++a) {
+            if (!((carried >> a) & 1)) continue;
+            const std::string &al = v.allele(a);
+            const int alen = (int)al.size();
+            const int missing_prefix = k / 2 - alen / 2, missing_suffix = (k + 1) / 2 - (alen - alen / 2);
+            std::string kmer = substr_clip(reference, (long)v.ref_pos - missing_prefix, missing_prefix);
+            kmer += al;
+            kmer += substr_clip(reference, (long)v.ref_pos + v.ref_size, missing_suffix);
+            emit(a, kmer);
+        }
+    }
+    // every block: the fast form where it applies
+    std::vector<AlleleSignatures> signatures(const std::string &reference, bool haploid) const
+    {
+        if (!is_lone_short()) return extract(reference, haploid);
+        std::vector<AlleleSignatures> result(1);
+        extract_lone(reference, haploid, [&](int a, const std::string &kmer) { result[0][a].push_back({kmer}); });
+        return result;
+    }
+
     // extract_kmers, var_block.hpp:95-219
     std::vector<AlleleSignatures> extract(const std::string &reference, bool haploid) const
     {

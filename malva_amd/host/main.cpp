@@ -336,6 +336,11 @@ int index_main(const Options &o)
     };
     std::vector<std::string> used;
     const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &, const std::string &reference) {
+        if (vb.is_lone_short()) { // nearly every block of a SNP panel: no containers
+            vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
+            flush(false);
+            return;
+        }
         const auto sigs = vb.extract(reference, o.haploid); // main.cpp:349
         for (const auto &per_allele : sigs)                  // add_kmers_to_bf, main.cpp:122-144
             for (const auto &as : per_allele)
@@ -864,7 +869,7 @@ int dump_main(const Options &o)
     }
     const bool for_index = o.kmc_path == "index";
     for_each_block(vcf, o, refs, for_index, nullptr, [&](Block &vb, const std::string &, const std::string &reference) {
-        const auto sigs = vb.extract(reference, o.haploid);
+        const auto sigs = vb.signatures(reference, o.haploid);
         std::cout << "BLOCK " << vb.vars.size() << (vb.is_lone_short() ? " lone" : "") << "\n";
         for (size_t vi = 0; vi < vb.vars.size(); ++vi) {
             const Variant &v = vb.vars[vi];

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--samples", type=int, default=2)
     ap.add_argument("--b", type=int, default=4)
     ap.add_argument("--dir", default="/tmp/cli_scale")
+    ap.add_argument("--no-run", action="store_true", help="only write the input files")
     args = ap.parse_args()
     n, nk = int(args.variants), int(args.kmers)
     os.makedirs(args.dir, exist_ok=True)
@@ -62,6 +63,8 @@ def main():
             fh.write("".join("%s\t%d\n" % (rows[j, :R].tobytes().decode(), cnt[j]) for j in range(i, min(nk, i + 100000))))
     print("inputs: %d SNPs x %d samples (%.0f MB VCF), %d k-mers as text, %.0f s" %
           (n, args.samples, os.path.getsize(vcf) / 1e6, nk, time.time() - t0), flush=True)
+    if args.no_run:
+        return
     common = ["-k", str(K), "-r", str(R), "-b", str(args.b), "-f", "AF", fa, vcf, prefix]
     for sub in ("index", "call"):
         t0 = time.time()
