@@ -35,7 +35,7 @@ bin/malva-geno: $(HOSTSRC) $(HOSTHDR) malva_amd/lib/libmalva_hip.so
 
 oracle: oracle/libmalva_oracle.so
 oracle/libmalva_oracle.so: oracle/malva_oracle.c
-	$(CC) -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Wall -o $@ $< -lm
+	$(CC) -O2 -ffp-contract=off -fPIC -shared -fvisibility=hidden -Wall -pthread -o $@ $< -lm
 
 # The reference build: its own xxhash.c (which includes its own xxhash.h),
 # untouched, straight from the read-only checkout.  Skipped on machines that do

@@ -259,10 +259,20 @@ def main():
         ok_gt = bool(np.array_equal(d_g1[:nv].cpu().numpy(), og1) and np.array_equal(d_g2[:nv].cpu().numpy(), og2)
                      and np.array_equal(d_gq[:nv].cpu().numpy(), ogq) and np.array_equal(d_cov[:2 * nv].cpu().numpy().view(np.uint32), ocov))
         parity_sample = {"bf_counters_equal": ok_bf, "map_values_equal": ok_map, "gt_gq_cov_equal": ok_gt, "rows": ns, "variants": nv}
+        # the same loop on every host core the box gives this job (atomic, commuting counter adds;
+        # tests/test_synth_cpu.py shows the results equal the single-threaded ones) -- after the parity check,
+        # because it adds to the same oracle counters
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        ns_all = int(min(n_rows, ns * max(1, cores // 2)))
+        t0 = time.perf_counter()
+        ocapi.kmc_scan_packed_mt(octx, obf, omap, hi[:ns_all], lo[:ns_all], cnt[:ns_all], K, R, cores)
+        cpu_all_s = time.perf_counter() - t0
         cpu_baseline = {"value": ns / cpu_scan_s, "unit": "kmers/s", "cores": 1, "kind": "port",
                         "sample": "first %d rows of rank 0's table through oracle/malva_oracle.c (single thread, as the reference); "
                                   "%d variants through its loop-B restatement" % (ns, nv),
-                        "variants_per_s": nv / cpu_geno_s}
+                        "variants_per_s": nv / cpu_geno_s,
+                        "all_cores": {"value": ns_all / cpu_all_s, "unit": "kmers/s", "cores": cores, "kind": "port",
+                                      "sample": "first %d rows, the same loop on %d threads sharing one index (atomic adds)" % (ns_all, cores)}}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_scan_filter.json")

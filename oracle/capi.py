@@ -50,6 +50,7 @@ def lib():
             "mo_add_kmers": (None, [vp, vp, vp, sz, sz, vp]),
             "mo_kmc_scan": (None, [vp, vp, vp, vp, sz, vp, sz, C.c_int, C.c_int]),
             "mo_kmc_scan_packed": (None, [vp, vp, vp, vp, vp, vp, sz, C.c_int, C.c_int]),
+            "mo_kmc_scan_packed_mt": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_int, C.c_int, C.c_int]),
             "mo_ref_scan": (C.c_int, [vp, vp, vp, sz, C.c_int, C.c_int]),
             "mo_lookup_weights": (None, [vp, vp, vp, sz, sz, vp, vp]),
             "mo_set_coverages": (None, [vp, vp, vp, u64, vp]),
@@ -204,6 +205,14 @@ def kmc_scan_packed(context_bf: BF, bf: BF, ref_bf: KMAP, hi, lo, counts, k, ref
     lo = np.ascontiguousarray(lo, dtype=np.uint64)
     counts = np.ascontiguousarray(counts, dtype=np.uint32)
     lib().mo_kmc_scan_packed(context_bf.h, bf.h, ref_bf.h, _p(hi), _p(lo), _p(counts), hi.shape[0], k, ref_k)
+
+
+def kmc_scan_packed_mt(context_bf: BF, bf: BF, ref_bf: KMAP, hi, lo, counts, k, ref_k, n_threads):
+    """the same scan by n_threads threads with atomic (commuting) counter updates: identical results"""
+    hi = np.ascontiguousarray(hi, dtype=np.uint64)
+    lo = np.ascontiguousarray(lo, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    return lib().mo_kmc_scan_packed_mt(context_bf.h, bf.h, ref_bf.h, _p(hi), _p(lo), _p(counts), hi.shape[0], k, ref_k, n_threads)
 
 
 def ref_scan(bf: BF, context_bf: BF, reference: bytes, k, ref_k):

@@ -466,6 +466,68 @@ MO_API void mo_kmc_scan_packed(mo_bf *context_bf, mo_bf *bf, mo_kmap *ref_bf, co
     }
 }
 
+/* The same loop run by T threads over T contiguous slices of the table: the "whole box" CPU figure of
+ * SURVEY 8(d)(ii), next to the single-threaded one that mirrors the reference.  Both counter updates are wrapping
+ * sums (Appendix A.2), so they commute; the threads share the read-only bits / rank / keys and add atomically.
+ * Results are identical to mo_kmc_scan_packed (tests/test_oracle_pins.py). */
+#include <pthread.h>
+typedef struct {
+    mo_bf *context_bf, *bf;
+    mo_kmap *ref_bf;
+    const uint64_t *hi, *lo;
+    const uint32_t *counts;
+    size_t begin, end;
+    int k, ref_k;
+} mt_job;
+static void *mt_scan_slice(void *arg)
+{
+    static const char L[4] = {'A', 'C', 'G', 'T'};
+    mt_job *j = (mt_job *)arg;
+    const int k = j->k, ref_k = j->ref_k;
+    char ctx[ref_k + 1], kmer[k + 1];
+    size_t i;
+    for (i = j->begin; i < j->end; i++) {
+        int q;
+        for (q = 0; q < ref_k; q++) {
+            int sh = 2 * (ref_k - 1 - q);
+            uint64_t c = sh >= 64 ? (j->hi[i] >> (sh - 64)) : (j->lo[i] >> sh);
+            ctx[q] = L[c & 3];
+        }
+        ctx[ref_k] = 0;
+        strncpy(kmer, ctx + ((ref_k - k) / 2), (size_t)k); /* main.cpp:493 */
+        kmer[k] = 0;
+        { /* ref_bf.increment, main.cpp:495 */
+            char ck[k + 1];
+            size_t n = km_canon(kmer, ck);
+            int64_t e = km_find(j->ref_bf, ck, n, km_strhash(ck, n));
+            if (e >= 0) __atomic_fetch_add((uint32_t *)&j->ref_bf->eval[e], (uint32_t)j->counts[i], __ATOMIC_RELAXED);
+        }
+        if (!mo_bf_test_key(j->context_bf, ctx) && j->bf->mode) { /* main.cpp:496-498 */
+            uint64_t b = bf_hash(kmer) % j->bf->size;
+            if (bf_bit(j->bf, b)) __atomic_fetch_add(&j->bf->counts[bf_rank(j->bf, b)], (uint16_t)j->counts[i], __ATOMIC_RELAXED);
+        }
+    }
+    return NULL;
+}
+MO_API int mo_kmc_scan_packed_mt(mo_bf *context_bf, mo_bf *bf, mo_kmap *ref_bf, const uint64_t *hi, const uint64_t *lo,
+                                 const uint32_t *counts, size_t n, int k, int ref_k, int n_threads)
+{
+    pthread_t th[256];
+    mt_job job[256];
+    int t, started = 0;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    for (t = 0; t < n_threads; t++) {
+        job[t] = (mt_job){context_bf, bf, ref_bf, hi, lo, counts, n * (size_t)t / (size_t)n_threads,
+                          n * (size_t)(t + 1) / (size_t)n_threads, k, ref_k};
+        if (pthread_create(&th[t], NULL, mt_scan_slice, &job[t]) != 0) break;
+        started++;
+    }
+    for (t = 0; t < started; t++) pthread_join(th[t], NULL);
+    for (t = started; t < n_threads; t++) mt_scan_slice(&job[t]); /* threads that could not start: run here */
+    return started;
+}
+
 /* Reference-context scan, main.cpp:383-401, one contig.  bf must be in read
  * mode only for symmetry with the reference (test_key ignores the mode).
  * std::string(reference, pos, n) clips at the end of the contig; a contig

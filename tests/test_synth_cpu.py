@@ -53,3 +53,33 @@ def test_kmer_table_shape_and_counts():
     ch, cl = synth.canonical_m(hi, lo, 43)
     assert np.array_equal(ch, hi) and np.array_equal(cl, lo)      # rows are canonical, as KMC lists them
     assert int(hi.max()) < (1 << 22)                                # 86 bits
+
+
+def test_threaded_oracle_scan_equals_the_single_threaded_one():
+    """bench.py's all-cores CPU figure: the oracle's scan loop over slices of the table with atomic counter adds.
+    Wrapping sums commute, so every counter must equal the single-threaded restatement's; a tiny filter makes
+    many rows collide on the same counters and heavy counts make the 16-bit cells wrap."""
+    k, ref_k, bits = 35, 43, 1 << 16
+    panel = synth.snp_panel(1500, 5)
+    sig, valid = synth.signature_rows(panel, k)
+    is_ref = np.zeros(sig.shape[0], dtype=np.uint8)
+    is_ref[panel.var_allele_off[:-1]] = 1
+    rows = np.zeros((int(valid.sum()), 40), dtype=np.uint8)
+    rows[:, :k] = sig[valid]
+    hi, lo, cnt = synth.kmer_table(panel, 60000, k, ref_k, 6)
+    cnt = (cnt.astype(np.uint32) * 977) % 60000 + 1
+    res = []
+    for threads in (0, 1, 5):
+        obf, octx, omap = ocapi.BF(bits), ocapi.BF(bits), ocapi.KMAP()
+        ocapi.add_kmers(obf, omap, rows, is_ref[valid])
+        obf.switch_mode()
+        ocapi.ref_scan(obf, octx, panel.genome.tobytes(), k, ref_k)
+        octx.switch_mode()
+        if threads:
+            assert ocapi.kmc_scan_packed_mt(octx, obf, omap, hi, lo, cnt, k, ref_k, threads) == threads
+        else:
+            ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        res.append((obf.counts().copy(), dict(omap.items())))
+    assert res[0][0].any() and any(res[0][1].values())
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and r[1] == res[0][1]
