@@ -26,7 +26,12 @@ def main():
     ap.add_argument("--b", type=int, default=4)
     ap.add_argument("--dir", default="/tmp/cli_scale")
     ap.add_argument("--no-run", action="store_true", help="only write the input files")
+    ap.add_argument("--c5", type=int, default=0, metavar="CLUSTERS",
+                    help="config C5 shape instead: CLUSTERS clusters of SNPs / MNPs / indels / multi-allelic records (tests/vcf_synth.py), "
+                         "k=35 r=63 b=8, run haploid and diploid")
     args = ap.parse_args()
+    if args.c5:
+        return c5(args)
     n, nk = int(args.variants), int(args.kmers)
     os.makedirs(args.dir, exist_ok=True)
     fa, vcf, prefix = (os.path.join(args.dir, x) for x in ("ref.fa", "panel.vcf", "sample.kmercount"))
@@ -78,6 +83,32 @@ def main():
         print("== malva-geno %s: %.2f s wall = %.3g variants/s\n   %s" % (sub, dt, n / dt, "\n   ".join(phases)), flush=True)
     nrec = sum(1 for l in open(os.path.join(args.dir, "out.vcf")) if not l.startswith("#"))
     print("records written by call: %d" % nrec)
+
+
+def c5(args):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import vcf_synth
+    os.makedirs(args.dir, exist_ok=True)
+    for haploid in (True, False):
+        prefix = os.path.join(args.dir, "c5h" if haploid else "c5d")
+        t0 = time.time()
+        contigs, records = vcf_synth.make_case(prefix, 77, n_clusters=args.c5, haploid=haploid, n_samples=8, k=K, vcf_strip_chr=True)
+        vcf_synth.donor_table(contigs, records, 63, 77, prefix + ".kmers.txt")
+        n = len(records)
+        print("C5 %s inputs: %d records in %d clusters, %d-base genome, %d k-mers, %.0f s" %
+              ("haploid" if haploid else "diploid", n, args.c5, sum(len(s_) for s_ in contigs.values()),
+               sum(1 for _ in open(prefix + ".kmers.txt")), time.time() - t0), flush=True)
+        common = ["-k", str(K), "-r", "63", "-b", "8", "-p"] + (["-1"] if haploid else []) + [prefix + ".fa", prefix + ".vcf", prefix + ".kmers"]
+        for sub in ("index", "call"):
+            t0 = time.time()
+            with open(prefix + ".out.vcf", "w") as so:
+                r = subprocess.run([os.path.join(ROOT, "bin", "malva-geno"), sub] + common, stdout=so, stderr=subprocess.PIPE, text=True)
+            dt = time.time() - t0
+            if r.returncode:
+                print(r.stderr[-2000:])
+                raise SystemExit("malva-geno %s failed" % sub)
+            notes = [l for l in r.stderr.split("\n") if "on the host" in l]
+            print("== malva-geno %s: %.2f s wall = %.3g records/s %s" % (sub, dt, n / dt, " ".join(notes)), flush=True)
 
 
 if __name__ == "__main__":
