@@ -391,6 +391,23 @@ int fill_geno_params(mg_ctx *c, float error_rate, int max_cov, int haploid, Geno
 
 // ---- lifetime -------------------------------------------------------------------
 
+// Every entry point may be called from any host thread: make the context's device current for the calling thread
+// (HIP's current device is per thread; a thread that never called hipSetDevice sits on device 0).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const mg_ctx *c)
+    {
+        int cur = -1;
+        if (c && hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) hipSetDevice(prev); // leave the caller's thread as it was
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 MG_EXPORT int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, uint64_t bf_bits)
 {
     if (!out) return MG_ERR_ARG;
@@ -434,6 +451,7 @@ MG_EXPORT int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, ui
 
 MG_EXPORT int mg_destroy(mg_ctx *c)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
@@ -473,6 +491,7 @@ MG_EXPORT const char *mg_last_error(const mg_ctx *c) { return c ? c->err.c_str()
 
 MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -480,12 +499,14 @@ MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 }
 MG_EXPORT int mg_synchronize(mg_ctx *c)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }
 MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 {
+    const DeviceGuard on_device(c);
     if (!c || !name) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
@@ -523,6 +544,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 
 MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
 {
+    const DeviceGuard on_device(c);
     if (!c || !name || !value) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) *value = c->use_summary;
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
@@ -548,6 +570,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
 
 MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride, size_t n)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     // the reference lets add_key run in read mode too (the bit is set, the rank goes stale); refuse that
@@ -557,6 +580,7 @@ MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride
 }
 MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint8_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -564,6 +588,7 @@ MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, 
 }
 MG_EXPORT int mg_debug_bf_index(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint64_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -572,6 +597,7 @@ MG_EXPORT int mg_debug_bf_index(mg_ctx *c, int which, const char *rows, size_t s
 
 MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (b.blk) {
@@ -631,6 +657,7 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
 
 MG_EXPORT int mg_bf_increment(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, const uint32_t *counters)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (!c->bf[which].mode) return fail(c, MG_ERR_STATE, "BF::increment in write mode returns false");
@@ -639,6 +666,7 @@ MG_EXPORT int mg_bf_increment(mg_ctx *c, int which, const char *rows, size_t str
 }
 MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint16_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -650,6 +678,7 @@ MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t str
 }
 MG_EXPORT int mg_bf_info(mg_ctx *c, int which, uint64_t *size_bits, uint64_t *n_set, int *mode)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     if (size_bits) *size_bits = c->bf[which].size;
     if (n_set) *n_set = c->bf[which].nset;
@@ -661,6 +690,7 @@ MG_EXPORT int mg_bf_info(mg_ctx *c, int which, uint64_t *size_bits, uint64_t *n_
 
 MG_EXPORT int mg_map_insert(mg_ctx *c, const char *rows, size_t stride, size_t n)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     TRY(map_reserve(c, n));
@@ -680,6 +710,7 @@ MG_EXPORT int mg_map_insert(mg_ctx *c, const char *rows, size_t stride, size_t n
 }
 MG_EXPORT int mg_map_test(mg_ctx *c, const char *rows, size_t stride, size_t n, uint8_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -692,6 +723,7 @@ MG_EXPORT int mg_map_test(mg_ctx *c, const char *rows, size_t stride, size_t n, 
 }
 MG_EXPORT int mg_map_increment(mg_ctx *c, const char *rows, size_t stride, size_t n, const int32_t *counters)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!counters) return fail(c, MG_ERR_ARG, "counters is NULL");
@@ -707,6 +739,7 @@ MG_EXPORT int mg_map_increment(mg_ctx *c, const char *rows, size_t stride, size_
 }
 MG_EXPORT int mg_map_get_count(mg_ctx *c, const char *rows, size_t stride, size_t n, int32_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -758,6 +791,7 @@ int map_dump(mg_ctx *c, std::vector<u64> *klo, std::vector<u64> *khi, std::vecto
 
 MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
 {
+    const DeviceGuard on_device(c);
     if (!c || !n_keys) return MG_ERR_ARG;
     std::vector<u64> a, b;
     std::vector<u32> ids;
@@ -770,6 +804,7 @@ MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
 
 MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (len && !contig) return fail(c, MG_ERR_ARG, "contig is NULL");
     if (!c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_ref_scan needs `bf` finalised (main.cpp:378 precedes :383)");
@@ -861,6 +896,7 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
 
 MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     if (c->k < 17 || c->ref_k > MG_MAX_PACKED_K)
@@ -918,6 +954,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
 
 MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n == 0) return MG_OK;
     if (!hi || !lo || !cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
@@ -936,6 +973,7 @@ MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, con
 
 MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (!c->stats_valid) return fail(c, MG_ERR_STATE, "no scan has run");
     HIP_TRY(c, hipEventSynchronize(c->ev[3]));
@@ -956,6 +994,7 @@ MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, const uint64_t *lo, size_t n, uint32_t klen,
                                     uint64_t *out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     if (klen < 17 || klen > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed k-mers: 17 <= k <= 64");
     if (n == 0) return MG_OK;
@@ -975,6 +1014,7 @@ MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, co
 
 MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     if (n_bf) *n_bf = c->bf[0].nset;
@@ -983,6 +1023,7 @@ MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
 }
 MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t *n_map)
 {
+    const DeviceGuard on_device(c);
     if (!c || !d_ptr) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     BFState &b = c->bf[MG_BF_ALT];
@@ -1008,6 +1049,7 @@ MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t
 }
 MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
 {
+    const DeviceGuard on_device(c);
     if (!c || !d_out) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     const u64 nb = c->bf[0].nset, nm = c->map.rows_total;
@@ -1017,6 +1059,7 @@ MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
 }
 MG_EXPORT int mg_counters_import_device(mg_ctx *c, const void *d_in)
 {
+    const DeviceGuard on_device(c);
     if (!c || !d_in) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     const u64 nb = c->bf[0].nset, nm = c->map.rows_total;
@@ -1026,6 +1069,7 @@ MG_EXPORT int mg_counters_import_device(mg_ctx *c, const void *d_in)
 }
 MG_EXPORT int mg_counters_reset(mg_ctx *c)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
     if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
@@ -1039,6 +1083,7 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
                               const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
                               uint32_t *cov_out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n_rows));
     if (n_alleles == 0) return MG_OK;
     if (!sig_kmer_off || !allele_sig_off || !cov_out || (n_rows && !is_ref)) return fail(c, MG_ERR_ARG, "NULL descriptor");
@@ -1071,6 +1116,7 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
                           float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status,
                           double *probs, const uint64_t *var_gt_off)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!cov || !freq || !var_allele_off || !gt1 || !gt2 || !gq || !status) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -1110,6 +1156,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
                               const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
                               uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off ||
@@ -1161,6 +1208,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
 
 MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 {
+    const DeviceGuard on_device(c);
     if (!c || (len && !ascii)) return MG_ERR_ARG;
     if (c->d_ref) hipFree(c->d_ref);
     c->d_ref = nullptr;
@@ -1178,6 +1226,7 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
                                       void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs,
                                       const void *d_var_gt_off)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
@@ -1206,6 +1255,7 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
                                uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status, double *probs,
                                const uint64_t *var_gt_off)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!pos || !var_allele_off || !allele_off || !allele_pool || !freq || !present_mask || !flags || !cov_out || !gt1 || !gt2 ||
@@ -1266,6 +1316,7 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
 
 MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *counts_out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (words_out) HIP_TRY(c, hipMemcpy(words_out, b.words, b.nwords * 8, hipMemcpyDeviceToHost));
@@ -1283,6 +1334,7 @@ MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *
 MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *words, const uint16_t *counts,
                            uint64_t n_counts)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (size_bits != b.size) return fail(c, MG_ERR_ARG, "filter size %llu does not match the context (%llu)",
@@ -1319,6 +1371,7 @@ MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, c
 // ascending positions of the set bits (= counter order) instead of gigabytes of zeros.
 MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out, uint16_t *counts_out)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (!b.mode) return fail(c, MG_ERR_STATE, "sparse export needs the filter finalised (rank directory)");
@@ -1336,6 +1389,7 @@ MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out,
 MG_EXPORT int mg_bf_import_sparse(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *positions,
                                   const uint16_t *counts, uint64_t n)
 {
+    const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (size_bits != b.size) return fail(c, MG_ERR_ARG, "filter size %llu does not match the context (%llu)",
@@ -1392,6 +1446,7 @@ void unpack_lform(u64 lo, u64 hi, u32 k, char *out)
 // expected to be k long, as every signature k-mer of the reference is).
 MG_EXPORT int mg_map_export(mg_ctx *c, char *rows_out, size_t stride, int32_t *vals_out)
 {
+    const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     std::vector<u64> lo, hi;
     std::vector<u32> ids;
@@ -1420,6 +1475,7 @@ MG_EXPORT int mg_map_export(mg_ctx *c, char *rows_out, size_t stride, int32_t *v
 }
 MG_EXPORT int mg_map_import(mg_ctx *c, const char *rows, size_t stride, size_t n, const int32_t *vals)
 {
+    const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     const u64 row0 = c->map.rows_total;

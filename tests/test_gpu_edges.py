@@ -157,3 +157,31 @@ def test_full_size_properties_b4():
     a = fresh(); a.kmc_scan(hi[: n_rows // 2], lo[: n_rows // 2], cnt[: n_rows // 2]); a_bf, a_map = state(a); a.close()
     b = fresh(); b.kmc_scan(hi[n_rows // 2:], lo[n_rows // 2:], cnt[n_rows // 2:]); b_bf, b_map = state(b); b.close()
     assert np.array_equal((a_bf + b_bf) & 0xFFFF, w_bf) and np.array_equal(a_map + b_map, w_map)
+
+
+def test_calls_from_another_host_thread():
+    """the ABI has no thread affinity: every entry point makes the context's device current for the calling thread
+    (a thread that never touched HIP sits on device 0) and puts the previous one back.  Build on this thread, scan and
+    read back on another, compare with the oracle."""
+    import threading
+    from gpu_util import build_index_pair, map_values_by_key
+    k, ref_k, bits = 35, 43, 1 << 20
+    panel = synth.snp_panel(800, 61)
+    hi, lo, cnt = synth.kmer_table(panel, 30000, k, ref_k, 62)
+    ctx = Context(k, ref_k, bits)
+    obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
+    ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+    got = {}
+
+    def work():
+        try:
+            ctx.kmc_scan(hi, lo, cnt)
+            got["counts"] = ctx.bf_export(BF_ALT)[3]
+            got["map"] = map_values_by_key(ctx)
+        except Exception as e:          # surfaced on the main thread below
+            got["error"] = e
+    t = threading.Thread(target=work)
+    t.start(); t.join()
+    assert "error" not in got, got.get("error")
+    assert np.array_equal(got["counts"], obf.counts()) and got["map"] == dict(omap.items())
+    ctx.close()
