@@ -6,6 +6,7 @@
 // libmalva_hip.so through include/malva_hip.h.  There is no CPU implementation of
 // those in this program: without a GPU it stops at mg_create.
 #include <fcntl.h>
+#include <future>
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -657,7 +658,15 @@ int call_main(const Options &o)
     const std::string best_default = o.haploid ? "0" : "0/0";
     auto n_gt = [&](uint64_t A) { return o.haploid ? A : A * (A + 1) / 2; };
 
-    auto run_and_print = [&]() {
+    // One batch: device round trips, then the records' text.  Runs on a worker thread while this thread parses the
+    // next batch (the ABI has no thread affinity); batches are handed over one at a time, so output order is kept.
+    struct Job {
+        std::vector<Rec> recs;
+        Batch iso, gen;
+    };
+    auto process = [&](Job &job) {
+        std::vector<Rec> &recs = job.recs;
+        Batch &iso = job.iso, &gen = job.gen;
         if (iso.n()) {
             const size_t n = iso.n(), na = iso.var_allele_off.back();
             iso.cov.resize(na); iso.g1.resize(n); iso.g2.resize(n); iso.gq.resize(n); iso.status.resize(n);
@@ -779,9 +788,18 @@ int call_main(const Options &o)
             out += ":" + std::to_string(b.gq[r.slot]) + "\n";
         }
         std::cout << out;
+    };
+    std::future<void> in_flight;
+    auto run_and_print = [&]() {
+        if (in_flight.valid()) in_flight.get(); // the previous batch is out (or its exception comes back here)
+        auto job = std::make_shared<Job>();
+        job->recs = std::move(recs);
+        job->iso = std::move(iso);
+        job->gen = std::move(gen);
         recs.clear();
         iso = Batch();
         gen = Batch();
+        in_flight = std::async(std::launch::async, [&process, job]() { process(*job); });
     };
 
     auto prefix_of = [&](const Variant &v) {
@@ -848,6 +866,7 @@ int call_main(const Options &o)
         if (recs.size() >= batch_records) run_and_print();
     });
     run_and_print();
+    in_flight.get();
     std::cout.flush();
     pelapsed("Processed " + std::to_string(n) + " variants");
     pelapsed("Execution completed");

@@ -32,7 +32,7 @@ def oracle_dump(fa, vcf, opt, for_index):
     return "\n".join(out) + "\n"
 
 
-def cli_dump(fa, vcf, opt, for_index):
+def cli_dump(fa, vcf, opt, for_index, pool=None):
     if not os.path.exists(BIN):
         pytest.fail("bin/malva-geno not built: run `make cli`")
     cmd = [BIN, "dump-kmers", "-k", str(opt.k), "-r", str(opt.ref_k), "-f", opt.freq_key]
@@ -41,7 +41,8 @@ def cli_dump(fa, vcf, opt, for_index):
     if opt.strip_chr:
         cmd.append("-p")
     cmd += [fa, vcf, "index" if for_index else "call"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ) if pool is None else dict(os.environ, MALVA_GENO_VCF_POOL=str(pool))   # record decoding inline / by the thread pool
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stdout
 
@@ -103,7 +104,9 @@ def test_gt_column_forms(tmp_path, haploid):
     fa, vcf = _write_case(tmp_path, rows, samples)
     opt = pipeline.Options(haploid=haploid, k=21, ref_k=29)
     for for_index in (True, False):
-        assert cli_dump(fa, vcf, opt, for_index) == oracle_dump(fa, vcf, opt, for_index)
+        want = oracle_dump(fa, vcf, opt, for_index)
+        assert cli_dump(fa, vcf, opt, for_index, pool=0) == want
+        assert cli_dump(fa, vcf, opt, for_index, pool=1) == want
     # GT as the second FORMAT key
     rows2 = [["5:" + c.split(":")[0] for c in r] for r in rows[:3]]
     fa, vcf = _write_case(tmp_path, rows2, samples, fmt="DP:GT")
@@ -135,4 +138,6 @@ def test_large_panel_sparse_sample_walk(tmp_path, haploid, phased):
         rows.append(cols)
     fa, vcf = _write_case(tmp_path, rows, samples, spacing=7)
     opt = pipeline.Options(haploid=haploid, k=21, ref_k=29)
-    assert cli_dump(fa, vcf, opt, True) == oracle_dump(fa, vcf, opt, True)
+    want = oracle_dump(fa, vcf, opt, True)
+    assert cli_dump(fa, vcf, opt, True) == want            # 3,000 sample columns: the pool decodes
+    assert cli_dump(fa, vcf, opt, True, pool=0) == want
