@@ -5,7 +5,10 @@
 // enumeration"); it emits flat descriptors for mg_lookup_cover / mg_genotype, and
 // blocks that hold one short-allele variant bypass it (mg_call_isolated).
 #pragma once
+#include <climits>
+#include <exception>
 #include <set>
+#include <thread>
 #include <unordered_map>
 
 #include "io.hpp"
@@ -274,9 +277,42 @@ class Block {
     {
         std::vector<AlleleSignatures> result(vars.size());
         const PanelIndex panel = panel_index();
-        for (int vi = 0; vi < (int)vars.size(); ++vi) {
+        // the variants of a block are enumerated independently of one another: a large block (C1 has one of 8,724
+        // variants) is cut over the host cores, interleaved because chain counts vary along the block
+        const int n_threads = vars.size() < 64 ? 1 : (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+        if (n_threads > 1) {
+            std::vector<std::exception_ptr> errs((size_t)n_threads);
+            std::vector<int> err_at((size_t)n_threads, INT_MAX);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < n_threads; ++t)
+                pool.emplace_back([&, t]() {
+                    for (int vi = t; vi < (int)vars.size(); vi += n_threads) {
+                        try {
+                            extract_one(vi, reference, haploid, panel, result[(size_t)vi]);
+                        } catch (...) {
+                            errs[(size_t)t] = std::current_exception();
+                            err_at[(size_t)t] = vi;
+                            return;
+                        }
+                    }
+                });
+            for (auto &th : pool) th.join();
+            int first = -1;
+            for (int t = 0; t < n_threads; ++t)
+                if (errs[(size_t)t] && (first < 0 || err_at[(size_t)t] < err_at[(size_t)first])) first = t;
+            if (first >= 0) std::rethrow_exception(errs[(size_t)first]); // the one the sequential walk would have met first
+            return result;
+        }
+        for (int vi = 0; vi < (int)vars.size(); ++vi) extract_one(vi, reference, haploid, panel, result[(size_t)vi]);
+        return result;
+    }
+
+    // the signatures of variant vi (one element of extract()'s result)
+    void extract_one(int vi, const std::string &reference, bool haploid, const PanelIndex &panel, AlleleSignatures &out) const
+    {
+        {
             const Variant &v = vars[(size_t)vi];
-            if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) continue;
+            if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) return;
             const auto combs = combine(chains(vi, -1), chains(vi, +1), vi);
             for (const auto &comb : combs) {
                 // get_ref_subs, var_block.hpp:682-702
@@ -323,11 +359,10 @@ class Block {
                         }
                         sig.push_back(std::move(kmer));
                     }
-                    result[(size_t)vi][v.allele_index(mid_allele)].push_back(std::move(sig));
+                    out[v.allele_index(mid_allele)].push_back(std::move(sig));
                 }
             }
         }
-        return result;
     }
 };
 

@@ -120,7 +120,7 @@ def test_large_panel_sparse_sample_walk(tmp_path, haploid, phased):
     (including the all-reference pick, and picks that exist only through unphased mixing)."""
     import numpy as np
     rng = np.random.default_rng(3)
-    n_s, n_v = 3000, 60
+    n_s, n_v = 3000, 90      # one block of 90 variants: enumerated by the thread pool (>= 64)
     samples = ["P%d" % i for i in range(n_s)]
     sep = "|" if phased else "/"
     rows = []
