@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One-off soak: many random clustered panels through bin/malva-geno (GPU) vs the oracle pipeline.
-usage: python tools/soak_cli.py [first_seed] [n]"""
+"""Test infrastructure (not collected by pytest; lives here because it uses the oracle). One-off soak: many random clustered panels through bin/malva-geno (GPU) vs the oracle pipeline.
+usage: python tests/soak_cli.py [first_seed] [n]"""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import vcf_synth  # noqa: E402
 from oracle import pipeline  # noqa: E402
 
