@@ -336,19 +336,57 @@ int index_main(const Options &o)
         }
     };
     std::vector<std::string> used;
+    // General blocks are enumerated by all host cores, a few thousand at a time, and their k-mers appended in block
+    // order: the insertion order (which decides the exact map's counter ids) stays a function of the input alone.
+    std::vector<Block> waiting;
+    std::vector<const std::string *> waiting_ref;
+    auto enumerate_waiting = [&]() {
+        const size_t nb = waiting.size();
+        if (!nb) return;
+        std::vector<std::vector<AlleleSignatures>> sigs(nb);
+        const unsigned n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, nb}));
+        std::vector<std::exception_ptr> errs(n_threads);
+        std::vector<size_t> err_at(n_threads, SIZE_MAX);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t]() {
+                for (size_t b = t; b < nb; b += n_threads) {
+                    try {
+                        sigs[b] = waiting[b].extract(*waiting_ref[b], o.haploid); // main.cpp:349
+                    } catch (...) {
+                        errs[t] = std::current_exception();
+                        err_at[t] = b;
+                        return;
+                    }
+                }
+            });
+        for (auto &th : pool) th.join();
+        size_t first = SIZE_MAX;
+        for (unsigned t = 0; t < n_threads; ++t)
+            if (errs[t] && (first == SIZE_MAX || err_at[t] < err_at[first])) first = t;
+        if (first != SIZE_MAX) std::rethrow_exception(errs[first]);
+        for (size_t b = 0; b < nb; ++b) {
+            for (const auto &per_allele : sigs[b]) // add_kmers_to_bf, main.cpp:122-144
+                for (const auto &as : per_allele)
+                    for (const auto &sig : as.second)
+                        for (const auto &kmer : sig) (as.first == 0 ? ref_rows : alt_rows).add(kmer);
+            flush(false);
+        }
+        waiting.clear();
+        waiting_ref.clear();
+    };
     const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &, const std::string &reference) {
         if (vb.is_lone_short()) { // nearly every block of a SNP panel: no containers
             vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
             flush(false);
             return;
         }
-        const auto sigs = vb.extract(reference, o.haploid); // main.cpp:349
-        for (const auto &per_allele : sigs)                  // add_kmers_to_bf, main.cpp:122-144
-            for (const auto &as : per_allele)
-                for (const auto &sig : as.second)
-                    for (const auto &kmer : sig) (as.first == 0 ? ref_rows : alt_rows).add(kmer);
-        flush(false);
+        waiting_ref.push_back(&reference);
+        waiting.push_back(std::move(vb));
+        vb = Block((int)o.k);
+        if (waiting.size() >= 4096) enumerate_waiting();
     });
+    enumerate_waiting();
     flush(true);
     pelapsed("Processed " + std::to_string(n) + " variants");
     dev.check(mg_bf_finalize(dev.ctx, MG_BF_ALT), "mg_bf_finalize(bf)"); // main.cpp:378
