@@ -100,9 +100,17 @@ inline bool read_fasta(const std::string &path, bool strip_chr, Reference &out)
             if (!out.seqs.count(name)) out.names.push_back(name);
             cur = &out.seqs[name];
             cur->clear();
-        } else if (cur) {
-            for (char c : line)
-                if (!isspace((unsigned char)c)) cur->push_back((char)toupper((unsigned char)c));
+        } else if (cur) { // sequence line: appended whole, upper-cased in place; white space inside a line is rare
+            const size_t at = cur->size();
+            cur->append(line);
+            bool spaces = false;
+            char *p = &(*cur)[0];
+            for (size_t i = at, e = cur->size(); i < e; ++i) { // toupper / isspace of the "C" locale, inlined
+                const unsigned char c = (unsigned char)p[i];
+                p[i] = (char)(c >= 'a' && c <= 'z' ? c - 32 : c);
+                spaces = spaces || c == ' ' || (c >= '\t' && c <= '\r');
+            }
+            if (spaces) cur->erase(std::remove_if(cur->begin() + (long)at, cur->end(), [](char c) { return isspace((unsigned char)c) != 0; }), cur->end());
         }
     }
     return true;
