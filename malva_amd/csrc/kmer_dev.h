@@ -221,13 +221,39 @@ __device__ __forceinline__ void gate_set(const BFView &b, u64 idx)
     if (b.pregate) atomicOr((unsigned long long *)&b.pregate[pre_word(b, idx)], pre_mask(b, idx));
 }
 // rank(idx) = ones in [0, idx)   (rank_support_v<1>, bloom_filter.hpp:108)
+// The 512-bit block that holds idx is one aligned 64-byte piece of `words` (the array is padded to whole blocks):
+// it is read whole, four 16-byte loads issued together with the directory entry, and both the bit and the ones in
+// front of it come out of registers -- one round trip instead of a word-by-word walk behind the bit test.
+__device__ __forceinline__ bool bf_bit_rank(const BFView &b, u64 idx, u32 *rank)
+{
+    const u64 blk = idx >> 9;
+    const u32 wi = (u32)(idx >> 6) & 7, bi = (u32)idx & 63;
+    const uint4 *p = reinterpret_cast<const uint4 *>(b.words + blk * 8);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    u32 r = b.blk ? b.blk[blk] : 0;
+    const u64 w[8] = {q0.x | (u64)q0.y << 32, q0.z | (u64)q0.w << 32, q1.x | (u64)q1.y << 32, q1.z | (u64)q1.w << 32,
+                      q2.x | (u64)q2.y << 32, q2.z | (u64)q2.w << 32, q3.x | (u64)q3.y << 32, q3.z | (u64)q3.w << 32};
+    bool bit = false;
+#pragma unroll
+    for (u32 j = 0; j < 8; ++j) {
+        const u64 m = j < wi ? ~0ULL : j == wi ? (1ULL << bi) - 1 : 0ULL;
+        r += (u32)__popcll(w[j] & m);
+        if (j == wi) bit = (w[j] >> bi) & 1;
+    }
+    *rank = r;
+    return bit;
+}
 __device__ __forceinline__ u32 bf_rank(const BFView &b, u64 idx)
 {
-    const u64 blk = idx >> 9, we = idx >> 6;
-    u32 r = b.blk[blk];
-    for (u64 w = blk * 8; w < we; ++w) r += (u32)__popcll(b.words[w]);
-    if (idx & 63) r += (u32)__popcll(b.words[we] & ((1ULL << (idx & 63)) - 1));
+    u32 r;
+    bf_bit_rank(b, idx, &r);
     return r;
+}
+// counter of slot idx as the reference reads it (0 when the bit is clear)   bloom_filter.hpp:115-125
+__device__ __forceinline__ u32 bf_count_at(const BFView &b, u64 idx)
+{
+    u32 r;
+    return bf_bit_rank(b, idx, &r) ? b.counts[r] : 0;
 }
 
 // ---- exact map view --------------------------------------------------------------
@@ -267,16 +293,19 @@ __device__ __forceinline__ u64 xxh3_lform(U128 key, int len)
 {
     return len >= 17 ? xxh3_packed(key, len) : xxh3_bytes(LformIn{key}, len);
 }
-// slot of a published key, or -1
-__device__ __forceinline__ long long map_find(const MapView &m, U128 key, u64 h)
+// Counter id of a published key (index into vals[]), or -1.  Read side only (every insert has completed: the host
+// orders the kernels), so a slot is read whole -- two 16-byte loads issued together, one round trip -- instead of
+// tag, then key low, then key high, then id, each waiting for the one before on the same line.
+__device__ __forceinline__ long long map_find_id(const MapView &m, U128 key, u64 h)
 {
     const u64 mask = (1ULL << m.cap_log2) - 1;
     u64 s = map_slot(m, h);
     const u32 tag = map_tag(h);
     for (;;) {
-        const u32 t = m.slots[s].tag;
-        if (t == 0) return -1;
-        if (t == tag && m.slots[s].klo == key.lo && m.slots[s].khi == key.hi) return (long long)s;
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 a = p[0], b = p[1]; // {tag, id, klo}, {khi, pad}
+        if (a.x == 0) return -1;
+        if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) return (long long)a.y;
         s = (s + 1) & mask;
     }
 }

@@ -436,7 +436,8 @@ MG_EXPORT int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, ui
         b.nwords = (bf_bits + 63) / 64;
         b.n_blk = (b.nwords + 7) / 8;
         b.mod = make_mod(bf_bits);
-        if (hipMalloc(&b.words, b.nwords * 8) != hipSuccess || hipMemsetAsync(b.words, 0, b.nwords * 8, c->stream) != hipSuccess) {
+        // whole 512-bit blocks (zero padded): lookups read the block of a bit in one go
+        if (hipMalloc(&b.words, b.n_blk * 64) != hipSuccess || hipMemsetAsync(b.words, 0, b.n_blk * 64, c->stream) != hipSuccess) {
             mg_destroy(c);
             return MG_ERR_NOMEM;
         }

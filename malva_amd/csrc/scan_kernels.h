@@ -446,8 +446,8 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
             const u64 word = bf.words[idx >> 6];
-            const long long s = map_find(map, c, h);
-            if (s >= 0) atomicAdd(&map.vals[map.slots[s].id], count); // ref_bf.increment (main.cpp:495)
+            const long long id = map_find_id(map, c, h);
+            if (id >= 0) atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
             hit = (word >> (idx & 63)) & 1;
         }
         st.push(hit, m, count);
@@ -469,9 +469,13 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
         const U128 l = mform_to_lform(m, r);
         const U128 cc = canon_sub(m, l, r, 0, r);
         const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
-        if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
+        // (the centre k-mer's slot and its block are computed and requested before the context bit is looked at:
+        // both random reads are in flight together)
         const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
-        atomicAdd(&bf.counts[bf_rank(bf, idx)], hits.cnt[j]);             // bf.increment (main.cpp:498)
+        u32 rank;
+        bf_bit_rank(bf, idx, &rank);
+        if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
+        atomicAdd(&bf.counts[rank], hits.cnt[j]);                         // bf.increment (main.cpp:498)
     }
 }
 

@@ -54,11 +54,11 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
         U128 key;
         long long s = -1;
         const bool regular = pack_regular(can, k, (int)map.klen, &key);
-        if (regular) s = map_find(map, key, xxh3_bytes(can, k));
+        if (regular) s = map_find_id(map, key, xxh3_bytes(can, k)); // counter id, or -1
         if (irregular) irregular[i] = regular ? 0 : 1;
         if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
-        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[map.slots[s].id], counters[i]);
-        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+        if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[s], counters[i]);
+        if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[s] : 0;
         return;
     }
     const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
@@ -69,10 +69,11 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
     }
     if (OP == OP_BF_TEST) ((u8 *)out)[i] = bf_bit(bf, idx);
     if (OP == OP_BF_INC) {
-        if (bf_bit(bf, idx)) atomicAdd(&bf.counts[bf_rank(bf, idx)], counters[i]);
+        u32 r;
+        if (bf_bit_rank(bf, idx, &r)) atomicAdd(&bf.counts[r], counters[i]);
     }
-    if (OP == OP_BF_GET) ((uint16_t *)out)[i] = bf.counts && bf_bit(bf, idx) ? (uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
-    if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts && bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+    if (OP == OP_BF_GET) ((uint16_t *)out)[i] = bf.counts ? (uint16_t)bf_count_at(bf, idx) : 0;
+    if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts ? (i32)(uint16_t)bf_count_at(bf, idx) : 0;
 }
 
 // KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows

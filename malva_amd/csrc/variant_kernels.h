@@ -58,13 +58,13 @@ template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, in
     if (is_ref) {
         U128 key;
         if (pack_regular(can, k, (int)map.klen, &key)) {
-            const long long s = map_find(map, key, xxh3_bytes(can, k));
-            if (s >= 0) return (i32)map.vals[map.slots[s].id];
+            const long long id = map_find_id(map, key, xxh3_bytes(can, k));
+            if (id >= 0) return (i32)map.vals[id];
         }
         return 0;
     }
     const u64 idx = mod_size(xxh3_bytes(can, k), bf.mod);
-    return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+    return (i32)(uint16_t)bf_count_at(bf, idx);
 }
 // 2-bit code of an upper-case ACGT byte without a table: (b >> 1) & 3 gives A0 C1 G3 T2
 __device__ __forceinline__ u32 acgt_code(u32 b, bool *ok)
@@ -194,11 +194,11 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
                 const U128 key = lt128(L, rc) ? L : rc;
                 const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
                 if (a == 0) {
-                    const long long s = map_find(map, key, h);
-                    w = s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+                    const long long id = map_find_id(map, key, h);
+                    w = id >= 0 ? (i32)map.vals[id] : 0;
                 } else {
                     const u64 idx = mod_size(h, bf.mod);
-                    w = bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+                    w = (i32)(uint16_t)bf_count_at(bf, idx);
                 }
                 if (w > 0) out = (u32)(float)(u32)w;
             }
@@ -343,11 +343,11 @@ __device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, co
             const u64 h = xxh3_packed(key, len);
             if (is_ref) {
                 if (len != (int)map.klen) return 0;
-                const long long s = map_find(map, key, h);
-                return s >= 0 ? (i32)map.vals[map.slots[s].id] : 0;
+                const long long id = map_find_id(map, key, h);
+                return id >= 0 ? (i32)map.vals[id] : 0;
             }
             const u64 idx = mod_size(h, bf.mod);
-            return bf_bit(bf, idx) ? (i32)(uint16_t)bf.counts[bf_rank(bf, idx)] : 0;
+            return (i32)(uint16_t)bf_count_at(bf, idx);
         }
     }
     return weight_bytes(LdsBytes{buf}, len, is_ref, bf, map);
