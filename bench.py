@@ -65,6 +65,12 @@ def main():
                     help="N ranks share GPU 0 and reduce over gloo: exercises the multi-rank code path on a 1-GPU box (numbers meaningless)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: whatever a library prints there (gloo's rank banner, RCCL warnings)
+    # goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from malva_amd import BF_ALT, BF_CTX, Context, synth
@@ -323,7 +329,8 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity_sample": parity_sample,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
