@@ -261,14 +261,22 @@ __device__ __forceinline__ u32 bf_count_at(const BFView &b, u64 idx)
 // written, >= 2 fingerprint of a published key.  Keys are canonical L-forms.
 // ids[slot] = smallest insertion row that carried the key; vals[id] is its counter,
 // so the counter vector has the same layout on every GPU that replays the inserts.
-// One slot = one 32-byte record, so a probe touches ONE cache line whether it ends at an empty slot, a
-// foreign tag or the key itself (four parallel arrays cost up to four random 128-byte lines per hit).
-struct __attribute__((aligned(32))) MapSlot {
+// One slot = one 64-byte record, so a probe touches ONE cache line whether it ends at an empty slot, a foreign tag
+// or the key itself (four parallel arrays cost up to four random 128-byte lines per hit).  The record also has
+// room for two entries of the FILTER's directory: a set bit of `bf` (position + 1) and its rank, i.e. the index of
+// its counter.  Both stores are addressed from the filter slot idx = XXH3 % size (map_home), so the scan's probe
+// of a table row -- "is this k-mer a key of the exact map?" and "is bit idx of bf set, and which counter is it?" --
+// reads one record instead of a filter word, a rank-directory entry and a map slot on three different lines.
+// The bit array and its rank directory stay what the ABI's per-k-mer calls, export and the reference scan use.
+struct __attribute__((aligned(64))) MapSlot {
     u32 tag; // 0 empty, 1 being written, >= 2 fingerprint of a published key
     u32 id;  // smallest insertion row that carried the key: index of its counter in vals[]
     u64 klo, khi;
+    u32 brank[2]; // filter entries (written once `bf` is finalised): counter index of set bit bidx[j] - 1
+    u64 bidx[2];  // 0 = free, else position of a set bit of `bf` + 1; slot 0 fills before slot 1
     u64 pad;
 };
+static_assert(sizeof(MapSlot) == 64, "one record per 64 bytes");
 struct MapView {
     MapSlot *slots;
     u32 *vals;
@@ -276,10 +284,11 @@ struct MapView {
     u32 klen; // every key held here is exactly this long (other lengths live in the host overflow list)
 };
 // The table is addressed with the same XXH3 value the Bloom filter uses for the
-// k-mer (one hash per table row serves both stores): slot from the top bits, tag
-// from the middle.
+// k-mer (one hash per table row serves both stores): home record from the filter slot
+// idx = h % size (so that a bit of the filter, which knows only idx, lands in the same
+// record as the keys that hash to it), tag from the middle of h.
 __device__ __forceinline__ u32 map_tag(u64 h) { return (u32)(h >> 8) | 0x80000000u; }
-__device__ __forceinline__ u64 map_slot(const MapView &m, u64 h) { return h >> (64 - m.cap_log2); }
+__device__ __forceinline__ u64 map_home(const MapView &m, u64 idx) { return (idx * 0x9E3779B97F4A7C15ULL) >> (64 - m.cap_log2); }
 // XXH3 of the ASCII rendering of a packed canonical key (any length 1..64)
 struct LformIn {
     U128 v;
@@ -294,18 +303,67 @@ __device__ __forceinline__ u64 xxh3_lform(U128 key, int len)
     return len >= 17 ? xxh3_packed(key, len) : xxh3_bytes(LformIn{key}, len);
 }
 // Counter id of a published key (index into vals[]), or -1.  Read side only (every insert has completed: the host
-// orders the kernels), so a slot is read whole -- two 16-byte loads issued together, one round trip -- instead of
+// orders the kernels), so a record is read whole -- 16-byte loads issued together, one round trip -- instead of
 // tag, then key low, then key high, then id, each waiting for the one before on the same line.
-__device__ __forceinline__ long long map_find_id(const MapView &m, U128 key, u64 h)
+__device__ __forceinline__ long long map_find_id(const MapView &m, U128 key, u64 h, u64 idx)
 {
     const u64 mask = (1ULL << m.cap_log2) - 1;
-    u64 s = map_slot(m, h);
+    u64 s = map_home(m, idx);
     const u32 tag = map_tag(h);
     for (;;) {
         const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
-        const uint4 a = p[0], b = p[1]; // {tag, id, klo}, {khi, pad}
+        const uint4 a = p[0], b = p[1]; // {tag, id, klo}, {khi, brank}
         if (a.x == 0) return -1;
         if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) return (long long)a.y;
+        s = (s + 1) & mask;
+    }
+}
+// Counter index (rank) of bit idx of the finalised filter, or -1 when the bit is clear.
+__device__ __forceinline__ long long bucket_rank(const MapView &m, u64 idx)
+{
+    const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
+    u64 s = map_home(m, idx);
+    for (;;) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 b = p[1], c = p[2]; // {khi, brank0, brank1}, {bidx0, bidx1}
+        const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+        if (b0 == want) return (long long)b.z;
+        if (b1 == want) return (long long)b.w;
+        if (b0 == 0 || b1 == 0) return -1;
+        s = (s + 1) & mask;
+    }
+}
+// Both questions of the scan's probe in one walk (the two chains share their records).
+__device__ __forceinline__ void bucket_probe(const MapView &m, U128 key, u64 h, u64 idx, long long *map_id, long long *rank)
+{
+    const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
+    u64 s = map_home(m, idx);
+    const u32 tag = map_tag(h);
+    bool map_open = true, bf_open = true;
+    *map_id = -1;
+    *rank = -1;
+    for (;;) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 a = p[0], b = p[1], c = p[2];
+        if (map_open) {
+            if (a.x == 0) map_open = false;
+            else if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) {
+                *map_id = (long long)a.y;
+                map_open = false;
+            }
+        }
+        if (bf_open) {
+            const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+            if (b0 == want) {
+                *rank = (long long)b.z;
+                bf_open = false;
+            } else if (b1 == want) {
+                *rank = (long long)b.w;
+                bf_open = false;
+            } else if (b0 == 0 || b1 == 0)
+                bf_open = false;
+        }
+        if (!map_open && !bf_open) return;
         s = (s + 1) & mask;
     }
 }

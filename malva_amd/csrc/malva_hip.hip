@@ -259,6 +259,19 @@ void map_free_table(MapState &m)
     hipFree(m.slots);
     m.slots = nullptr;
 }
+// (re)write the filter's directory into the records: whenever the finalised filter's bits or the table change
+int build_bf_entries(mg_ctx *c)
+{
+    const BFState &alt = c->bf[MG_BF_ALT];
+    MapState &m = c->map;
+    if (!m.slots || !alt.mode || !alt.blk) return MG_OK;
+    const u64 cap = 1ULL << m.cap_log2;
+    hipLaunchKernelGGL(bf_entries_clear_kernel, dim3(nblocks(cap)), dim3(TPB), 0, c->stream, m.slots, cap);
+    hipLaunchKernelGGL(bf_entries_build_kernel, dim3(nblocks(alt.nwords)), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), view(c), alt.nwords);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+
 // make room for `extra` more insertion rows: table load <= 1/4, vals indexable by row
 int map_reserve(mg_ctx *c, u64 extra)
 {
@@ -278,9 +291,15 @@ int map_reserve(mg_ctx *c, u64 extra)
         m.vals = nv;
         m.vals_cap = ncap;
     }
+    // records: load <= 1/4 for the keys, and two filter-directory entries per record at load <= 1/4 as well
+    const BFState &alt = c->bf[MG_BF_ALT];
+    const u64 dir_entries = alt.mode ? alt.nset : 0;
     u32 want = 10;
-    while ((1ULL << want) < need_rows * 4) ++want;
-    if (!m.slots) return map_alloc(c, m, want);
+    while ((1ULL << want) < need_rows * 4 || (1ULL << want) < dir_entries * 2) ++want;
+    if (!m.slots) {
+        TRY(map_alloc(c, m, want));
+        return build_bf_entries(c);
+    }
     if (want > m.cap_log2) {
         MapView ov{};
         ov.slots = m.slots;
@@ -289,10 +308,11 @@ int map_reserve(mg_ctx *c, u64 extra)
         m.slots = nullptr;
         TRY(map_alloc(c, m, want));
         MapView nv = view(c);
-        hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << ov.cap_log2)), dim3(TPB), 0, c->stream, ov, nv);
+        hipLaunchKernelGGL(map_rehash_kernel, dim3(nblocks(1ULL << ov.cap_log2)), dim3(TPB), 0, c->stream, ov, nv, c->bf[MG_BF_ALT].mod);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipFree(ov.slots);
+        return build_bf_entries(c); // the new records start without the filter's directory
     }
     return MG_OK;
 }
@@ -653,6 +673,13 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
+    if (which == MG_BF_ALT) { // the filter's directory inside the exact map's records (MapSlot)
+        const bool had = c->map.slots != nullptr;
+        const u32 before = c->map.cap_log2;
+        TRY(map_reserve(c, 0)); // creates or grows the table if the directory needs it, and then writes the directory
+        if (had && c->map.cap_log2 == before) TRY(build_bf_entries(c));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return MG_OK;
 }
 
@@ -890,7 +917,7 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
                        view(c), open, hits, c->d_hit_count);
     if (timed) hipEventRecord(c->ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, 1024u)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
-                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), hits, c->d_hit_count);
+                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
     if (timed) hipEventRecord(c->ev[3], c->stream);
 }
 } // namespace

@@ -445,10 +445,10 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
-            const u64 word = bf.words[idx >> 6];
-            const long long id = map_find_id(map, c, h);
+            long long id, rank; // one record answers both: exact-map key?  bit idx of bf set?
+            bucket_probe(map, c, h, idx, &id, &rank);
             if (id >= 0) atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
-            hit = (word >> (idx & 63)) & 1;
+            hit = rank >= 0;
         }
         st.push(hit, m, count);
         st.flush_if_above(CAP - TPB, hits, &counters[1]);
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
 }
 
 template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFView bf, BFView ctx, RowList hits,
+__global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFView bf, BFView ctx, MapView map, RowList hits,
                                                         unsigned long long *counters)
 {
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
@@ -472,10 +472,9 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
         // (the centre k-mer's slot and its block are computed and requested before the context bit is looked at:
         // both random reads are in flight together)
         const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
-        u32 rank;
-        bf_bit_rank(bf, idx, &rank);
+        const long long rank = bucket_rank(map, idx);                     // set for every row of this list
         if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
-        atomicAdd(&bf.counts[rank], hits.cnt[j]);                         // bf.increment (main.cpp:498)
+        if (rank >= 0) atomicAdd(&bf.counts[rank], hits.cnt[j]);          // bf.increment (main.cpp:498)
     }
 }
 

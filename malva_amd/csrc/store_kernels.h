@@ -54,7 +54,10 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
         U128 key;
         long long s = -1;
         const bool regular = pack_regular(can, k, (int)map.klen, &key);
-        if (regular) s = map_find_id(map, key, xxh3_bytes(can, k)); // counter id, or -1
+        if (regular) { // counter id, or -1
+            const u64 h = xxh3_bytes(can, k);
+            s = map_find_id(map, key, h, mod_size(h, bf.mod));
+        }
         if (irregular) irregular[i] = regular ? 0 : 1;
         if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
         if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[s], counters[i]);
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
     gate_set(bf, mod_size(h, bf.mod));
     const u32 tag = map_tag(h);
     const u64 mask = (1ULL << map.cap_log2) - 1;
-    u64 s = map_slot(map, h);
+    u64 s = map_home(map, mod_size(h, bf.mod));
     const u32 my_id = row0 + (u32)i;
     bool done = false;
     // every lane retries inside one common loop, so a lane that owns a slot in
@@ -132,10 +135,10 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
 __global__ void __launch_bounds__(TPB) map_clear_kernel(MapSlot *slots, u64 cap)
 {
     const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (s < cap) slots[s] = MapSlot{0u, 0xFFFFFFFFu, 0, 0, 0};
+    if (s < cap) slots[s] = MapSlot{0u, 0xFFFFFFFFu, 0, 0, {0u, 0u}, {0ULL, 0ULL}, 0};
 }
 // move every published entry of an old table into a new (larger, empty) one
-__global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm)
+__global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView newm, ModDesc mod)
 {
     const u64 s0 = (u64)blockIdx.x * TPB + threadIdx.x;
     if (s0 >= (1ULL << oldm.cap_log2)) return;
@@ -143,11 +146,45 @@ __global__ void __launch_bounds__(TPB) map_rehash_kernel(MapView oldm, MapView n
     U128 key{oldm.slots[s0].klo, oldm.slots[s0].khi};
     const u64 h = xxh3_lform(key, (int)oldm.klen);
     const u64 mask = (1ULL << newm.cap_log2) - 1;
-    u64 s = map_slot(newm, h);
+    u64 s = map_home(newm, mod_size(h, mod));
     while (atomicCAS(&newm.slots[s].tag, 0u, map_tag(h)) != 0u) s = (s + 1) & mask;
     newm.slots[s].klo = key.lo;
     newm.slots[s].khi = key.hi;
     newm.slots[s].id = oldm.slots[s0].id;
+}
+// The filter's directory inside the records (MapSlot::bidx / brank): cleared, then one entry per set bit of the
+// finalised filter.  Bit positions are distinct, so an entry is claimed with one CAS and never looked at again here.
+__global__ void __launch_bounds__(TPB) bf_entries_clear_kernel(MapSlot *slots, u64 cap)
+{
+    const u64 s = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (s >= cap) return;
+    slots[s].bidx[0] = slots[s].bidx[1] = 0;
+    slots[s].brank[0] = slots[s].brank[1] = 0;
+}
+__global__ void __launch_bounds__(TPB) bf_entries_build_kernel(BFView bf, MapView m, u64 nwords)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 bits = bf.words[w];
+    if (!bits) return;
+    u32 rank = bf_rank(bf, w * 64);
+    const u64 mask = (1ULL << m.cap_log2) - 1;
+    while (bits) {
+        const u64 pos = w * 64 + (u64)__builtin_ctzll(bits);
+        bits &= bits - 1;
+        u64 s = map_home(m, pos);
+        for (;;) {
+            int j = -1;
+            if (atomicCAS((unsigned long long *)&m.slots[s].bidx[0], 0ULL, (unsigned long long)(pos + 1)) == 0ULL) j = 0;
+            else if (atomicCAS((unsigned long long *)&m.slots[s].bidx[1], 0ULL, (unsigned long long)(pos + 1)) == 0ULL) j = 1;
+            if (j >= 0) {
+                m.slots[s].brank[j] = rank;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+        ++rank;
+    }
 }
 // gate bits of every published key (after a filter import rebuilt the gate from the bits alone)
 __global__ void __launch_bounds__(TPB) map_gate_kernel(MapView m, BFView bf)

@@ -58,7 +58,8 @@ template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, in
     if (is_ref) {
         U128 key;
         if (pack_regular(can, k, (int)map.klen, &key)) {
-            const long long id = map_find_id(map, key, xxh3_bytes(can, k));
+            const u64 h = xxh3_bytes(can, k);
+            const long long id = map_find_id(map, key, h, mod_size(h, bf.mod));
             if (id >= 0) return (i32)map.vals[id];
         }
         return 0;
@@ -209,12 +210,13 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
                 const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
                 const U128 key = lt128(L, rc) ? L : rc;
                 const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
+                const u64 idx = mod_size(h, bf.mod);
                 if (a == 0) {
-                    const long long id = map_find_id(map, key, h);
+                    const long long id = map_find_id(map, key, h, idx);
                     w = id >= 0 ? (i32)map.vals[id] : 0;
-                } else {
-                    const u64 idx = mod_size(h, bf.mod);
-                    w = (i32)(uint16_t)bf_count_at(bf, idx);
+                } else { // the filter's directory entry sits in the exact map's record of the same slot
+                    const long long rank = bucket_rank(map, idx);
+                    w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
                 }
                 if (w > 0) out = (u32)(float)(u32)w;
             }
@@ -359,7 +361,7 @@ __device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, co
             const u64 h = xxh3_packed(key, len);
             if (is_ref) {
                 if (len != (int)map.klen) return 0;
-                const long long id = map_find_id(map, key, h);
+                const long long id = map_find_id(map, key, h, mod_size(h, bf.mod));
                 return id >= 0 ? (i32)map.vals[id] : 0;
             }
             const u64 idx = mod_size(h, bf.mod);
