@@ -416,6 +416,8 @@ __global__ void __launch_bounds__(TPB) scan_bin_gate_kernel(int k_rt, int r_rt, 
 }
 
 
+// (Probe and hit pass fused in one kernel -- no second list, no re-hash -- was measured: 0.276 ms against 0.100 +
+// 0.050 ms; a third of the lanes running a second XXH3 while the others idle costs more than the list.)
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
                                                          unsigned long long *counters)
