@@ -86,6 +86,7 @@ struct mg_ctx {
     int scan_rows = 2;    // table rows per thread per iteration of the filter kernel (swept: 2 is best)
     int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
+    u32 iso_call_no = 0;  // mg_call_isolated calls so far (see iso_cover_kernel)
     int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
     int pre_k = 1;      // bits per entry of the coarse gate (chosen at finalize from the load)
     int use_pregate = 1;
@@ -1262,14 +1263,16 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
     if (!c->map.slots) TRY(map_reserve(c, 0));
     GenoParams p;
     TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
-    u32 *need_slow = (u32 *)(c->d_hit_count + 3); // a spare word of the scan's counter block
-    HIP_TRY(c, hipMemsetAsync(need_slow, 0, 4, c->stream));
+    u32 *need_slow = (u32 *)(c->d_hit_count + 3); // a spare word of the scan's counter block, compared with a call number
+    if (++c->iso_call_no == 0) c->iso_call_no = 1;  // (never 0: the scan clears the block) so that nothing has to reset it
     hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
-                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow);
+                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
+                       c->iso_call_no);
     hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
-                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow);
+                       (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
+                       c->iso_call_no);
     hipLaunchKernelGGL(iso_genotype_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (u64)n_vars, (const u32 *)d_var_allele_off,
                        (const float *)d_freq, p, (const u32 *)d_cov_out, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status,
                        (double *)d_probs, (const u64 *)d_var_gt_off);

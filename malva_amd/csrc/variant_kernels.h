@@ -138,17 +138,18 @@ __device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
 // registers.  Fused in one kernel (the first form) the likelihoods' 193 VGPRs left 2 waves per SIMD to hide the
 // lookups' latency.  The coverage words written by the first kernel and read by the second are 8 B per SNP.
 //   iso_cover_kernel<false>: TWO threads per variant, alleles split by parity (a biallelic SNP: REF on one, ALT on
-//       the other); a signature with a non-ACGT base is only marked (ISO_SLOW) and `*need_slow` raised
-//   iso_cover_kernel<true>: the same grid, returns at once unless `*need_slow`; redoes the marked alleles byte-wise
+//       the other); a signature with a non-ACGT base is only marked (ISO_SLOW) and `*need_slow` set to this call's number
+//   iso_cover_kernel<true>: the same grid, returns at once unless `*need_slow` holds this call's number; redoes the marked alleles byte-wise
 //       (kept out of the first kernel because its generic XXH3 alone needs 190 VGPRs)
 //   iso_genotype_kernel: one thread per variant
 constexpr u32 ISO_SLOW = 0xFFFFFFFFu; // never a coverage: those are float-rounded counts below 2^31
 template <bool SLOW>
 __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off,
                                                         const u32 *allele_off, const u8 *pool, const u64 *present_mask,
-                                                        const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow)
+                                                        const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow,
+                                                        u32 call_no)
 {
-    if (SLOW && *need_slow == 0) return;
+    if (SLOW && *need_slow != call_no) return;
     const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
     const u64 v = t >> 1;
     if (v >= n_vars) return;
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
             i32 w = 0;
             if (!fast) {
                 out = ISO_SLOW;
-                *need_slow = 1;
+                *need_slow = call_no;
             } else {
                 L = shl128(L, 2 * mp);
                 if (mp) L.lo |= lf >> (2 * (lmax - mp));                         // last mp bases of the left flank
