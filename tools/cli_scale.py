@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--variants", type=float, default=1e6)
     ap.add_argument("--kmers", type=float, default=2e6)
     ap.add_argument("--samples", type=int, default=2)
+    ap.add_argument("--spacing", type=int, default=100, help="bases between SNPs (below k/2 + 1 = 18 neighbours share k-mers: general blocks)")
     ap.add_argument("--b", type=int, default=4)
     ap.add_argument("--dir", default="/tmp/cli_scale")
     ap.add_argument("--no-run", action="store_true", help="only write the input files")
@@ -36,31 +37,39 @@ def main():
     os.makedirs(args.dir, exist_ok=True)
     fa, vcf, prefix = (os.path.join(args.dir, x) for x in ("ref.fa", "panel.vcf", "sample.kmercount"))
     t0 = time.time()
-    panel = synth.snp_panel(n, seed=20261003)
+    panel = synth.snp_panel(n, seed=20261003, spacing=args.spacing)
     g = panel.genome.tobytes().decode()
     with open(fa, "w") as fh:
         fh.write(">1\n")
         for i in range(0, len(g), 1 << 20):
             fh.write(g[i:i + (1 << 20)] + "\n")
     rng = np.random.default_rng(5)
-    # phased diploid samples; sample 0 carries 0|1 everywhere so that both alleles are present in the panel
-    gts = rng.integers(0, 2, size=(n, args.samples, 2), dtype=np.int8)
-    gts[:, 0, 0], gts[:, 0, 1] = 0, 1
+    # phased diploid samples; sample 0 carries 0|1 everywhere so that both alleles are present in the panel; the
+    # others carry the ALT allele with the record's AF (a panel is mostly 0|0)
+    af = panel.freq[1::2]
     ref = panel.pool[0::2].tobytes().decode()
     alt = panel.pool[1::2].tobytes().decode()
     with open(vcf, "w") as fh:
         fh.write("##fileformat=VCFv4.2\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"af\">\n"
                  "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##contig=<ID=1,length=%d>\n" % len(g))
         fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("S%d" % i for i in range(args.samples)) + "\n")
-        af = panel.freq[1::2]
-        out = []
-        for i in range(n):
-            gt = "\t".join("%d|%d" % (a, b) for a, b in gts[i])
-            out.append("1\t%d\t.\t%s\t%s\t.\t.\tAF=%.4f\tGT\t%s\n" % (panel.pos[i] + 1, ref[i], alt[i], af[i], gt))
-            if len(out) == 100000:
-                fh.write("".join(out))
-                out = []
-        fh.write("".join(out))
+        step = max(1, (64 << 20) // (4 * args.samples))
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            gts = (rng.random((b - a, args.samples, 2)) < af[a:b, None, None]).astype(np.uint8)
+            gts[:, 0, 0], gts[:, 0, 1] = 0, 1
+            cells = np.empty((b - a, args.samples, 4), dtype=np.uint8)   # "a|b\t"
+            cells[:, :, 0] = 48 + gts[:, :, 0]
+            cells[:, :, 1] = ord("|")
+            cells[:, :, 2] = 48 + gts[:, :, 1]
+            cells[:, :, 3] = ord("\t")
+            flat = cells.reshape(b - a, -1)
+            out = []
+            for i in range(a, b):
+                out.append("1\t%d\t.\t%s\t%s\t.\t.\tAF=%.4f\tGT\t" % (panel.pos[i] + 1, ref[i], alt[i], af[i]))
+                out.append(flat[i - a, :-1].tobytes().decode())
+                out.append("\n")
+            fh.write("".join(out))
     hi, lo, cnt = synth.kmer_table(panel, nk, K, R, seed=777)
     rows = synth.unpack_ascii(hi, lo, R)
     with open(prefix + ".txt", "w") as fh:
