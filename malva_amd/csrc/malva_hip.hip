@@ -1217,6 +1217,17 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     TRY(upload(c, c->s_open[0], pool, pool_len, &d[10]));
     TRY(upload(c, c->s_open[1], canon, na, &d[11]));
     TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
+    // per block: sorted positions? largest ref_size - min_size (they bound the chain walks, bk_chains)
+    std::vector<u8> blk_sorted(n_blocks, 1);
+    std::vector<u32> blk_max_gain(n_blocks, 0);
+    for (size_t b = 0; b < n_blocks; ++b)
+        for (u32 v = blk_var_off[b]; v < blk_var_off[b + 1]; ++v) {
+            if (v > blk_var_off[b] && pos[v] < pos[v - 1]) blk_sorted[b] = 0;
+            if (ref_size[v] >= min_size[v]) blk_max_gain[b] = std::max(blk_max_gain[b], ref_size[v] - min_size[v]);
+        }
+    void *d_sorted, *d_gain;
+    TRY(upload(c, c->s_bin[0], blk_sorted.data(), n_blocks, &d_sorted));
+    TRY(upload(c, c->s_bin[1], blk_max_gain.data(), 4 * n_blocks, &d_gain));
     void *d_cov, *d_ovf;
     TRY(scratch(c, c->s_out, 4 * na, &d_cov));
     TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
@@ -1225,6 +1236,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     B.var_block = (const u32 *)d[3]; B.pos = (const i32 *)d[4]; B.ref_size = (const u32 *)d[5]; B.min_size = (const u32 *)d[6];
     B.present = (const u8 *)d[7]; B.var_allele_off = (const u32 *)d[8]; B.allele_off = (const u32 *)d[9]; B.pool = (const u8 *)d[10];
     B.canon = (const u8 *)d[11]; B.gt = (const uint16_t *)d[12];
+    B.blk_sorted = (const u8 *)d_sorted; B.blk_max_gain = (const u32 *)d_gain;
     B.n_samples = n_samples; B.haploid = haploid; B.k = (int)c->k;
     hipLaunchKernelGGL(cover_blocks_kernel, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
                        (u32 *)d_cov, (u8 *)d_ovf);

@@ -250,6 +250,8 @@ struct BlockBatch {
     const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
     const u32 *blk_ref_len;   //            and its length
     const u32 *blk_var_off;   // [n_blocks + 1]
+    const u8 *blk_sorted;     // per block: positions never decrease along the block (any sane VCF)
+    const u32 *blk_max_gain;  //            max over its variants of ref_size - min_size
     const u32 *var_block;     // [n_vars] block of each variant
     const i32 *pos;           // 0-based position in the contig
     const u32 *ref_size, *min_size;
@@ -266,6 +268,7 @@ constexpr int BK_MAXC = 8;   // chains per side
 constexpr int BK_MAXL = 12;  // members per chain
 constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
 constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
+constexpr int BK_CODE_BITS = 16; // a chain's pick as a code: bits per member = ceil(log2(alleles)); 8 KB LDS bitmap
 
 struct BkChains {
     int n;
@@ -288,7 +291,19 @@ __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, 
     };
     out->n = 0;
     bool halt = false;
+    // The reference walks to the end of the block whatever happens (var_block.hpp:436-525: O(B) per variant, O(B^2) per
+    // block).  Nothing can join a chain once the walk is beyond the reach of every chain -- positions only move away and
+    // a chain's reach grows only when something joins -- so with sorted positions the walk stops there: same chains.
+    const bool sorted = B.blk_sorted[B.var_block[i]];
+    const int max_gain = (int)B.blk_max_gain[B.var_block[i]];
     for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
+        if (sorted) {
+            int max_sum = 0;
+            for (int c = 0; c < out->n; ++c) max_sum = max(max_sum, out->sum[c]);
+            if (step > 0 ? B.pos[j] > B.pos[i] + (int)B.ref_size[i] - (int)B.min_size[i] - 1 + max_sum + (k + 1) / 2
+                         : B.pos[j] + max_gain - 1 + max_sum + (k + 1) / 2 < B.pos[i])
+                break;
+        }
         if (!B.present[j]) continue;
         if (ov(i, j)) continue;
         const int gain = (int)B.ref_size[j] - (int)B.min_size[j];
@@ -381,6 +396,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     __shared__ u32 sh_cov[128];
     __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
     __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
+    __shared__ u32 sh_seen[(1u << BK_CODE_BITS) / 32]; // distinct picks of the chain in hand
     const int g = blockIdx.x;
     if ((u64)g >= n_vars) return;
     const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
@@ -428,6 +444,74 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
         const int m = sh_comb_len[c], jm = sh_comb_mid[c];
         const int first_pos = B.pos[comb[0]];
         const int last_end = B.pos[comb[m - 1]] + (int)B.ref_size[comb[m - 1]];
+        // one haplotype pick along the chain -> its signature k-mer -> weight -> max into the mid allele's coverage;
+        // allele_of(j) = allele of member j under the pick
+        auto evaluate = [&](auto allele_of) {
+            // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
+            int len_v = 0, mid_pos = 0, mid_len = 0;
+            u32 mid_allele = 0;
+            for (int j = 0; j < m; ++j) {
+                const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                if (j == jm) {
+                    mid_pos = len_v;
+                    mid_len = al;
+                    mid_allele = allele_of(j);
+                }
+                len_v += al;
+                if (j + 1 < m) len_v += B.pos[comb[j + 1]] - (B.pos[comb[j]] + (int)B.ref_size[comb[j]]);
+            }
+            const u32 mid_canon = B.canon[a0 + mid_allele];
+            if (m == 1 && mid_len >= k) { // the whole allele is the signature: sliding k-mers, done below
+                atomicOr(&sh_slide[mid_canon >> 5], 1u << (mid_canon & 31));
+                return;
+            }
+            const int first_part = mid_pos + mid_len / 2;
+            const int mp = k / 2 - first_part;                  // missing_prefix (negative: cut)
+            const int ms = (k + 1) / 2 - (len_v - first_part);  // missing_suffix
+            if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
+                bad = true; // the reference clips or throws here: leave it to the host path
+                return;
+            }
+            // W[x] = Vext[x - mp] for x in [0, k), where Vext is V with the reference continuing on both sides:
+            // a piece that covers v in [vs, vs + L) lands at x in [vs + mp, vs + L + mp), clipped to the window
+            for (int x = 0; x < mp && x < k; ++x) buf[x] = ref[first_pos - mp + x];
+            int vs = 0;
+            for (int j = 0; j < m; ++j) {
+                const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
+                const u8 *ap = B.pool + B.allele_off[slot];
+                const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
+                for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) buf[x] = ap[x - mp - vs];
+                vs += al;
+                if (j + 1 < m) {
+                    const int gs = B.pos[comb[j]] + (int)B.ref_size[comb[j]];
+                    const int gl = B.pos[comb[j + 1]] - gs;
+                    for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) buf[x] = ref[gs + (x - mp - vs)];
+                    vs += gl;
+                }
+            }
+            for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
+            const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
+            if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+        };
+        // The picks of all samples are first reduced to the DISTINCT ones (the reference's unordered_set, var_block.hpp
+        // :734-786): a pick is a code of a few bits per member, marked in an LDS bitmap by the pass over the samples
+        // and evaluated once by the pass over the bitmap.  A panel has thousands of samples and a chain a handful of
+        // distinct picks.  Chains whose code does not fit BK_CODE_BITS evaluate every sample's picks directly.
+        int code_bits = 0;
+        for (int j = 0; j < m; ++j) {
+            const u32 A_j = B.var_allele_off[comb[j] + 1] - B.var_allele_off[comb[j]];
+            code_bits += A_j <= 2 ? 1 : 32 - __clz((int)A_j - 1);
+        }
+        const bool coded = code_bits <= BK_CODE_BITS;
+        if (coded) {
+            for (u32 w = threadIdx.x; w < ((1u << code_bits) + 31) / 32; w += TPB) sh_seen[w] = 0;
+            __syncthreads();
+        }
+        auto bits_of = [&](int j) -> int { // width of member j's field in the code
+            const u32 A_j = B.var_allele_off[comb[j] + 1] - B.var_allele_off[comb[j]];
+            return A_j <= 2 ? 1 : 32 - __clz((int)A_j - 1);
+        };
         for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
             bool phased = true;
             if (!B.haploid)
@@ -446,53 +530,29 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
                     if (phased) return pick ? a2 : a1;
                     return (pick >> j) & 1 ? a2 : a1;
                 };
-                // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
-                int len_v = 0, mid_pos = 0, mid_len = 0;
-                u32 mid_allele = 0;
-                for (int j = 0; j < m; ++j) {
-                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
-                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
-                    if (j == jm) {
-                        mid_pos = len_v;
-                        mid_len = al;
-                        mid_allele = allele_of(j);
+                if (coded) {
+                    u32 code = 0;
+                    int sh = 0;
+                    for (int j = 0; j < m; ++j) {
+                        code |= allele_of(j) << sh;
+                        sh += bits_of(j);
                     }
-                    len_v += al;
-                    if (j + 1 < m) len_v += B.pos[comb[j + 1]] - (B.pos[comb[j]] + (int)B.ref_size[comb[j]]);
-                }
-                const u32 mid_canon = B.canon[a0 + mid_allele];
-                if (m == 1 && mid_len >= k) { // the whole allele is the signature: sliding k-mers, done below
-                    atomicOr(&sh_slide[mid_canon >> 5], 1u << (mid_canon & 31));
-                    continue;
-                }
-                const int first_part = mid_pos + mid_len / 2;
-                const int mp = k / 2 - first_part;                  // missing_prefix (negative: cut)
-                const int ms = (k + 1) / 2 - (len_v - first_part);  // missing_suffix
-                if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
-                    bad = true; // the reference clips or throws here: leave it to the host path
-                    continue;
-                }
-                // W[x] = Vext[x - mp] for x in [0, k), where Vext is V with the reference continuing on both sides:
-                // a piece that covers v in [vs, vs + L) lands at x in [vs + mp, vs + L + mp), clipped to the window
-                for (int x = 0; x < mp && x < k; ++x) buf[x] = ref[first_pos - mp + x];
-                int vs = 0;
-                for (int j = 0; j < m; ++j) {
-                    const u32 slot = B.var_allele_off[comb[j]] + allele_of(j);
-                    const u8 *ap = B.pool + B.allele_off[slot];
-                    const int al = (int)(B.allele_off[slot + 1] - B.allele_off[slot]);
-                    for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) buf[x] = ap[x - mp - vs];
-                    vs += al;
-                    if (j + 1 < m) {
-                        const int gs = B.pos[comb[j]] + (int)B.ref_size[comb[j]];
-                        const int gl = B.pos[comb[j + 1]] - gs;
-                        for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) buf[x] = ref[gs + (x - mp - vs)];
-                        vs += gl;
-                    }
-                }
-                for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
-                const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
-                if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+                    atomicOr(&sh_seen[code >> 5], 1u << (code & 31));
+                } else
+                    evaluate(allele_of);
             }
+        }
+        if (coded) {
+            __syncthreads();
+            for (u32 code = threadIdx.x; code < (1u << code_bits); code += TPB) {
+                if (!((sh_seen[code >> 5] >> (code & 31)) & 1)) continue;
+                evaluate([&](int j) -> u32 {
+                    int sh = 0;
+                    for (int q = 0; q < j; ++q) sh += bits_of(q);
+                    return (code >> sh) & ((1u << bits_of(j)) - 1);
+                });
+            }
+            __syncthreads(); // the bitmap is reused by the next chain
         }
     }
     if (bad) sh_bad = 1;

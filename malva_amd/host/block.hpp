@@ -31,6 +31,7 @@ class Block {
     std::vector<Variant> vars;
     int k;
     explicit Block(int k_) : k(k_) {}
+    struct PanelIndex;
     bool empty() const { return vars.empty(); }
     void clear() { vars.clear(); }
     void add(Variant &&v) { vars.push_back(std::move(v)); }
@@ -57,7 +58,9 @@ class Block {
 
     // get_combs_on_the_right (step +1) / _left (step -1), var_block.hpp:436-525, 534-624.  The two are
     // mirror images; ordered(x, y) puts the pair in genome order as the reference's argument order does.
-    std::vector<std::vector<int>> chains(int i, int step) const
+    // px (optional): lets the walk stop where nothing can join any more -- the reference walks to the end of the
+    // block whatever happens (O(B^2) per block); with sorted positions the chains are the same
+    std::vector<std::vector<int>> chains(int i, int step, const PanelIndex *px = nullptr) const
     {
         const Variant &mid = vars[(size_t)i];
         std::vector<std::vector<int>> out;
@@ -67,6 +70,13 @@ class Block {
         bool halt = false;
         for (int j = i + step; j >= 0 && j < (int)vars.size() && !halt; j += step) {
             const Variant &cur = vars[(size_t)j];
+            if (px && px->sorted) {
+                int max_sum = 0;
+                for (int s_ : sums) max_sum = std::max(max_sum, s_);
+                if (step > 0 ? cur.ref_pos > mid.ref_pos + mid.ref_size - mid.min_size - 1 + max_sum + (k + 1) / 2
+                             : cur.ref_pos + px->max_gain - 1 + max_sum + (k + 1) / 2 < mid.ref_pos)
+                    break;
+            }
             if (!cur.is_present) continue;
             if (ov(mid, cur)) continue;
             const int gain = cur.ref_size - cur.min_size;
@@ -154,6 +164,8 @@ class Block {
         std::vector<uint8_t> any_unphased;     // per variant: some sample is unphased there
         std::vector<uint8_t> regular;          // per variant: genotypes and phasing both hold n_samples entries
         size_t n_samples = 0;
+        bool sorted = true;                    // positions never decrease along the block
+        int max_gain = 0;                      // max ref_size - min_size over the block
     };
     PanelIndex panel_index() const
     {
@@ -165,6 +177,10 @@ class Block {
         px.regular.assign(B, 0);
         for (const Variant &v : vars)
             if (v.is_present) px.n_samples = std::max(px.n_samples, v.genotypes.size());
+        for (size_t j = 0; j < B; ++j) {
+            if (j && vars[j].ref_pos < vars[j - 1].ref_pos) px.sorted = false;
+            px.max_gain = std::max(px.max_gain, vars[j].ref_size - vars[j].min_size);
+        }
         for (size_t j = 0; j < B; ++j) {
             const Variant &v = vars[j];
             if (!v.is_present) continue;
@@ -313,7 +329,7 @@ class Block {
         {
             const Variant &v = vars[(size_t)vi];
             if (!v.is_present || v.ref_pos < k || v.ref_pos > (int)reference.size() - k) return;
-            const auto combs = combine(chains(vi, -1), chains(vi, +1), vi);
+            const auto combs = combine(chains(vi, -1, &panel), chains(vi, +1, &panel), vi);
             for (const auto &comb : combs) {
                 // get_ref_subs, var_block.hpp:682-702
                 std::vector<std::string> rsubs;
