@@ -268,7 +268,8 @@ constexpr int BK_MAXC = 8;   // chains per side
 constexpr int BK_MAXL = 12;  // members per chain
 constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
 constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
-constexpr int BK_CODE_BITS = 16; // a chain's pick as a code: bits per member = ceil(log2(alleles)); 8 KB LDS bitmap
+constexpr int BK_CODE_BITS = 63; // a chain's pick as a code: bits per member = ceil(log2(alleles))
+constexpr int BK_SET_CAP = 2048; // distinct picks of one chain held in the LDS set (16 KB); more: every pick evaluated directly
 
 struct BkChains {
     int n;
@@ -396,7 +397,8 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     __shared__ u32 sh_cov[128];
     __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
     __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
-    __shared__ u32 sh_seen[(1u << BK_CODE_BITS) / 32]; // distinct picks of the chain in hand
+    __shared__ unsigned long long sh_set[BK_SET_CAP]; // distinct picks of the chain in hand: code + 1, 0 = free
+    __shared__ u32 sh_set_n;
     const int g = blockIdx.x;
     if ((u64)g >= n_vars) return;
     const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
@@ -495,65 +497,81 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
             if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
         };
         // The picks of all samples are first reduced to the DISTINCT ones (the reference's unordered_set, var_block.hpp
-        // :734-786): a pick is a code of a few bits per member, marked in an LDS bitmap by the pass over the samples
-        // and evaluated once by the pass over the bitmap.  A panel has thousands of samples and a chain a handful of
-        // distinct picks.  Chains whose code does not fit BK_CODE_BITS evaluate every sample's picks directly.
-        int code_bits = 0;
-        for (int j = 0; j < m; ++j) {
-            const u32 A_j = B.var_allele_off[comb[j] + 1] - B.var_allele_off[comb[j]];
-            code_bits += A_j <= 2 ? 1 : 32 - __clz((int)A_j - 1);
-        }
-        const bool coded = code_bits <= BK_CODE_BITS;
-        if (coded) {
-            for (u32 w = threadIdx.x; w < ((1u << code_bits) + 31) / 32; w += TPB) sh_seen[w] = 0;
-            __syncthreads();
-        }
+        // :734-786): a pick is a code of a few bits per member, collected in an LDS hash set by the pass over the
+        // samples and evaluated once by the pass over the set.  A panel has thousands of samples and a chain a handful
+        // of distinct picks.  A chain whose code does not fit 63 bits, or with more than BK_SET_CAP / 2 distinct picks,
+        // has every sample's picks evaluated directly.
         auto bits_of = [&](int j) -> int { // width of member j's field in the code
             const u32 A_j = B.var_allele_off[comb[j] + 1] - B.var_allele_off[comb[j]];
             return A_j <= 2 ? 1 : 32 - __clz((int)A_j - 1);
         };
-        for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
-            bool phased = true;
-            if (!B.haploid)
-                for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
-            u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
-            if (!B.haploid && !phased && m > BK_MAXU) {
-                bad = true;
-                continue;
-            }
-            for (u32 pick = 0; pick < npick; ++pick) {
-                // allele of member j under this pick
-                auto allele_of = [&](int j) -> u32 {
-                    const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
-                    const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
-                    if (B.haploid) return a1;
-                    if (phased) return pick ? a2 : a1;
-                    return (pick >> j) & 1 ? a2 : a1;
-                };
-                if (coded) {
-                    u32 code = 0;
+        int code_bits = 0;
+        for (int j = 0; j < m; ++j) code_bits += bits_of(j);
+        const bool coded = code_bits <= BK_CODE_BITS;
+        // every sample's picks: into the set (collect) or straight to evaluate()
+        auto walk_samples = [&](bool collect) {
+            for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
+                bool phased = true;
+                if (!B.haploid)
+                    for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
+                const u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
+                if (!B.haploid && !phased && m > BK_MAXU) {
+                    bad = true;
+                    continue;
+                }
+                for (u32 pick = 0; pick < npick; ++pick) {
+                    auto allele_of = [&](int j) -> u32 { // allele of member j under this pick
+                        const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
+                        const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
+                        if (B.haploid) return a1;
+                        if (phased) return pick ? a2 : a1;
+                        return (pick >> j) & 1 ? a2 : a1;
+                    };
+                    if (!collect) {
+                        evaluate(allele_of);
+                        continue;
+                    }
+                    unsigned long long code = 0;
                     int sh = 0;
                     for (int j = 0; j < m; ++j) {
-                        code |= allele_of(j) << sh;
+                        code |= (unsigned long long)allele_of(j) << sh;
                         sh += bits_of(j);
                     }
-                    atomicOr(&sh_seen[code >> 5], 1u << (code & 31));
-                } else
-                    evaluate(allele_of);
+                    u32 at = (u32)((code * 0x9E3779B97F4A7C15ULL) >> 40) & (BK_SET_CAP - 1);
+                    for (int tries = 0; tries < BK_SET_CAP; ++tries) {
+                        const unsigned long long seen = atomicCAS(&sh_set[at], 0ULL, code + 1);
+                        if (seen == 0ULL) {
+                            atomicAdd(&sh_set_n, 1u);
+                            break;
+                        }
+                        if (seen == code + 1) break;
+                        at = (at + 1) & (BK_SET_CAP - 1);
+                    }
+                    if (sh_set_n > BK_SET_CAP / 2) return; // too many distinct picks: this chain is redone directly
+                }
             }
-        }
+        };
         if (coded) {
+            for (u32 w = threadIdx.x; w < BK_SET_CAP; w += TPB) sh_set[w] = 0;
+            if (threadIdx.x == 0) sh_set_n = 0;
             __syncthreads();
-            for (u32 code = threadIdx.x; code < (1u << code_bits); code += TPB) {
-                if (!((sh_seen[code >> 5] >> (code & 31)) & 1)) continue;
-                evaluate([&](int j) -> u32 {
-                    int sh = 0;
-                    for (int q = 0; q < j; ++q) sh += bits_of(q);
-                    return (code >> sh) & ((1u << bits_of(j)) - 1);
-                });
-            }
-            __syncthreads(); // the bitmap is reused by the next chain
-        }
+            walk_samples(true);
+            __syncthreads();
+            if (sh_set_n <= BK_SET_CAP / 2) {
+                for (u32 w = threadIdx.x; w < BK_SET_CAP; w += TPB) {
+                    if (!sh_set[w]) continue;
+                    const unsigned long long code = sh_set[w] - 1;
+                    evaluate([&](int j) -> u32 {
+                        int sh = 0;
+                        for (int q = 0; q < j; ++q) sh += bits_of(q);
+                        return (u32)(code >> sh) & ((1u << bits_of(j)) - 1);
+                    });
+                }
+            } else
+                walk_samples(false);
+            __syncthreads(); // the set is reused by the next chain
+        } else
+            walk_samples(false);
     }
     if (bad) sh_bad = 1;
     __syncthreads();
