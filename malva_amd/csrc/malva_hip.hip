@@ -87,6 +87,7 @@ struct mg_ctx {
     int scan_grid = 8192; // workgroups of the filter kernel (32 per CU; swept 2048..8192)
     int scan_ablate = 0;  // timing-only diagnostic, see scan_filter_kernel
     u32 iso_call_no = 0;  // mg_call_isolated calls so far (see iso_cover_kernel)
+    u32 blocks_set_limit = BK_SET_CAP / 2; // cover_blocks_kernel: distinct picks per chain kept in LDS before it evaluates every pick
     int scan_variant = 2; // filter-kernel VAR bits (staging / load width): 16-byte loads measured best
     int pre_k = 1;      // bits per entry of the coarse gate (chosen at finalize from the load)
     int use_pregate = 1;
@@ -533,6 +534,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
     else if (!strcmp(name, "scan_ablate")) c->scan_ablate = (int)value;
+    else if (!strcmp(name, "blocks_set_limit")) c->blocks_set_limit = (u32)std::min<int64_t>(std::max<int64_t>(value, 0), BK_SET_CAP / 2);
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
@@ -1238,6 +1240,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     B.canon = (const u8 *)d[11]; B.gt = (const uint16_t *)d[12];
     B.blk_sorted = (const u8 *)d_sorted; B.blk_max_gain = (const u32 *)d_gain;
     B.n_samples = n_samples; B.haploid = haploid; B.k = (int)c->k;
+    B.set_limit = c->blocks_set_limit;
     hipLaunchKernelGGL(cover_blocks_kernel, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
                        (u32 *)d_cov, (u8 *)d_ovf);
     HIP_TRY(c, hipGetLastError());

@@ -263,6 +263,7 @@ struct BlockBatch {
     const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14
     u32 n_samples;
     int haploid, k;
+    u32 set_limit; // distinct picks per chain held in the LDS set (<= BK_SET_CAP / 2; tests shrink it to reach the direct form)
 };
 constexpr int BK_MAXC = 8;   // chains per side
 constexpr int BK_MAXL = 12;  // members per chain
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
                         if (seen == code + 1) break;
                         at = (at + 1) & (BK_SET_CAP - 1);
                     }
-                    if (sh_set_n > BK_SET_CAP / 2) return; // too many distinct picks: this chain is redone directly
+                    if (sh_set_n > B.set_limit) return; // too many distinct picks: this chain is redone directly
                 }
             }
         };
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
             __syncthreads();
             walk_samples(true);
             __syncthreads();
-            if (sh_set_n <= BK_SET_CAP / 2) {
+            if (sh_set_n <= B.set_limit) {
                 for (u32 w = threadIdx.x; w < BK_SET_CAP; w += TPB) {
                     if (!sh_set[w]) continue;
                     const unsigned long long code = sh_set[w] - 1;

@@ -53,7 +53,14 @@ def test_dense_clusters_hit_the_device_capacities(tmp_path, seed, haploid):
     _run_case(tmp_path, seed, haploid, 35, 43, dense=True)
 
 
-def _run_case(tmp_path, seed, haploid, k, ref_k, dense):
+@pytest.mark.parametrize("seed,haploid,dense,limit", [(51, False, False, 0), (52, True, False, 1), (53, False, True, 2)])
+def test_direct_evaluation_when_the_pick_set_overflows(tmp_path, seed, haploid, dense, limit):
+    """the kernel keeps a chain's distinct haplotype picks in an LDS set and evaluates each once; with the set limited
+    to 0..2 picks nearly every chain overflows it and every sample's pick is evaluated directly: same coverages"""
+    _run_case(tmp_path, seed, haploid, 35, 43, dense=dense, set_limit=limit)
+
+
+def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
     prefix = str(tmp_path / "case")
     contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=40 if dense else 120, vcf_strip_chr=True,
                                            dense=dense, n_samples=4 if dense else 5)
@@ -67,6 +74,8 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense):
     refs = read_fasta(fa, True)
     # the same index and counters on the device, through the ASCII batch calls
     ctx = Context(k, ref_k, opt.bf_size)
+    if set_limit is not None:
+        ctx.set_option("blocks_set_limit", set_limit)
     bits = idx.bf.set_positions()
     ctx.bf_import_sparse(BF_ALT, 1, opt.bf_size, bits, idx.bf.counts())
     ctx.bf_import_sparse(BF_CTX, 1, opt.bf_size, idx.context_bf.set_positions(), idx.context_bf.counts())
