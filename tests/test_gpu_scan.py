@@ -144,3 +144,13 @@ def rows_of_random(k):
     rng = np.random.default_rng(99)
     from malva_amd.capi import rows_of
     return rows_of([bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=k)) for _ in range(5)])
+
+
+@pytest.mark.parametrize("pregate_log2,expect_k", [(10, 0), (20, 4)])
+def test_coarse_gate_is_chosen_or_skipped_at_finalize(pregate_log2, expect_k):
+    """gate sized automatically (2^25 bits for this small index, i.e. larger than the coarse gate given here): a
+    coarse gate of 2^10 bits would be saturated by 6,000 entries and is skipped; one of 2^20 bits is used with 4 bits
+    per entry (direct two-level form: 64 slices are more than the partitioned form takes).  Same counters either way."""
+    def check(ctx):
+        assert ctx.get_option("pregate_k") == expect_k and ctx.get_option("scan_bins") == 0
+    _scan_case(35, 43, 1 << 33, 3000, 100000, 71, after=check, options=[("pregate_log2", pregate_log2)])
