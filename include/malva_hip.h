@@ -14,7 +14,9 @@
  *     the last failure on a context is mg_last_error(ctx).  Nothing throws.
  *   - all device memory is owned by the opaque mg_ctx (one context = one GPU).
  *     Calls on one context must be serialised by the caller, exactly like the
- *     single-threaded reference.
+ *     single-threaded reference; they may come from any host thread (each entry
+ *     point makes the context's GPU current for the calling thread and puts the
+ *     previous one back), and different contexts may be driven concurrently.
  *   - "rows" arguments are host buffers of n fixed-stride ASCII k-mers, each
  *     NUL-terminated inside its stride (the reference passes `const char*`
  *     and measures with strlen, bloom_filter.hpp:69); 1 <= strlen <= 128.
