@@ -47,7 +47,13 @@ ref:
 	    echo "built oracle/_ref/libxxhash_ref.so from $(REFERENCE)/xxhash.c"; \
 	else echo "reference not present: keeping prebuilt oracle/_ref (if any)"; fi
 
+# the microbenchmark behind DESIGN.md's bound for the filter kernel (run it on an MI355X)
+microbench: bin/l2_gather_bench
+bin/l2_gather_bench: tools/l2_gather_bench.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
 clean:
 	rm -rf malva_amd/lib bin oracle/libmalva_oracle.so oracle/_ref
 
-.PHONY: all lib cli oracle ref clean
+.PHONY: all lib cli oracle ref microbench clean

@@ -1,7 +1,7 @@
 // Microbenchmark behind DESIGN.md's bound for the scan's filter kernel: how many independent, uniformly random
 // 8-byte reads per second one MI355X sustains from a table of F bytes (F = 16 KiB .. 1 GiB: L2-resident up to
 // 4 MiB per XCD), alone and beside a non-temporal 20-byte-per-lane stream shaped like the k-mer table.
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/l2_gather_bench tools/l2_gather_bench.hip && gpurun_out/l2_gather_bench
+//   make microbench && bin/l2_gather_bench
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
