@@ -46,6 +46,7 @@ extern "C" {
 #define MG_ERR_STATE (-3)  /* call not valid in the filter's current mode */
 #define MG_ERR_NOMEM (-4)  /* allocation failed */
 #define MG_ERR_LIMIT (-5)  /* size beyond what the implementation addresses */
+#define MG_ERR_COMM (-6)   /* RCCL unavailable or a collective failed */
 
 #define MG_BF_ALT 0 /* `bf`         main.cpp:300 -- ALT-allele signature k-mers        */
 #define MG_BF_CTX 1 /* `context_bf` main.cpp:302 -- reference contexts (ref_k-mers)    */
@@ -64,7 +65,10 @@ int mg_create(mg_ctx **out, int device, uint32_t k, uint32_t ref_k, uint64_t bf_
 int mg_destroy(mg_ctx *ctx);
 const char *mg_last_error(const mg_ctx *ctx);
 /* Launch everything on `hip_stream` (a hipStream_t; NULL = the context's own
- * stream).  Lets a caller time the kernels with events on its own stream. */
+ * stream).  Lets a caller time the kernels with events on its own stream.
+ * NULL never means HIP's default stream: a caller that works on the legacy
+ * default stream (handle 0 in most bindings) passes MG_STREAM_DEFAULT. */
+#define MG_STREAM_DEFAULT ((void *)1) /* == hipStreamLegacy */
 int mg_set_stream(mg_ctx *ctx, void *hip_stream);
 int mg_synchronize(mg_ctx *ctx);
 
@@ -128,6 +132,30 @@ int mg_counters_reset(mg_ctx *ctx);
  * d_ptr[0 .. n_bf + n_map) replaces export + all-reduce + import. */
 int mg_counters_view(mg_ctx *ctx, void **d_ptr, uint64_t *n_bf, uint64_t *n_map);
 
+/* The exchange itself, inside the library: RCCL (librccl.so.1, opened on first use) over xGMI.  The reference has
+ * no counterpart (single-threaded, CMakeLists.txt:46 links pthread and never uses it); SURVEY 8(b)/(e) define it.
+ *
+ *   one process per GPU   rank 0: mg_comm_unique_id(id); ship the 128 bytes to the other ranks (any channel);
+ *                         every rank: mg_comm_init(ctx, rank, world, id); after its shard's mg_kmc_scan*:
+ *                         mg_counters_allreduce(ctx) -- ncclAllReduce(sum, uint32), in place over the
+ *                         mg_counters_view allocation, asynchronous on the context's stream.
+ *   one process, N GPUs   mg_comm_init_all(ctxs, N) (one context per device) and, after the N shard scans,
+ *                         mg_counters_allreduce_all(ctxs, N): the same all-reduces as one RCCL group.
+ *                         Contexts that all sit on ONE device (rehearsing the N-way layout on a one-GPU box; RCCL
+ *                         rejects duplicate devices) are summed by a kernel instead; mg_comm_info tells which.
+ * Every rank must hold the same index (same inserts / same index file): the counter layout is then identical. */
+#define MG_COMM_ID_BYTES 128
+#define MG_COMM_NONE 0
+#define MG_COMM_RCCL 1
+#define MG_COMM_LOCAL 2
+int mg_comm_unique_id(void *id_out /* MG_COMM_ID_BYTES */);
+int mg_comm_init(mg_ctx *ctx, int rank, int world, const void *id);
+int mg_comm_init_all(mg_ctx **ctxs, int n);
+int mg_comm_destroy(mg_ctx *ctx);
+int mg_comm_info(mg_ctx *ctx, int *rank, int *world, int *backend);
+int mg_counters_allreduce(mg_ctx *ctx);
+int mg_counters_allreduce_all(mg_ctx **ctxs, int n);
+
 /* ---- per-variant path ----------------------------------------------------- */
 
 /* set_coverages (main.cpp:151-184) over flat signature descriptors of any
@@ -175,7 +203,10 @@ int mg_genotype(mg_ctx *ctx, const uint32_t *cov, const float *freq, const uint3
  * GT/GQ in one launch.  `reference` is the concatenation of the upper-cased
  * contigs already uploaded with mg_reference_upload; pos[v] is the variant's
  * offset in that buffer.  flags bit0: eligible (is_present and not within k of
- * a contig end, var_block.hpp:104).  present_mask bit a: some panel haplotype
+ * a contig end, var_block.hpp:104).  An eligible variant's flanks -- k/2 bases
+ * before pos, ceil(k/2) after the REF allele -- must lie inside its contig: a
+ * right flank clipped by the contig end makes a shorter k-mer in the reference
+ * (var_block.hpp:187), which is mg_cover_blocks' / the host enumerator's case.  present_mask bit a: some panel haplotype
  * carries allele a (build_alleles_combs, var_block.hpp:734-786).  probs (optional):
  * normalised likelihood lists at caller-provided var_gt_off, as in mg_genotype. */
 int mg_reference_upload(mg_ctx *ctx, const char *ascii, size_t len);

@@ -1,14 +1,23 @@
 """ctypes binding of include/malva_hip.h.  No fallback: a missing or unloadable
 libmalva_hip.so is an error.
 
-Note for processes that also use PyTorch-ROCm: import torch (and touch the GPU with it) BEFORE creating a
-Context.  torch bundles its own HIP runtime and fails to find GPUs if /opt/rocm's runtime initialised first."""
+One HIP runtime per process.  libmalva_hip.so asks the loader for `libamdhip64.so.7` and gets whichever copy is
+already mapped, else /opt/rocm's.  PyTorch-ROCm bundles its own copy and asks for it by FILE name
+(`libamdhip64.so`), which never matches an already mapped /opt/rocm copy: a process that mapped /opt/rocm's first
+and imports torch later ends up with two runtimes, and torch then reports "No HIP GPUs".  lib() therefore maps
+torch's copy first whenever torch is installed (without importing torch), so the order of `import torch` and
+Context() no longer matters.  MALVA_HIP_RUNTIME=system keeps /opt/rocm's (for processes that never import torch)."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
 BF_ALT, BF_CTX = 0, 1
+STREAM_DEFAULT = 1          # MG_STREAM_DEFAULT: HIP's legacy default stream (a NULL handle means the context's own stream)
+COMM_NONE, COMM_RCCL, COMM_LOCAL = 0, 1, 2
+COMM_ID_BYTES = 128
 GT_NORMAL, GT_OVERCOV, GT_SINGLE, GT_NOCOV = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +34,23 @@ def library_path():
     return os.path.join(_HERE, "lib", "libmalva_hip.so")
 
 
+def _map_process_hip_runtime():
+    """see the module docstring; returns the path mapped, or None"""
+    if os.environ.get("MALVA_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return None                      # torch already imported: its runtime is mapped and ours will bind to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -32,6 +58,7 @@ def lib():
     path = library_path()
     if not os.path.exists(path):
         raise MalvaError(-100, "%s not built: run `make lib` (hipcc --offload-arch=gfx950)" % path)
+    _map_process_hip_runtime()
     L = C.CDLL(path)
     vp, cp, sz, u64, u32, i32, i64 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int32, C.c_int64
     fl, it = C.c_float, C.c_int
@@ -59,6 +86,13 @@ def lib():
         "mg_counters_import_device": [vp, vp],
         "mg_counters_reset": [vp],
         "mg_counters_view": [vp, vp, vp, vp],
+        "mg_comm_unique_id": [vp],
+        "mg_comm_init": [vp, it, it, vp],
+        "mg_comm_init_all": [C.POINTER(vp), it],
+        "mg_comm_destroy": [vp],
+        "mg_comm_info": [vp, vp, vp, vp],
+        "mg_counters_allreduce": [vp],
+        "mg_counters_allreduce_all": [C.POINTER(vp), it],
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
@@ -91,6 +125,8 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
             "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
+            "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
+            "mg_counters_allreduce_all",
             "mg_lookup_cover", "mg_cover_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_set_option", "mg_get_option"]
@@ -98,6 +134,33 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 calls it and ships the bytes to the other ranks"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().mg_comm_unique_id(buf)
+    if rc != 0:
+        raise MalvaError(rc, "mg_comm_unique_id failed (librccl.so.1 not loadable?)")
+    return buf.raw
+
+
+def _ctx_array(ctxs):
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    return arr
+
+
+def comm_init_all(ctxs):
+    """one process, several contexts: one per device (RCCL group) or all on one device (kernel sum)"""
+    rc = lib().mg_comm_init_all(_ctx_array(ctxs), len(ctxs))
+    if rc != 0:
+        raise MalvaError(rc, lib().mg_last_error(ctxs[0].h).decode())
+
+
+def counters_allreduce_all(ctxs):
+    rc = lib().mg_counters_allreduce_all(_ctx_array(ctxs), len(ctxs))
+    if rc != 0:
+        raise MalvaError(rc, lib().mg_last_error(ctxs[0].h).decode())
 
 
 def rows_of(kmers, stride=None):
@@ -323,6 +386,23 @@ class Context:
 
     def counters_reset(self):
         self._ck(self._L.mg_counters_reset(self.h))
+
+    # multi-GPU exchange inside the library (RCCL)
+    def comm_init(self, rank, world, comm_id: bytes):
+        assert len(comm_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._ck(self._L.mg_comm_init(self.h, rank, world, buf))
+
+    def comm_destroy(self):
+        self._ck(self._L.mg_comm_destroy(self.h))
+
+    def comm_info(self):
+        r, w, b = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.mg_comm_info(self.h, C.byref(r), C.byref(w), C.byref(b)))
+        return r.value, w.value, b.value
+
+    def counters_allreduce(self):
+        self._ck(self._L.mg_counters_allreduce(self.h))
 
     # per-variant path
     def lookup_cover(self, rows, is_ref, sig_kmer_off, allele_sig_off):

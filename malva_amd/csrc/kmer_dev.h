@@ -123,17 +123,30 @@ __device__ __forceinline__ u64 xxh3_packed(U128 c, int len)
 {
     return len > 32 ? xxh3_packed_33to64(c.lo, c.hi, len) : xxh3_packed_17to32(c.lo, c.hi, len);
 }
-// LEN known at compile time (33..64): the fixed-length form; LEN == 0: runtime length
+// XXH3 of the ASCII rendering of a packed canonical key (any length 1..64)
+struct LformIn {
+    U128 v;
+    __device__ __forceinline__ u32 operator()(int i) const
+    {
+        const u32 c = (u32)((i < 32 ? v.lo >> (2 * i) : v.hi >> (2 * (i - 32))) & 3);
+        return (0x54474341u >> (8 * c)) & 0xFF;
+    }
+};
+__device__ __forceinline__ u64 xxh3_lform(U128 key, int len)
+{
+    return len >= 17 ? xxh3_packed(key, len) : xxh3_bytes(LformIn{key}, len);
+}
+// LEN known at compile time (33..64): the fixed-length form; LEN == 0: runtime length (any 1..64)
 template <int LEN> __device__ __forceinline__ u64 xxh3_packed_k(U128 c, int len_rt)
 {
     if constexpr (LEN >= 33 && LEN <= 64) return xxh3_packed_fixed<LEN>(c.lo, c.hi);
-    else return xxh3_packed(c, len_rt);
+    else return xxh3_lform(c, len_rt);
 }
 // the same with the ASCII table of ascii_lut_fill in LDS (used where LEN is fixed; ignored otherwise)
 template <int LEN> __device__ __forceinline__ u64 xxh3_packed_k(U128 c, int len_rt, const u32 *lut)
 {
     if constexpr (LEN >= 33 && LEN <= 64) return xxh3_packed_fixed<LEN, true>(c.lo, c.hi, lut);
-    else return xxh3_packed(c, len_rt);
+    else return xxh3_lform(c, len_rt);
 }
 
 // ---- hash -> bit index (hash % _size, bloom_filter.hpp:84) --------------------
@@ -174,6 +187,7 @@ struct BFView {
     // size sits in front of it: same construction over the same idx, fewer bits per entry.  Only rows that pass
     // the coarse gate pay the (HBM / Infinity Cache) line of the fine one.
     u64 *pregate;
+    u64 *pregate_fill; // the same array whenever it is allocated: inserts always fill it, `pregate` says whether probes use it
     ModDesc mod;
     u32 gate_shift;
     u32 gate_k;   // bits per entry, 1..4
@@ -218,7 +232,7 @@ __device__ __forceinline__ void gate_set(const BFView &b, u64 idx)
 {
     if (!b.gate) return;
     atomicOr((unsigned long long *)&b.gate[gate_word(b, idx)], gate_mask(b, idx));
-    if (b.pregate) atomicOr((unsigned long long *)&b.pregate[pre_word(b, idx)], pre_mask(b, idx));
+    if (b.pregate_fill) atomicOr((unsigned long long *)&b.pregate_fill[pre_word(b, idx)], pre_mask(b, idx));
 }
 // rank(idx) = ones in [0, idx)   (rank_support_v<1>, bloom_filter.hpp:108)
 // The 512-bit block that holds idx is one aligned 64-byte piece of `words` (the array is padded to whole blocks):
@@ -289,19 +303,6 @@ struct MapView {
 // record as the keys that hash to it), tag from the middle of h.
 __device__ __forceinline__ u32 map_tag(u64 h) { return (u32)(h >> 8) | 0x80000000u; }
 __device__ __forceinline__ u64 map_home(const MapView &m, u64 idx) { return (idx * 0x9E3779B97F4A7C15ULL) >> (64 - m.cap_log2); }
-// XXH3 of the ASCII rendering of a packed canonical key (any length 1..64)
-struct LformIn {
-    U128 v;
-    __device__ __forceinline__ u32 operator()(int i) const
-    {
-        const u32 c = (u32)((i < 32 ? v.lo >> (2 * i) : v.hi >> (2 * (i - 32))) & 3);
-        return (0x54474341u >> (8 * c)) & 0xFF;
-    }
-};
-__device__ __forceinline__ u64 xxh3_lform(U128 key, int len)
-{
-    return len >= 17 ? xxh3_packed(key, len) : xxh3_bytes(LformIn{key}, len);
-}
 // Counter id of a published key (index into vals[]), or -1.  Read side only (every insert has completed: the host
 // orders the kernels), so a record is read whole -- 16-byte loads issued together, one round trip -- instead of
 // tag, then key low, then key high, then id, each waiting for the one before on the same line.

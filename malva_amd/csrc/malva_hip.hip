@@ -2,12 +2,16 @@
 // See include/malva_hip.h for the interface and the reference lines each entry
 // point replaces; DESIGN.md for the data layout and the roofline of each kernel.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library itself is opened on first use (mg_comm_*)
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -101,6 +105,12 @@ struct mg_ctx {
     unsigned long long *d_bin_meta = nullptr; // spill count, then u32 [BIN_MAXP][BIN_SEGS] segment fills
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
     int gate_log2 = 25; // gate of at most 2^gate_log2 bits = 4 MiB (swept 24..26: 25 gives the best whole-scan time)
+    // multi-GPU exchange (mg_comm_*): an RCCL communicator, or -- contexts of one process that share a device, where
+    // RCCL refuses duplicate ranks -- the list of contexts whose counters a kernel sums
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    std::vector<mg_ctx *> local_group;
+    hipEvent_t ev_x = nullptr; // orders the local-group exchange between the contexts' streams
     std::string err;
 };
 
@@ -131,6 +141,7 @@ int fail(mg_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 inline unsigned nblocks(u64 n) { return (unsigned)((n + TPB - 1) / TPB); }
+int comm_drop(mg_ctx *c); // multi-GPU section
 
 int scratch(mg_ctx *c, Scratch &s, size_t bytes, void **out)
 {
@@ -185,6 +196,7 @@ BFView view(const mg_ctx *c, int which)
     v.gate_shift = b.gate_shift;
     v.gate_k = (u32)c->gate_k;
     v.pregate = pregate_on(c) ? b.pregate : nullptr;
+    v.pregate_fill = b.pregate; // filled whenever it exists, so use_pregate / pre_skip may change between scans
     v.pre_shift = b.pre_shift;
     v.pre_k = (u32)c->pre_k;
     v.use_gate = (c->use_summary && b.gate) ? 1 : 0;
@@ -478,6 +490,8 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     if (!c) return MG_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    comm_drop(c);
+    if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->joined) { // the two counter arrays alias one allocation
         hipFree(c->joined);
         c->bf[MG_BF_ALT].counts = nullptr;
@@ -930,8 +944,8 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
-    if (c->k < 17 || c->ref_k > MG_MAX_PACKED_K)
-        return fail(c, MG_ERR_LIMIT, "packed scan supports 17 <= k <= ref_k <= 64 (k=%u ref_k=%u)", c->k, c->ref_k);
+    if (c->ref_k > MG_MAX_PACKED_K)
+        return fail(c, MG_ERR_LIMIT, "packed scan supports k <= ref_k <= 64 (k=%u ref_k=%u)", c->k, c->ref_k);
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.slots) TRY(map_reserve(c, 0));
@@ -941,7 +955,6 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
     for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
     const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
-    const bool d35_43 = c->k == 35 && c->ref_k == 43;
     c->stats_valid = false;
     // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
     BinSet bins{};
@@ -974,7 +987,9 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         const u32 *pc = (const u32 *)d_cnt + r0;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
         if (partition) HIP_TRY(c, hipMemsetAsync(c->d_bin_meta, 0, 8, c->stream));
-        if (d35_43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
+        // the reference's defaults (k35 r43, argument_parser.hpp:57-58) and config C5 (k35 r63) get fixed-length hashing
+        if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
+        else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
         else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
@@ -1027,7 +1042,7 @@ MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, co
 {
     const DeviceGuard on_device(c);
     TRY(check_which(c, which));
-    if (klen < 17 || klen > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed k-mers: 17 <= k <= 64");
+    if (klen < 1 || klen > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed k-mers: 1 <= k <= 64");
     if (n == 0) return MG_OK;
     void *dh, *dl, *dout;
     TRY(upload(c, c->s_misc[5], hi, n * 8, &dh));
@@ -1052,10 +1067,10 @@ MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
     if (n_map) *n_map = c->map.rows_total;
     return MG_OK;
 }
-MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t *n_map)
+namespace {
+// the two counter arrays as ONE allocation [bf counters | map counters] (what an in-place all-reduce wants)
+int ensure_joined(mg_ctx *c)
 {
-    const DeviceGuard on_device(c);
-    if (!c || !d_ptr) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     BFState &b = c->bf[MG_BF_ALT];
     MapState &m = c->map;
@@ -1073,9 +1088,18 @@ MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t
         m.vals = j + nb;
         m.vals_cap = nm;
     }
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t *n_map)
+{
+    const DeviceGuard on_device(c);
+    if (!c || !d_ptr) return MG_ERR_ARG;
+    TRY(ensure_joined(c));
     *d_ptr = c->joined;
-    if (n_bf) *n_bf = b.nset;
-    if (n_map) *n_map = m.rows_total;
+    if (n_bf) *n_bf = c->bf[MG_BF_ALT].nset;
+    if (n_map) *n_map = c->map.rows_total;
     return MG_OK;
 }
 MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
@@ -1105,6 +1129,255 @@ MG_EXPORT int mg_counters_reset(mg_ctx *c)
     if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
     if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
     for (auto &kv : c->map.irregular) kv.second = 0;
+    return MG_OK;
+}
+
+// ---- multi-GPU exchange: RCCL over xGMI -----------------------------------------------------
+// The scan shards by table rows; what has to be combined afterwards is one vector of wrapping u32 sums
+// (mg_counters_view).  One ncclAllReduce(sum, uint32) over it, in place, on the context's stream.
+// librccl is opened on first use: a single-GPU run never maps its half gigabyte, and a process that has already
+// mapped a librccl.so.1 (PyTorch-ROCm bundles one) gets that copy -- one RCCL, like one HIP runtime, per process.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (!r.h) {
+            const char *e = dlerror();
+            r.err = std::string("cannot open librccl.so.1: ") + (e ? e : "?");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.h, n);
+            if (!p) {
+                ok = false;
+                r.err = std::string("librccl lacks ") + n;
+            }
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) r.h = nullptr;
+    });
+    return r.h ? &r : nullptr;
+}
+#define NCCL_TRY(c, R, expr)                                                                           \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return fail(c, MG_ERR_COMM, "%s: %s", #expr, (R)->GetErrorString(r_)); \
+    } while (0)
+
+// sum of up to MG_MAX_LOCAL counter vectors that live on ONE device, written back to all of them
+constexpr int MG_MAX_LOCAL = 16;
+struct LocalPtrs {
+    u32 *p[MG_MAX_LOCAL];
+    int n;
+};
+__global__ void __launch_bounds__(TPB) local_sum_kernel(LocalPtrs v, u64 n)
+{
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += (u64)gridDim.x * TPB) {
+        u32 s = 0;
+        for (int j = 0; j < v.n; ++j) s += v.p[j][i];
+        for (int j = 0; j < v.n; ++j) v.p[j][i] = s;
+    }
+}
+int comm_drop(mg_ctx *c)
+{
+    if (c->comm) {
+        Rccl *R = rccl();
+        if (R) R->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    for (mg_ctx *o : c->local_group) // a local group dissolves as a whole
+        if (o != c) o->local_group.clear();
+    c->local_group.clear();
+    c->comm_world = 0;
+    c->comm_rank = 0;
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT int mg_comm_unique_id(void *id_out)
+{
+    if (!id_out) return MG_ERR_ARG;
+    Rccl *R = rccl();
+    if (!R) return MG_ERR_COMM;
+    static_assert(sizeof(ncclUniqueId) == MG_COMM_ID_BYTES, "MG_COMM_ID_BYTES");
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return MG_ERR_COMM;
+    memcpy(id_out, &id, sizeof id);
+    return MG_OK;
+}
+
+MG_EXPORT int mg_comm_init(mg_ctx *c, int rank, int world, const void *id)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world || !id) return fail(c, MG_ERR_ARG, "mg_comm_init: rank %d of %d", rank, world);
+    Rccl *R = rccl();
+    if (!R) return fail(c, MG_ERR_COMM, "RCCL unavailable");
+    comm_drop(c);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(c, R, R->CommInitRank(&c->comm, world, uid, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_comm_init_all(mg_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1 || n > 64) return MG_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return MG_ERR_ARG;
+    bool distinct = true, same = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) {
+            if (ctxs[i] == ctxs[j]) return fail(ctxs[0], MG_ERR_ARG, "mg_comm_init_all: context %d listed twice", i);
+            if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+            else same = false;
+        }
+    for (int i = 0; i < n; ++i) comm_drop(ctxs[i]);
+    if (n == 1 || distinct) { // one rank per device: RCCL (n == 1 too, so that a single-GPU run drives the same calls)
+        Rccl *R = rccl();
+        if (!R) return fail(ctxs[0], MG_ERR_COMM, "RCCL unavailable");
+        ncclUniqueId uid;
+        NCCL_TRY(ctxs[0], R, R->GetUniqueId(&uid));
+        int prev = -1;
+        hipGetDevice(&prev);
+        NCCL_TRY(ctxs[0], R, R->GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (int i = 0; i < n && bad == ncclSuccess; ++i) {
+            hipSetDevice(ctxs[i]->device);
+            bad = R->CommInitRank(&ctxs[i]->comm, n, uid, i);
+        }
+        const ncclResult_t ge = R->GroupEnd();
+        if (prev >= 0) hipSetDevice(prev);
+        if (bad != ncclSuccess || ge != ncclSuccess) {
+            for (int i = 0; i < n; ++i) ctxs[i]->comm = nullptr;
+            return fail(ctxs[0], MG_ERR_COMM, "ncclCommInitRank x%d: %s", n, R->GetErrorString(bad != ncclSuccess ? bad : ge));
+        }
+        for (int i = 0; i < n; ++i) {
+            ctxs[i]->comm_rank = i;
+            ctxs[i]->comm_world = n;
+        }
+        return MG_OK;
+    }
+    if (!same) return fail(ctxs[0], MG_ERR_ARG, "mg_comm_init_all: contexts must sit on distinct devices, or all on one");
+    if (n > MG_MAX_LOCAL) return fail(ctxs[0], MG_ERR_LIMIT, "at most %d contexts may share a device", MG_MAX_LOCAL);
+    // all on one device (a rehearsal of the N-GPU layout on a one-GPU box: RCCL rejects duplicate devices)
+    for (int i = 0; i < n; ++i) {
+        ctxs[i]->local_group.assign(ctxs, ctxs + n);
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_world = n;
+        if (!ctxs[i]->ev_x) {
+            const DeviceGuard g(ctxs[i]);
+            if (hipEventCreateWithFlags(&ctxs[i]->ev_x, hipEventDisableTiming) != hipSuccess) return fail(ctxs[i], MG_ERR_HIP, "hipEventCreate");
+        }
+    }
+    return MG_OK;
+}
+
+MG_EXPORT int mg_comm_destroy(mg_ctx *c)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    return comm_drop(c);
+}
+
+MG_EXPORT int mg_comm_info(mg_ctx *c, int *rank, int *world, int *backend)
+{
+    if (!c) return MG_ERR_ARG;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm_world;
+    if (backend) *backend = c->comm ? MG_COMM_RCCL : !c->local_group.empty() ? MG_COMM_LOCAL : MG_COMM_NONE;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_counters_allreduce(mg_ctx *c)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!c->comm) return fail(c, MG_ERR_STATE, "mg_counters_allreduce: no RCCL communicator (mg_comm_init first; contexts sharing a device use mg_counters_allreduce_all)");
+    TRY(ensure_joined(c));
+    Rccl *R = rccl();
+    const u64 nn = c->bf[MG_BF_ALT].nset + c->map.rows_total;
+    if (nn == 0) return MG_OK;
+    NCCL_TRY(c, R, R->AllReduce(c->joined, c->joined, nn, ncclUint32, ncclSum, c->comm, c->stream));
+    return MG_OK;
+}
+
+MG_EXPORT int mg_counters_allreduce_all(mg_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1) return MG_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return MG_ERR_ARG;
+    mg_ctx *c0 = ctxs[0];
+    u64 nn = 0;
+    for (int i = 0; i < n; ++i) {
+        const DeviceGuard g(ctxs[i]);
+        TRY(ensure_joined(ctxs[i]));
+        const u64 ni = ctxs[i]->bf[MG_BF_ALT].nset + ctxs[i]->map.rows_total;
+        if (i && (ni != nn || ctxs[i]->bf[MG_BF_ALT].nset != c0->bf[MG_BF_ALT].nset))
+            return fail(c0, MG_ERR_STATE, "context %d holds another index (%llu counters, context 0 %llu): every rank must load the same index",
+                        i, (unsigned long long)ni, (unsigned long long)nn);
+        nn = ni;
+        if (ctxs[i]->comm_world != n) return fail(c0, MG_ERR_STATE, "context %d is not part of a %d-way group (mg_comm_init_all)", i, n);
+    }
+    if (nn == 0) return MG_OK;
+    if (c0->comm) { // one rank per device, one process: a group of all-reduces, each on its context's stream
+        Rccl *R = rccl();
+        int prev = -1;
+        hipGetDevice(&prev);
+        NCCL_TRY(c0, R, R->GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (int i = 0; i < n && bad == ncclSuccess; ++i) {
+            hipSetDevice(ctxs[i]->device);
+            bad = R->AllReduce(ctxs[i]->joined, ctxs[i]->joined, nn, ncclUint32, ncclSum, ctxs[i]->comm, ctxs[i]->stream);
+        }
+        const ncclResult_t ge = R->GroupEnd();
+        if (prev >= 0) hipSetDevice(prev);
+        if (bad != ncclSuccess || ge != ncclSuccess) return fail(c0, MG_ERR_COMM, "ncclAllReduce x%d: %s", n, R->GetErrorString(bad != ncclSuccess ? bad : ge));
+        return MG_OK;
+    }
+    if (c0->local_group.size() != (size_t)n) return fail(c0, MG_ERR_STATE, "mg_comm_init_all first");
+    // contexts sharing one device: context 0's stream waits for every scan, sums, and everyone waits for the sum
+    const DeviceGuard g(c0);
+    LocalPtrs v{};
+    v.n = n;
+    for (int i = 0; i < n; ++i) {
+        v.p[i] = ctxs[i]->joined;
+        if (i) {
+            HIP_TRY(c0, hipEventRecord(ctxs[i]->ev_x, ctxs[i]->stream));
+            HIP_TRY(c0, hipStreamWaitEvent(c0->stream, ctxs[i]->ev_x, 0));
+        }
+    }
+    hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)std::min<u64>(nblocks(nn), 4096u)), dim3(TPB), 0, c0->stream, v, nn);
+    HIP_TRY(c0, hipGetLastError());
+    HIP_TRY(c0, hipEventRecord(c0->ev_x, c0->stream));
+    for (int i = 1; i < n; ++i) HIP_TRY(c0, hipStreamWaitEvent(ctxs[i]->stream, c0->ev_x, 0));
     return MG_OK;
 }
 
@@ -1314,8 +1587,10 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
         if (flags[v] & 1) {
             const u32 a0 = var_allele_off[v];
             const u64 rs = allele_off[a0 + 1] - allele_off[a0];
-            if (pos[v] < c->k || pos[v] + rs + c->k > c->ref_len)
-                return fail(c, MG_ERR_ARG, "variant %zu flagged eligible but within k of the reference buffer end", v);
+            // what iso_cover_kernel reads: k/2 bases before the site, ceil(k/2) after the REF allele (the buffer's
+            // 64-byte padding absorbs the aligned dwords around them)
+            if (pos[v] < c->k / 2 || pos[v] + rs + (c->k + 1) / 2 > c->ref_len)
+                return fail(c, MG_ERR_ARG, "variant %zu flagged eligible but its flanks leave the uploaded reference", v);
         }
     if (allele_off[na] > pool_len) return fail(c, MG_ERR_ARG, "allele offsets exceed the pool");
     void *d_pos, *d_vo, *d_ao, *d_pool, *d_fr, *d_pm, *d_fl, *d_cov, *d_g1, *d_g2, *d_gq, *d_st;
@@ -1524,16 +1799,18 @@ MG_EXPORT int mg_map_import(mg_ctx *c, const char *rows, size_t stride, size_t n
     const DeviceGuard on_device(c);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
-    const u64 row0 = c->map.rows_total;
     TRY(mg_map_insert(c, rows, stride, n));
     if (vals) {
-        // imported keys are distinct, so row i keeps id row0 + i; irregular rows go to the overflow list
-        HIP_TRY(c, hipMemcpy(c->map.vals + row0, vals, n * 4, hipMemcpyHostToDevice));
-        for (size_t i = 0; i < n; ++i) {
-            std::string key(rows + i * stride, strnlen(rows + i * stride, stride));
-            auto it = c->map.irregular.find(key);
-            if (it != c->map.irregular.end()) it->second = vals[i];
-        }
+        // values go through a lookup of each key (a file may repeat a key, or name one that was already present:
+        // the counter of a key is the one its first insertion row owns); irregular rows live in the host list
+        // under the canonical form KMAP::canonical gives them (kmap.hpp:86-97)
+        std::vector<u8> irr(n);
+        TRY(run_rows<OP_MAP_SET>(c, 0, rows, stride, n, vals, nullptr, nullptr, 0, irr.data()));
+        for (size_t i = 0; i < n; ++i)
+            if (irr[i]) {
+                auto it = c->map.irregular.find(host_irregular_key(rows + i * stride, stride));
+                if (it != c->map.irregular.end()) it->second = vals[i];
+            }
     }
     return MG_OK;
 }

@@ -489,6 +489,6 @@ __global__ void __launch_bounds__(TPB) packed_index_kernel(const u64 *hi, const 
     const U128 m{lo[i], hi[i]};
     const U128 l = mform_to_lform(m, klen);
     const U128 c = canon_sub(m, l, klen, 0, klen);
-    out[i] = mod_size(xxh3_packed(c, klen), mod);
+    out[i] = mod_size(xxh3_lform(c, klen), mod);
 }
 

@@ -34,7 +34,7 @@ template <class CAN> __device__ __forceinline__ bool pack_regular(const CAN &c, 
     return true;
 }
 
-enum RowOp { OP_BF_INSERT, OP_BF_TEST, OP_BF_INC, OP_BF_GET, OP_BF_INDEX, OP_MAP_TEST, OP_MAP_INC, OP_MAP_GET, OP_WEIGHT };
+enum RowOp { OP_BF_INSERT, OP_BF_TEST, OP_BF_INC, OP_BF_GET, OP_BF_INDEX, OP_MAP_TEST, OP_MAP_INC, OP_MAP_GET, OP_MAP_SET, OP_WEIGHT };
 
 // One thread per row.  H4/H5/H7/H8 (bloom_filter.hpp:81-125) and H9
 // (kmap.hpp:99-131) in batch form, plus the mixed lookup of set_coverages
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
     const u8 *row = rows + i * stride;
     const int k = row_len(row, (int)stride);
     CanonBytes<RowIn> can(RowIn{row}, k);
-    bool want_map = OP == OP_MAP_TEST || OP == OP_MAP_INC || OP == OP_MAP_GET;
+    bool want_map = OP == OP_MAP_TEST || OP == OP_MAP_INC || OP == OP_MAP_GET || OP == OP_MAP_SET;
     if (OP == OP_WEIGHT) want_map = is_ref[i] != 0;
     if (want_map) {
         U128 key;
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
         if (irregular) irregular[i] = regular ? 0 : 1;
         if (OP == OP_MAP_TEST) ((u8 *)out)[i] = s >= 0;
         if (OP == OP_MAP_INC && s >= 0) atomicAdd(&map.vals[s], counters[i]);
+        if (OP == OP_MAP_SET && s >= 0) map.vals[s] = counters[i]; // index load: the stored value of an imported key
         if (OP == OP_MAP_GET || OP == OP_WEIGHT) ((i32 *)out)[i] = s >= 0 ? (i32)map.vals[s] : 0;
         return;
     }

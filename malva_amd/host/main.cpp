@@ -48,7 +48,10 @@ const char *USAGE =
     "      -u, --uniform                     use uniform a priori probabilities (default:false)\n"
     "      -v, --verbose                     output COVS and GTS in INFO column (default: false)\n"
     "      -1, --haploid                     run MALVA in haploid mode (default: false)\n"
-    "      -d, --device                      GPU to run on (default:0)          [this build]\n"
+    "      -d, --device                      first GPU to run on (default:0)                     [this build]\n"
+    "      -g, --gpus                        GPUs to use, devices -d .. -d+N-1 (default:1)       [this build]\n"
+    "                                        call: the k-mer table is sharded over them, the per-allele counters\n"
+    "                                        are all-reduced over RCCL, the variants are split between them\n"
     "\n"
     "  <kmc_output_prefix>: <prefix>.txt or <prefix> holding `kmc_tools transform <db> dump` text\n"
     "  (one `KMER<tab>count` per line).\n"
@@ -61,7 +64,7 @@ struct Options { // argument_parser.hpp:51-66
     unsigned max_coverage = 200;
     uint64_t bf_size = 1ULL << 35;
     bool strip_chr = false, uniform = false, verbose = false, haploid = false;
-    int device = 0;
+    int device = 0, gpus = 1;
     std::string fasta_path, vcf_path, kmc_path;
 };
 
@@ -76,10 +79,11 @@ bool parse_arguments(int argc, char **argv, Options &o)
                                       {"uniform", required_argument, nullptr, 'u'},     {"verbose", no_argument, nullptr, 'v'},
                                       {"haplod", no_argument, nullptr, '1'},            {"haploid", no_argument, nullptr, '1'},
                                       {"device", required_argument, nullptr, 'd'},      {"help", no_argument, nullptr, 'h'},
+                                      {"gpus", required_argument, nullptr, 'g'},
                                       {nullptr, 0, nullptr, 0}};
     bool die = false;
     optind = 1;
-    for (int c; (c = getopt_long(argc, argv, "k:r:e:s:f:c:b:d:hpuv1", longopts, nullptr)) != -1;) {
+    for (int c; (c = getopt_long(argc, argv, "k:r:e:s:f:c:b:d:g:hpuv1", longopts, nullptr)) != -1;) {
         std::istringstream arg(optarg ? optarg : "");
         switch (c) {
         case 'p': o.strip_chr = true; break;
@@ -95,6 +99,7 @@ bool parse_arguments(int argc, char **argv, Options &o)
             o.bf_size *= 1ULL << 33; // "GB" on the command line, 2^33 bits each (argument_parser.hpp:119-123)
             break;
         case 'd': arg >> o.device; break;
+        case 'g': arg >> o.gpus; break;
         case 'v': o.verbose = true; break;
         case '1': o.haploid = true; break;
         case '?': die = true; break;
@@ -106,6 +111,10 @@ bool parse_arguments(int argc, char **argv, Options &o)
         die = true;
     } else if (argc - optind > 3) {
         std::cerr << "malva : too many arguments\n";
+        die = true;
+    }
+    if (o.gpus < 1 || o.gpus > 64) {
+        std::cerr << "malva : --gpus must be 1..64\n";
         die = true;
     }
     if (die) {
@@ -273,10 +282,32 @@ void save_index(Device &dev, const Options &o)
     if (gzclose(f) != Z_OK) throw std::runtime_error("index file: close failed");
 }
 
-void load_index(Device &dev, const Options &o)
+// every device of a multi-GPU call holds the whole index (the read-only structures are replicated):
+// the file is read once and imported into all contexts side by side
+template <class F> void on_all_devices(std::vector<Device> &devs, F f)
+{
+    if (devs.size() == 1) return f(devs[0], 0);
+    std::vector<std::exception_ptr> errs(devs.size());
+    std::vector<std::thread> pool;
+    for (size_t d = 0; d < devs.size(); ++d)
+        pool.emplace_back([&, d]() {
+            try {
+                f(devs[d], d);
+            } catch (...) {
+                errs[d] = std::current_exception();
+            }
+        });
+    for (auto &t : pool) t.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
+void load_index(std::vector<Device> &devs, const Options &o)
 {
     gzFile f = gzopen(index_path(o).c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open index " + index_path(o) + " (run `malva-geno index` with the same -k -r -b first)");
+    struct stat st;
+    const uint64_t file_bytes = stat(index_path(o).c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
     char magic[8];
     gz_get(f, magic, 8);
     uint64_t hdr[3];
@@ -285,23 +316,45 @@ void load_index(Device &dev, const Options &o)
         gzclose(f);
         throw std::runtime_error("index " + index_path(o) + " was built with other -k/-r/-b");
     }
-    for (int which : {MG_BF_CTX, MG_BF_ALT}) {
+    // a corrupt length must not turn into a huge allocation: a filter holds at most bf_size set bits and fewer than
+    // 2^32 counters (mg_bf_finalize), and no field can promise more bytes than gzip can have packed into the file
+    const uint64_t most = std::min<uint64_t>(o.bf_size, 0xFFFFFFFEULL), inflated_cap = file_bytes * 1100 + (1u << 20);
+    struct Filter {
+        uint64_t mode = 0;
+        std::vector<uint64_t> pos;
+        std::vector<uint16_t> cnt;
+    } filt[2];
+    for (int i = 0; i < 2; ++i) { // payload order: context_bf, bf
         uint64_t h2[2];
         gz_get(f, h2, 2);
-        std::vector<uint64_t> pos(h2[1]);
-        std::vector<uint16_t> cnt(h2[1]);
-        gz_get(f, pos.data(), pos.size());
-        gz_get(f, cnt.data(), cnt.size());
-        dev.check(mg_bf_import_sparse(dev.ctx, which, (int)h2[0], o.bf_size, pos.data(), cnt.data(), h2[1]), "mg_bf_import_sparse");
+        if (h2[0] > 1 || h2[1] > most || h2[1] * 10 > inflated_cap) {
+            gzclose(f);
+            throw std::runtime_error("index " + index_path(o) + " is corrupt (filter header)");
+        }
+        filt[i].mode = h2[0];
+        filt[i].pos.resize(h2[1]);
+        filt[i].cnt.resize(h2[1]);
+        gz_get(f, filt[i].pos.data(), filt[i].pos.size());
+        gz_get(f, filt[i].cnt.data(), filt[i].cnt.size());
     }
     uint64_t nkeys = 0;
     gz_get(f, &nkeys, 1);
+    if (nkeys > 0xFFFFFFFEULL || nkeys * (STRIDE + 4) > inflated_cap) {
+        gzclose(f);
+        throw std::runtime_error("index " + index_path(o) + " is corrupt (key count)");
+    }
     std::vector<char> rows(nkeys * STRIDE);
     std::vector<int32_t> vals(nkeys);
     gz_get(f, rows.data(), rows.size());
     gz_get(f, vals.data(), vals.size());
     gzclose(f);
-    if (nkeys) dev.check(mg_map_import(dev.ctx, rows.data(), STRIDE, nkeys, vals.data()), "mg_map_import");
+    on_all_devices(devs, [&](Device &dev, size_t) {
+        const int which[2] = {MG_BF_CTX, MG_BF_ALT};
+        for (int i = 0; i < 2; ++i)
+            dev.check(mg_bf_import_sparse(dev.ctx, which[i], (int)filt[i].mode, o.bf_size, filt[i].pos.data(), filt[i].cnt.data(), filt[i].pos.size()),
+                      "mg_bf_import_sparse");
+        if (nkeys) dev.check(mg_map_import(dev.ctx, rows.data(), STRIDE, nkeys, vals.data()), "mg_map_import");
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -468,12 +521,17 @@ inline void parse_table_line(const char *p, const char *e, const Options &o, Tab
 // host cores, 64 MiB of text per task (a line belongs to the task that holds its first byte), and the parsed
 // pieces are scanned by THIS thread in whatever order they complete -- the counter updates commute.  A
 // compressed dump is inflated and parsed by one thread.
-void scan_table(Device &dev, const Options &o, const std::string &path)
+//
+// With several GPUs the table shards by rows: every device has a consumer thread that takes the next parsed piece
+// and scans it into ITS context's counters; one all-reduce over RCCL then makes every device hold the whole
+// table's counters.
+void scan_table(std::vector<Device> &devs, const Options &o, const std::string &path)
 {
-    uint64_t total = 0;
+    std::atomic<uint64_t> total{0};
     OddRows odd;
-    auto scan_piece = [&](TablePiece &t) {
-        if (!t.cnt.empty()) dev.check(mg_kmc_scan(dev.ctx, t.hi.data(), t.lo.data(), t.cnt.data(), t.cnt.size()), "mg_kmc_scan");
+    Device &dev = devs[0];
+    auto scan_piece_on = [&](Device &d, TablePiece &t) {
+        if (!t.cnt.empty()) d.check(mg_kmc_scan(d.ctx, t.hi.data(), t.lo.data(), t.cnt.data(), t.cnt.size()), "mg_kmc_scan");
         total += t.cnt.size();
         t.clear();
     };
@@ -543,24 +601,32 @@ void scan_table(Device &dev, const Options &o, const std::string &path)
         };
         std::vector<std::thread> pool;
         for (unsigned i = 0; i < n_threads; ++i) pool.emplace_back(worker);
-        for (;;) {
-            TablePiece t;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !done.empty() || finished_threads == n_threads; });
-                if (done.empty()) break;
-                t = std::move(done.front());
-                done.pop_front();
-                cv.notify_all();
+        auto consumer = [&](Device &d) { // one per device; this thread is device 0's
+            for (;;) {
+                TablePiece t;
+                bool failed;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !done.empty() || finished_threads == n_threads; });
+                    if (done.empty()) break;
+                    t = std::move(done.front());
+                    done.pop_front();
+                    failed = !error.empty();
+                    cv.notify_all();
+                }
+                try {
+                    if (!failed) scan_piece_on(d, t);
+                } catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (error.empty()) error = e.what();
+                    cv.notify_all();
+                }
             }
-            try {
-                if (error.empty()) scan_piece(t);
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (error.empty()) error = e.what();
-                cv.notify_all();
-            }
-        }
+        };
+        std::vector<std::thread> consumers;
+        for (size_t d = 1; d < devs.size(); ++d) consumers.emplace_back([&, d]() { consumer(devs[d]); });
+        consumer(devs[0]);
+        for (auto &th : consumers) th.join();
         for (auto &th : pool) th.join();
         munmap((void *)base, size);
         if (!error.empty()) throw std::runtime_error(error);
@@ -570,11 +636,12 @@ void scan_table(Device &dev, const Options &o, const std::string &path)
         TablePiece t;
         std::string line;
         const size_t piece = 1u << 24;
+        size_t turn = 0; // one inflating thread: the pieces still go round the devices, so the exchange is exercised
         while (in.next(line)) {
             parse_table_line(line.data(), line.data() + line.size(), o, t, odd);
-            if (t.cnt.size() == piece) scan_piece(t);
+            if (t.cnt.size() == piece) scan_piece_on(devs[turn++ % devs.size()], t);
         }
-        scan_piece(t);
+        scan_piece_on(devs[turn % devs.size()], t);
     }
     total += odd.cnt.size();
     if (odd.cnt.size()) { // main.cpp:495-499 through the ASCII batch calls
@@ -590,8 +657,27 @@ void scan_table(Device &dev, const Options &o, const std::string &path)
                 pc.push_back(odd.cnt[i]);
             }
         if (pass.n) dev.check(mg_bf_increment(dev.ctx, MG_BF_ALT, pass.data.data(), STRIDE, pass.n, pc.data()), "mg_bf_increment");
+        // device 0's counters join the all-reduce below; exact-map keys the packed table cannot hold live in a host
+        // list inside each context, which no collective reaches: the other devices get those increments directly
+        Rows irr;
+        std::vector<int32_t> irr_c;
+        for (size_t i = 0; i < odd.cnt.size(); ++i) {
+            const std::string kmer(&odd.kmer.data[i * STRIDE]);
+            if (kmer.find_first_not_of("ACGT") != std::string::npos) {
+                irr.add(kmer);
+                irr_c.push_back((int32_t)odd.cnt[i]);
+            }
+        }
+        for (size_t d = 1; d < devs.size() && irr.n; ++d)
+            devs[d].check(mg_map_increment(devs[d].ctx, irr.data.data(), STRIDE, irr.n, irr_c.data()), "mg_map_increment");
     }
-    std::cerr << "[malva-geno] scanned " << total << " k-mers" << std::endl;
+    if (devs.size() > 1) { // the exchange step: ncclAllReduce(sum, uint32) of [bf counters | map counters] on every device
+        std::vector<mg_ctx *> ctxs;
+        for (auto &d : devs) ctxs.push_back(d.ctx);
+        dev.check(mg_counters_allreduce_all(ctxs.data(), (int)ctxs.size()), "mg_counters_allreduce_all");
+        for (auto &d : devs) d.check(mg_synchronize(d.ctx), "mg_synchronize");
+    }
+    std::cerr << "[malva-geno] scanned " << total << " k-mers" << (devs.size() > 1 ? " on " + std::to_string(devs.size()) + " devices" : std::string()) << std::endl;
 }
 
 // one output record waiting for its device results
@@ -654,14 +740,27 @@ int call_main(const Options &o)
         std::cerr << "ERROR: cannot open " << o.kmc_path << std::endl;
         return 1;
     }
-    Device dev;
-    if (mg_create(&dev.ctx, o.device, o.k, o.ref_k, o.bf_size) != MG_OK) {
-        std::cerr << "ERROR: no usable MI355X/HIP device " << o.device << "; this build has no CPU path" << std::endl;
-        return 1;
+    // --gpus N: one context per device -d .. -d+N-1.  MALVA_GENO_SHARE_DEVICE=1 puts all N contexts on device -d: the
+    // N-way layout (sharded scan, exchange, split genotyping) rehearsed on a one-GPU box, the exchange then being a
+    // kernel instead of RCCL (which rejects two ranks on one device).
+    const bool share_device = getenv("MALVA_GENO_SHARE_DEVICE") && atoi(getenv("MALVA_GENO_SHARE_DEVICE")) != 0;
+    std::vector<Device> devs((size_t)o.gpus);
+    for (int d = 0; d < o.gpus; ++d)
+        if (mg_create(&devs[(size_t)d].ctx, share_device ? o.device : o.device + d, o.k, o.ref_k, o.bf_size) != MG_OK) {
+            std::cerr << "ERROR: no usable MI355X/HIP device " << (share_device ? o.device : o.device + d) << "; this build has no CPU path" << std::endl;
+            return 1;
+        }
+    if (o.gpus > 1) {
+        std::vector<mg_ctx *> ctxs;
+        for (auto &d : devs) ctxs.push_back(d.ctx);
+        devs[0].check(mg_comm_init_all(ctxs.data(), o.gpus), "mg_comm_init_all");
+        int backend = MG_COMM_NONE;
+        mg_comm_info(devs[0].ctx, nullptr, nullptr, &backend);
+        std::cerr << "[malva-geno] " << o.gpus << " contexts, exchange: " << (backend == MG_COMM_RCCL ? "RCCL all-reduce" : "one device, kernel sum") << std::endl;
     }
-    load_index(dev, o);
+    load_index(devs, o);
     pelapsed("Reference processed");
-    scan_table(dev, o, table); // main.cpp:482-500
+    scan_table(devs, o, table); // main.cpp:482-500
     pelapsed("BF weights created");
 
     // concatenated reference for the fused isolated path
@@ -672,7 +771,7 @@ int call_main(const Options &o)
             contig_base[name] = all.size();
             all += refs.seqs.at(name);
         }
-        dev.check(mg_reference_upload(dev.ctx, all.data(), all.size()), "mg_reference_upload");
+        on_all_devices(devs, [&](Device &d, size_t) { d.check(mg_reference_upload(d.ctx, all.data(), all.size()), "mg_reference_upload"); });
     }
     {
         VcfReader hdr(o.vcf_path, "-");
@@ -701,10 +800,12 @@ int call_main(const Options &o)
     struct Job {
         std::vector<Rec> recs;
         Batch iso, gen;
+        size_t device = 0; // batches go round the devices: after the exchange every one of them holds the whole table's counters
     };
-    auto process = [&](Job &job) {
+    auto process = [&](Job &job) -> std::string {
         std::vector<Rec> &recs = job.recs;
         Batch &iso = job.iso, &gen = job.gen;
+        Device &dev = devs[job.device];
         if (iso.n()) {
             const size_t n = iso.n(), na = iso.var_allele_off.back();
             iso.cov.resize(na); iso.g1.resize(n); iso.g2.resize(n); iso.gq.resize(n); iso.status.resize(n);
@@ -825,19 +926,28 @@ int call_main(const Options &o)
             out += gname(b.g1[r.slot], b.g2[r.slot]); // early-outs and "nothing beats 0.0" come back as 0 / 0/0
             out += ":" + std::to_string(b.gq[r.slot]) + "\n";
         }
-        std::cout << out;
+        return out;
     };
-    std::future<void> in_flight;
+    // as many batches in flight as there are devices; their text leaves in submission order
+    std::deque<std::future<std::string>> in_flight;
+    size_t jobs_started = 0;
+    auto drain = [&](size_t keep) {
+        while (in_flight.size() > keep) {
+            std::cout << in_flight.front().get(); // (or the batch's exception comes back here)
+            in_flight.pop_front();
+        }
+    };
     auto run_and_print = [&]() {
-        if (in_flight.valid()) in_flight.get(); // the previous batch is out (or its exception comes back here)
+        drain(devs.size() - 1);
         auto job = std::make_shared<Job>();
         job->recs = std::move(recs);
         job->iso = std::move(iso);
         job->gen = std::move(gen);
+        job->device = jobs_started++ % devs.size();
         recs.clear();
         iso = Batch();
         gen = Batch();
-        in_flight = std::async(std::launch::async, [&process, job]() { process(*job); });
+        in_flight.push_back(std::async(std::launch::async, [&process, job]() { return process(*job); }));
     };
 
     auto prefix_of = [&](const Variant &v) {
@@ -849,7 +959,12 @@ int call_main(const Options &o)
     };
 
     const size_t n = for_each_block(vcf, o, refs, false, nullptr, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
-        const bool lone = vb.is_lone_short() && contig_base.count(seq_name);
+        // The fused kernel reads ceil(k/2) bases to the right of the REF allele.  A lone variant whose right flank
+        // would cross the contig end (a deletion longer than about k/2 within k of it) gets a CLIPPED, shorter
+        // k-mer in the reference (std::string(reference, pos, n), var_block.hpp:187) and in extract_lone at index
+        // time: such a variant takes the general path, whose device enumerator hands clipped windows to the host.
+        const bool lone = vb.is_lone_short() && contig_base.count(seq_name) &&
+                          (long)vb.vars[0].ref_pos + vb.vars[0].ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
         if (lone) {
             const Variant &v = vb.vars[0];
             const uint32_t A = (uint32_t)v.n_alleles();
@@ -904,7 +1019,7 @@ int call_main(const Options &o)
         if (recs.size() >= batch_records) run_and_print();
     });
     run_and_print();
-    in_flight.get();
+    drain(0);
     std::cout.flush();
     pelapsed("Processed " + std::to_string(n) + " variants");
     pelapsed("Execution completed");

@@ -80,6 +80,16 @@ def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref
     with gzip.open(table + ".txt", "wb") as dst:
         dst.write(data)
     assert run_cli(["call"] + args) == got
+    # --gpus 3: the table sharded over three contexts (pieces of the gzip stream go round them), one exchange, the
+    # record batches split between them -- on a one-GPU box the three contexts share the device
+    # (MALVA_GENO_SHARE_DEVICE) and the exchange is the kernel sum instead of RCCL; same bytes out
+    import torch
+    share = {} if torch.cuda.device_count() >= 3 else {"MALVA_GENO_SHARE_DEVICE": "1"}
+    env3 = dict(os.environ, MALVA_GENO_BATCH="61", **share)
+    assert run_cli(["call", "--gpus", "3"] + args, env=env3) == got
+    with open(table + ".txt", "wb") as dst:                      # and through the mapped, multi-threaded reader
+        dst.write(data)
+    assert run_cli(["call", "-g", "3"] + args, env=dict(env3, MALVA_GENO_TABLE_TASK="700")) == got
 
 
 def test_sars_cov2_panel_config_c1(tmp_path, golden_dir):
