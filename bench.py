@@ -51,6 +51,13 @@ def main():
     ap.add_argument("--kmers", type=float, default=1e8, help="k-mer table rows per GPU")
     ap.add_argument("--variants", type=float, default=1e6, help="isolated biallelic SNPs per GPU")
     ap.add_argument("--b", type=int, default=4, help="filter size in units of 2^33 bits (malva-geno -b)")
+    ap.add_argument("--k", type=int, default=35, help="signature k-mer length (malva-geno -k)")
+    ap.add_argument("--r", type=int, default=43, help="context k-mer length of the KMC table (malva-geno -r); 63 = config C5's")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --kmers is the WHOLE table, sharded over the ranks (north_star's 8-GPU claim: "
+                         "--strong --kmers 3e9 --variants 8e7 --b 16); default is weak scaling, --kmers rows per GPU")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="N > 1: native = mg_counters_allreduce (RCCL inside libmalva_hip.so); torch = torch.distributed over the aliased vector")
     ap.add_argument("--cpu-sample", type=float, default=5e6, help="rows of the table the CPU oracle scans (0 = skip)")
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
@@ -92,8 +99,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    K, R = 35, 43
+    K, R = args.k, args.r
     n_rows = int(args.kmers)
+    if args.strong:                                          # fixed total work: this rank's share of the table
+        from malva_amd.dist import shard_range as _sr
+        a_, b_ = _sr(int(args.kmers), rank, world)
+        n_rows = b_ - a_
     n_vars_total = int(args.variants) * (world if args.grow_panel else 1)
     from malva_amd.dist import shard_range
     v0, v1 = shard_range(n_vars_total, rank, world)
@@ -105,7 +116,11 @@ def main():
     panel = synth.snp_panel(n_vars_total, seed=20261003)
     log(rank, "panel: %d SNPs on a %.3g-base genome (%.1fs)" % (n_vars_total, panel.genome.size, time.time() - t0))
     ctx = Context(K, R, bf_bits, device=local)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit stream for the library's kernels AND torch's work on the aliased counters (a NULL handle would
+    # mean the library's private stream: torch's default stream has handle 0)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    ctx.set_stream(work_stream.cuda_stream)
     if args.no_summary:
         ctx.set_option("use_summary", 0)
     if args.scan_ablate:
@@ -115,7 +130,7 @@ def main():
         ctx.set_option(name, int(value))
     t0 = time.time()
     sig, _ = synth.snp_signature_rows(panel, K)
-    stride = 40
+    stride = (K + 1 + 7) // 8 * 8
     batch = 1 << 20
     for a in range(0, sig.shape[0], 2 * batch):
         chunk = sig[a:a + 2 * batch]
@@ -163,6 +178,28 @@ def main():
     d_probs = torch.zeros(3 * n_vars, dtype=torch.float64, device=dev)   # normalised likelihoods (GTS) + workspace
     cptr, n_bf, n_map = ctx.counters_view()                 # [bf counters | map counters], one allocation inside the context
     d_counters = alias_int32(cptr, n_bf + n_map, dev)         # reduced in place: no export/import copies
+    exchange = "none"
+    if world > 1:
+        exchange = "torch.distributed all_reduce(sum,int32), in place"
+        if args.exchange == "native" and not args.rehearse_on_one_gpu:
+            # RCCL inside the library: rank 0's ncclUniqueId travels over the process group, then every step's
+            # exchange is mg_counters_allreduce on the library's stream.  If the library cannot bring RCCL up on
+            # this node the run still measures (torch's RCCL, same collective) and the JSON line says so.
+            from malva_amd import capi
+            try:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(rank, world, uid[0])
+                ok = torch.ones(1, dtype=torch.int32, device=dev)
+            except Exception as e:          # noqa: BLE001 -- reported, never silent
+                log(0, "rank %d: native exchange unavailable (%s)" % (rank, e))
+                ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                exchange = "mg_counters_allreduce: ncclAllReduce(sum,uint32) inside libmalva_hip.so, in place"
+            else:
+                exchange += " (native RCCL init failed on some rank: see stderr)"
+    native = exchange.startswith("mg_counters_allreduce")
 
     scan_ms = []
     packed_steps = []
@@ -170,7 +207,9 @@ def main():
     def step(record=False):
         ctx.counters_reset()
         ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
-        if world > 1:
+        if world > 1 and native:
+            ctx.counters_allreduce()
+        elif world > 1:
             # a large vector is worth halving on the wire; for a small one the guard's extra round trip costs more
             if 4.0 * d_counters.numel() >= args.pack16_min_mb * (1 << 20):
                 packed_steps.append(allreduce_counters_packed_(d_counters))
@@ -290,12 +329,16 @@ def main():
         if t.get("units_per_launch") == n_rows and t.get("bf_bits") == bf_bits:
             traffic = t["hbm_bytes_per_launch"]
     if rank == 0:
-        total_kmers = n_rows * world * args.steps
+        total_rows = int(args.kmers) if args.strong else n_rows * world
+        total_kmers = total_rows * args.steps
         total_vars = n_vars_total * args.steps
         rows_per_launch = min(n_rows, 1 << 27)      # mg_kmc_scan_device walks the table in chunks of 2^27 rows; the first is timed
         achieved = SCAN_BYTES_PER_KMER * rows_per_launch / (filt_ms * 1e-3) / 1e9
+        scan_ms_sum = filt_ms + probe_ms + hits_ms         # the three kernels of one scan chunk, back to back on one stream
+        achieved_scan = SCAN_BYTES_PER_KMER * rows_per_launch / (scan_ms_sum * 1e-3) / 1e9
+        spec = "%d,%d" % (K, R) if (K, R) in ((35, 43), (35, 63)) else "0,0"
         out = {
-            "metric": "KMC k-mers scanned/sec (whole call step: scan + counter all-reduce + genotyping), k=35 r=43",
+            "metric": "KMC k-mers scanned/sec (whole call step: scan + counter all-reduce + genotyping), k=%d r=%d" % (K, R),
             "value": total_kmers / elapsed,
             "unit": "kmers/s",
             "variants_per_s": total_vars / elapsed,
@@ -304,23 +347,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "C3%s: %.3g KMC k-mers per GPU (table of %.3g rows sharded by rows) against a panel of %.3g isolated biallelic SNPs, "
-                                   "k=35 r=43 b=%d, table resident in HBM" % (" per GPU" if args.grow_panel or world == 1 else " table x N, fixed panel",
-                                                                               n_rows, n_rows * world, n_vars_total, args.b),
-                       "kmers_per_gpu": n_rows, "kmers_total": n_rows * world, "panel_variants": n_vars_total, "variants_genotyped_per_gpu": n_vars,
-                       "bf_bits": bf_bits, "parallelism": "table rows x%d (weak), panel genotyping split x%d, index replicated" % (world, world),
+            "config": {"workload": "%s%s: %.3g KMC k-mers per GPU (table of %.3g rows sharded by rows) against a panel of %.3g isolated biallelic SNPs, "
+                                   "k=%d r=%d b=%d, table resident in HBM" % (
+                                       "C3" if (n_vars_total, args.b, K, R) == (1000000, 4, 35, 43) else "custom",
+                                       " per GPU" if args.grow_panel or world == 1 else (" whole table / N, fixed panel" if args.strong else " table x N, fixed panel"),
+                                       n_rows, total_rows, n_vars_total, K, R, args.b),
+                       "kmers_per_gpu": n_rows, "kmers_total": total_rows, "panel_variants": n_vars_total, "variants_genotyped_per_gpu": n_vars,
+                       "k": K, "ref_k": R, "bf_bits": bf_bits,
+                       "parallelism": "table rows x%d (%s), panel genotyping split x%d, index replicated" % (world, "strong" if args.strong else "weak", world),
                        "summary_bitmaps": not args.no_summary,
-                       "exchange": ("none" if world == 1 else "all_reduce(sum,int32) over %d counters, in place%s" % (
-                           n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
-            "roofline": {"kernel": ("scan_bin_kernel<35,43,4> + scan_bin_gate_kernel<35,43> (partitioned second level, %d slices)" % ctx.get_option("scan_bins")
-                                    if ctx.get_option("scan_bins") else "scan_filter_kernel<35,43,2>"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "exchange": ("none" if world == 1 else "%s over %d counters%s" % (
+                           exchange, n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
+            "roofline": {"kernel": ("scan_bin_kernel<%s,4> + scan_bin_gate_kernel<%s> (partitioned second level, %d slices)" % (spec, spec, ctx.get_option("scan_bins"))
+                                    if ctx.get_option("scan_bins") else "scan_filter_kernel<%s,2>" % spec), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": rows_per_launch, "avg_launch_ms": filt_ms},
+            # the whole H10 loop (filter + probe + hit kernels, summed): the fraction SURVEY 8(d)'s 44 B/k-mer budget is about
+            "roofline_scan": {"kernels": "scan_filter + scan_probe + scan_hits", "bound": "hbm", "achieved": achieved_scan, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": achieved_scan / HBM_PEAK_GBS, "ms": scan_ms_sum, "bytes_per_unit": SCAN_BYTES_PER_KMER,
+                              "units_per_launch": rows_per_launch},
             "kernels_ms": {"scan_filter": filt_ms, "scan_probe": probe_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg,
                            "gate_open_rows": n_open, "bf_hit_rows": n_hits},
             "genotype_roofline": {"achieved": GENO_BYTES_PER_SNP * n_vars / (geno_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

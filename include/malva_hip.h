@@ -117,6 +117,25 @@ int mg_ref_scan(mg_ctx *ctx, const char *contig, size_t len);
 int mg_kmc_scan(mg_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n);
 int mg_kmc_scan_device(mg_ctx *ctx, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n);
 
+/* KMC database feed: CKMCFile::OpenForListing / ReadNextKmer / CKmerAPI::to_string (main.cpp:444-449, 482-490; the KMC
+ * API is a third-party library the reference links, absent from its checkout: format restated from KMC's published
+ * database layout, "parity unpinned" -- DESIGN.md).  The host hands over what the two files hold and parses nothing:
+ *   mg_kmc_set_lut       <db>.kmc_pre: the prefix table (every bin's 4^lut_prefix_len entries, concatenated: first
+ *                        record index of each prefix), record geometry and the [min_count, max_count] listing filter
+ *   mg_kmc_scan_records  a run of raw <db>.kmc_suf records (suffix bytes + little-endian counter), `first_record` =
+ *                        index of the first one in the database; decoded to table rows ON THE DEVICE (prefix from the
+ *                        table, suffix from the record), then scanned as mg_kmc_scan does.  10 bytes per 43-mer cross
+ *                        PCIe instead of 20.  Upload and scan of consecutive pieces overlap (two staging slots);
+ *                        buffers from mg_host_alloc (pinned) make the uploads asynchronous.
+ *   mg_kmc_decode_records  the decoded rows themselves (tests / inspection). */
+int mg_host_alloc(void **out, size_t bytes);
+int mg_host_free(void *p);
+int mg_kmc_set_lut(mg_ctx *ctx, const uint64_t *lut, size_t n_lut, uint32_t lut_prefix_len, uint32_t suffix_bytes,
+                   uint32_t counter_bytes, uint32_t min_count, uint64_t max_count, uint64_t total_records);
+int mg_kmc_scan_records(mg_ctx *ctx, const void *records, size_t n, uint64_t first_record);
+int mg_kmc_decode_records(mg_ctx *ctx, const void *records, size_t n, uint64_t first_record, uint64_t *hi_out,
+                          uint64_t *lo_out, uint32_t *cnt_out);
+
 /* ---- multi-GPU exchange step --------------------------------------------- */
 
 /* The scan's only state is two commutative wrapping-u32 sums:

@@ -81,6 +81,11 @@ def lib():
         "mg_ref_scan": [vp, vp, sz],
         "mg_kmc_scan": [vp, vp, vp, vp, sz],
         "mg_kmc_scan_device": [vp, vp, vp, vp, sz],
+        "mg_host_alloc": [C.POINTER(vp), sz],
+        "mg_host_free": [vp],
+        "mg_kmc_set_lut": [vp, vp, sz, u32, u32, u32, u32, u64, u64],
+        "mg_kmc_scan_records": [vp, vp, sz, u64],
+        "mg_kmc_decode_records": [vp, vp, sz, u64, vp, vp, vp],
         "mg_counters_size": [vp, vp, vp],
         "mg_counters_export_device": [vp, vp],
         "mg_counters_import_device": [vp, vp],
@@ -124,6 +129,7 @@ def lib():
 EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_synchronize", "mg_bf_insert", "mg_bf_test",
             "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
             "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
+            "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
             "mg_counters_allreduce_all",
@@ -358,6 +364,25 @@ class Context:
 
     def kmc_scan_device(self, d_hi, d_lo, d_cnt, n):
         self._ck(self._L.mg_kmc_scan_device(self.h, C.c_void_p(d_hi), C.c_void_p(d_lo), C.c_void_p(d_cnt), n))
+
+    # KMC database feed
+    def kmc_set_lut(self, lut, lut_prefix_len, suffix_bytes, counter_bytes, min_count, max_count, total_records):
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        self._ck(self._L.mg_kmc_set_lut(self.h, _p(lut), lut.size, lut_prefix_len, suffix_bytes, counter_bytes, min_count, max_count,
+                                        total_records))
+        self._kmc_rec = suffix_bytes + counter_bytes
+
+    def kmc_scan_records(self, records, first_record=0):
+        records = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+        assert records.size % self._kmc_rec == 0
+        self._ck(self._L.mg_kmc_scan_records(self.h, _p(records), records.size // self._kmc_rec, first_record))
+
+    def kmc_decode_records(self, records, first_record=0):
+        records = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+        n = records.size // self._kmc_rec
+        hi, lo, cnt = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
+        self._ck(self._L.mg_kmc_decode_records(self.h, _p(records), n, first_record, _p(hi), _p(lo), _p(cnt)))
+        return hi, lo, cnt
 
     def scan_stats(self):
         """-> (filter ms, probe ms, hits ms, open rows, bf-hit rows)"""

@@ -89,6 +89,19 @@ __device__ __forceinline__ U128 shr128(U128 v, int s) // 0 <= s < 128
     }
     return r;
 }
+__device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
+{
+    U128 r;
+    if (s == 0) return v;
+    if (s < 64) {
+        r.hi = (v.hi << s) | (v.lo >> (64 - s));
+        r.lo = v.lo << s;
+    } else {
+        r.hi = v.lo << (s - 64);
+        r.lo = 0;
+    }
+    return r;
+}
 __device__ __forceinline__ U128 mask128(int bits) // 0 < bits <= 128
 {
     U128 m;

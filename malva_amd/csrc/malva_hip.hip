@@ -111,6 +111,14 @@ struct mg_ctx {
     int comm_rank = 0, comm_world = 0;
     std::vector<mg_ctx *> local_group;
     hipEvent_t ev_x = nullptr; // orders the local-group exchange between the contexts' streams
+    // host-fed scans (mg_kmc_scan, mg_kmc_scan_records): two staging slots, uploads on their own stream beside the scan
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    Scratch s_stage[2][3], s_raw[2];
+    u64 *d_kmc_lut = nullptr; // <db>.kmc_pre's prefix table (+ guard), mg_kmc_set_lut
+    u64 kmc_n_lut = 0;
+    u32 kmc_prefix_len = 0, kmc_suffix_bytes = 0, kmc_counter_bytes = 0, kmc_min_count = 0;
+    u64 kmc_max_count = 0;
     std::string err;
 };
 
@@ -492,6 +500,14 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipDeviceSynchronize();
     comm_drop(c);
     if (c->ev_x) hipEventDestroy(c->ev_x);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]);
+        if (c->ev_free[i]) hipEventDestroy(c->ev_free[i]);
+        for (auto &q : c->s_stage[i]) hipFree(q.p);
+        hipFree(c->s_raw[i].p);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    hipFree(c->d_kmc_lut);
     if (c->joined) { // the two counter arrays alias one allocation
         hipFree(c->joined);
         c->bf[MG_BF_ALT].counts = nullptr;
@@ -998,20 +1014,156 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     return MG_OK;
 }
 
+namespace {
+// Host-fed scans stream the table through the device in pieces.  Two staging slots: while the scan kernels work
+// on one, the copy stream fills the other (PCIe and HBM work overlap; with pinned host memory -- mg_host_alloc --
+// the copies are truly asynchronous, with pageable memory the runtime stages them and the host blocks per copy,
+// which still leaves the previous piece's kernels running underneath).
+int pipeline_ready(mg_ctx *c)
+{
+    if (c->copy_stream) return MG_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming));
+    }
+    return MG_OK;
+}
+constexpr size_t HOST_PIECE = 1u << 24; // rows per staged piece: 320 MB of SoA rows per slot
+} // namespace
+
 MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n)
 {
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n == 0) return MG_OK;
     if (!hi || !lo || !cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
-    const size_t piece = 1u << 26; // host table streamed through the device in 64M-row pieces
-    for (size_t r0 = 0; r0 < n; r0 += piece) {
-        const size_t nr = n - r0 < piece ? n - r0 : piece;
-        void *dh, *dl, *dc;
-        TRY(upload(c, c->s_misc[5], hi + r0, nr * 8, &dh));
-        TRY(upload(c, c->s_misc[6], lo + r0, nr * 8, &dl));
-        TRY(upload(c, c->s_misc[7], cnt + r0, nr * 4, &dc));
-        TRY(mg_kmc_scan_device(c, dh, dl, dc, nr));
+    if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
+    TRY(pipeline_ready(c));
+    const size_t cap = n < HOST_PIECE ? n : HOST_PIECE;
+    void *d[2][3];
+    for (int sl = 0; sl < 2; ++sl)
+        for (int i = 0; i < 3; ++i) TRY(scratch(c, c->s_stage[sl][i], cap * (i == 2 ? 4 : 8), &d[sl][i]));
+    size_t piece_no = 0;
+    for (size_t r0 = 0; r0 < n; r0 += HOST_PIECE, ++piece_no) {
+        const size_t nr = n - r0 < HOST_PIECE ? n - r0 : HOST_PIECE;
+        const int sl = (int)(piece_no & 1);
+        if (piece_no >= 2) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_free[sl], 0)); // the scan that used this slot is done
+        HIP_TRY(c, hipMemcpyAsync(d[sl][0], hi + r0, nr * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(d[sl][1], lo + r0, nr * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(d[sl][2], cnt + r0, nr * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->ev_up[sl], c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[sl], 0));
+        TRY(mg_kmc_scan_device(c, d[sl][0], d[sl][1], d[sl][2], nr));
+        HIP_TRY(c, hipEventRecord(c->ev_free[sl], c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller may reuse its buffers
+    return MG_OK;
+}
+
+// ---- KMC database feed -------------------------------------------------------------------------
+
+MG_EXPORT int mg_host_alloc(void **out, size_t bytes)
+{
+    if (!out) return MG_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? MG_OK : MG_ERR_NOMEM;
+}
+MG_EXPORT int mg_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) return MG_ERR_HIP;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_kmc_set_lut(mg_ctx *c, const uint64_t *lut, size_t n_lut, uint32_t lut_prefix_len, uint32_t suffix_bytes,
+                             uint32_t counter_bytes, uint32_t min_count, uint64_t max_count, uint64_t total_records)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!lut || n_lut == 0) return fail(c, MG_ERR_ARG, "mg_kmc_set_lut: empty prefix table");
+    if (lut_prefix_len == 0 || lut_prefix_len > 15) return fail(c, MG_ERR_ARG, "mg_kmc_set_lut: lut_prefix_len %u (1..15)", lut_prefix_len);
+    if (counter_bytes < 1 || counter_bytes > 4) return fail(c, MG_ERR_LIMIT, "KMC counters of %u bytes (1..4 supported: the reference reads them into a uint32)", counter_bytes);
+    if (suffix_bytes < 1 || suffix_bytes > 15 || lut_prefix_len + 4 * suffix_bytes != c->ref_k)
+        return fail(c, MG_ERR_ARG, "database k = %u (prefix %u + %u suffix bytes), context expects -r %u", lut_prefix_len + 4 * suffix_bytes,
+                    lut_prefix_len, suffix_bytes, c->ref_k);
+    if (c->ref_k > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed scan supports ref_k <= 64");
+    if (n_lut % (1ULL << (2 * lut_prefix_len)) != 0) return fail(c, MG_ERR_ARG, "prefix table of %zu entries is not a whole number of 4^%u-entry bins", n_lut, lut_prefix_len);
+    if (lut[0] != 0) return fail(c, MG_ERR_ARG, "prefix table does not start at record 0");
+    for (size_t j = 1; j < n_lut; ++j)
+        if (lut[j] < lut[j - 1] || lut[j] > total_records) return fail(c, MG_ERR_ARG, "prefix table is not ascending within the %llu records", (unsigned long long)total_records);
+    hipFree(c->d_kmc_lut);
+    c->d_kmc_lut = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_kmc_lut, (n_lut + 1) * 8));
+    HIP_TRY(c, hipMemcpy(c->d_kmc_lut, lut, n_lut * 8, hipMemcpyHostToDevice));
+    const u64 guard = ~0ULL; // above every record index
+    HIP_TRY(c, hipMemcpy(c->d_kmc_lut + n_lut, &guard, 8, hipMemcpyHostToDevice));
+    c->kmc_n_lut = n_lut;
+    c->kmc_prefix_len = lut_prefix_len;
+    c->kmc_suffix_bytes = suffix_bytes;
+    c->kmc_counter_bytes = counter_bytes;
+    c->kmc_min_count = min_count;
+    c->kmc_max_count = max_count;
+    return MG_OK;
+}
+
+MG_EXPORT int mg_kmc_scan_records(mg_ctx *c, const void *records, size_t n, uint64_t first_record)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n == 0) return MG_OK;
+    if (!records) return fail(c, MG_ERR_ARG, "NULL records");
+    if (!c->d_kmc_lut) return fail(c, MG_ERR_STATE, "mg_kmc_set_lut first");
+    if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
+    TRY(pipeline_ready(c));
+    const size_t rs = c->kmc_suffix_bytes + c->kmc_counter_bytes;
+    const size_t cap = n < HOST_PIECE ? n : HOST_PIECE;
+    void *d[2][3], *raw[2];
+    for (int sl = 0; sl < 2; ++sl) {
+        for (int i = 0; i < 3; ++i) TRY(scratch(c, c->s_stage[sl][i], cap * (i == 2 ? 4 : 8), &d[sl][i]));
+        TRY(scratch(c, c->s_raw[sl], cap * rs + 64, &raw[sl]));
+    }
+    size_t piece_no = 0;
+    for (size_t r0 = 0; r0 < n; r0 += HOST_PIECE, ++piece_no) {
+        const size_t nr = n - r0 < HOST_PIECE ? n - r0 : HOST_PIECE;
+        const int sl = (int)(piece_no & 1);
+        if (piece_no >= 2) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_free[sl], 0));
+        HIP_TRY(c, hipMemcpyAsync(raw[sl], (const char *)records + r0 * rs, nr * rs, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->ev_up[sl], c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[sl], 0));
+        hipLaunchKernelGGL(kmc_decode_kernel, dim3((unsigned)((nr + KMC_TILE - 1) / KMC_TILE)), dim3(TPB), 0, c->stream, (const u8 *)raw[sl], (u64)nr,
+                           (u64)(first_record + r0), c->kmc_suffix_bytes, c->kmc_counter_bytes, c->kmc_prefix_len, (const u64 *)c->d_kmc_lut, c->kmc_n_lut,
+                           c->kmc_min_count, c->kmc_max_count, (u64 *)d[sl][0], (u64 *)d[sl][1], (u32 *)d[sl][2]);
+        HIP_TRY(c, hipGetLastError());
+        TRY(mg_kmc_scan_device(c, d[sl][0], d[sl][1], d[sl][2], nr));
+        HIP_TRY(c, hipEventRecord(c->ev_free[sl], c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+// the decoded rows of a run of records (tests, and callers that want the table itself)
+MG_EXPORT int mg_kmc_decode_records(mg_ctx *c, const void *records, size_t n, uint64_t first_record, uint64_t *hi_out, uint64_t *lo_out,
+                                    uint32_t *cnt_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n == 0) return MG_OK;
+    if (!records || !hi_out || !lo_out || !cnt_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (!c->d_kmc_lut) return fail(c, MG_ERR_STATE, "mg_kmc_set_lut first");
+    const size_t rs = c->kmc_suffix_bytes + c->kmc_counter_bytes;
+    for (size_t r0 = 0; r0 < n; r0 += HOST_PIECE) {
+        const size_t nr = n - r0 < HOST_PIECE ? n - r0 : HOST_PIECE;
+        void *d[3], *raw;
+        for (int i = 0; i < 3; ++i) TRY(scratch(c, c->s_stage[0][i], nr * (i == 2 ? 4 : 8), &d[i]));
+        TRY(scratch(c, c->s_raw[0], nr * rs + 64, &raw));
+        HIP_TRY(c, hipMemcpyAsync(raw, (const char *)records + r0 * rs, nr * rs, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(kmc_decode_kernel, dim3((unsigned)((nr + KMC_TILE - 1) / KMC_TILE)), dim3(TPB), 0, c->stream, (const u8 *)raw, (u64)nr,
+                           (u64)(first_record + r0), c->kmc_suffix_bytes, c->kmc_counter_bytes, c->kmc_prefix_len, (const u64 *)c->d_kmc_lut, c->kmc_n_lut,
+                           c->kmc_min_count, c->kmc_max_count, (u64 *)d[0], (u64 *)d[1], (u32 *)d[2]);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(hi_out + r0, d[0], nr * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(lo_out + r0, d[1], nr * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(cnt_out + r0, d[2], nr * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return MG_OK;

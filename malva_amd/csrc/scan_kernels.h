@@ -480,6 +480,85 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
     }
 }
 
+// ---- KMC database records -> table rows -------------------------------------------------------------------
+// A KMC (>= 2, "0x200") database lists its k-mers as fixed-size records in <db>.kmc_suf: the SUFFIX of the k-mer
+// (k - p symbols, 2 bits each, first symbol in the top bits of the first byte) followed by the counter
+// (little-endian); the PREFIX (p symbols) is not stored per record: <db>.kmc_pre holds, for every bin and every
+// prefix value, the index of the first record that carries it (CKMCFile::ReadNextKmer walks that table while it
+// lists; main.cpp:482-490 is its caller).  This kernel turns a run of raw records into the scan's SoA rows on the
+// device, so the host moves 10 bytes per 43-mer over PCIe instead of 20 and parses nothing.
+//   lut[j], j < n_lut   first record of prefix (j mod 4^p) in bin j / 4^p;  lut[n_lut] = a value above every record
+// A workgroup decodes KMC_TILE consecutive records: their bytes are staged through LDS with coalesced dword loads,
+// one lane finds the table entry of the tile's first record (binary search over the whole table, once per tile),
+// the next KMC_WIN entries go to LDS and every record finds its own entry there (a tile normally spans a handful);
+// records beyond the window (runs of empty prefixes) search the global table.
+constexpr int KMC_TILE = 1024, KMC_WIN = 512, KMC_MAX_REC = 20;
+__device__ __forceinline__ u64 kmc_upper_bound(const u64 *a, u64 lo, u64 hi, u64 x) // first index in [lo, hi) with a[i] > x, else hi
+{
+    while (lo < hi) {
+        const u64 mid = lo + (hi - lo) / 2;
+        if (a[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(TPB) kmc_decode_kernel(const u8 *__restrict__ rec, u64 n, u64 first_record, u32 suffix_bytes,
+                                                         u32 counter_bytes, u32 prefix_len, const u64 *__restrict__ lut, u64 n_lut,
+                                                         u32 min_count, u64 max_count, u64 *__restrict__ hi, u64 *__restrict__ lo,
+                                                         u32 *__restrict__ cnt)
+{
+    __shared__ u32 sh_bytes[KMC_TILE * KMC_MAX_REC / 4 + 1];
+    __shared__ u64 sh_lut[KMC_WIN + 1];
+    __shared__ u64 sh_j0;
+    const u32 rs = suffix_bytes + counter_bytes;
+    const u64 t0 = (u64)blockIdx.x * KMC_TILE;
+    if (t0 >= n) return;
+    const u32 nt = (u32)min((u64)KMC_TILE, n - t0);
+    // the tile's bytes: `rec` is 4-byte aligned and t0 * rs is a multiple of 4 (KMC_TILE is); reads stay inside
+    // the buffer's padding (the launcher rounds the allocation up)
+    const u32 nd = (nt * rs + 3) / 4;
+    const u32 *src = (const u32 *)(rec + t0 * rs);
+    for (u32 i = threadIdx.x; i < nd; i += TPB) sh_bytes[i] = __builtin_nontemporal_load(src + i);
+    if (threadIdx.x == 0) sh_j0 = kmc_upper_bound(lut, 0, n_lut + 1, first_record + t0) - 1; // lut[0] == 0 <= every record
+    __syncthreads();
+    const u64 j0 = sh_j0;
+    for (u32 i = threadIdx.x; i <= (u32)KMC_WIN; i += TPB) sh_lut[i] = j0 + i <= n_lut ? lut[j0 + i] : ~0ULL;
+    __syncthreads();
+    const u8 *b8 = (const u8 *)sh_bytes;
+    const u64 pmask = prefix_len >= 32 ? ~0ULL : (1ULL << (2 * prefix_len)) - 1;
+    for (u32 q = threadIdx.x; q < nt; q += TPB) {
+        const u64 g = first_record + t0 + q;
+        u64 j;
+        if (g < sh_lut[KMC_WIN]) { // inside the window: last entry <= g
+            u32 a = 0, b = KMC_WIN;
+            while (a < b) {
+                const u32 mid = (a + b) / 2;
+                if (sh_lut[mid] <= g) a = mid + 1;
+                else b = mid;
+            }
+            j = j0 + a - 1;
+        } else
+            j = kmc_upper_bound(lut, j0 + KMC_WIN, n_lut + 1, g) - 1;
+        const u64 prefix = j & pmask;
+        const u8 *r = b8 + q * rs;
+        U128 v{0, 0};
+        for (u32 s = 0; s < suffix_bytes; ++s) { // big-endian suffix
+            v.hi = (v.hi << 8) | (v.lo >> 56);
+            v.lo = (v.lo << 8) | r[s];
+        }
+        const U128 pre = shl128(U128{prefix, 0}, (int)(8 * suffix_bytes));
+        v.lo |= pre.lo;
+        v.hi |= pre.hi;
+        u64 c = 0;
+        for (u32 s = 0; s < counter_bytes; ++s) c |= (u64)r[suffix_bytes + s] << (8 * s);
+        // CKMCFile::ReadNextKmer skips records outside [min_count, max_count]; a zero count adds nothing anywhere
+        if (c < min_count || c > max_count) c = 0;
+        hi[t0 + q] = v.hi;
+        lo[t0 + q] = v.lo;
+        cnt[t0 + q] = (u32)c;
+    }
+}
+
 // debug: hash % size of packed k-mers (M-form, klen bases)
 __global__ void __launch_bounds__(TPB) packed_index_kernel(const u64 *hi, const u64 *lo, u64 n, int klen, ModDesc mod,
                                                            u64 *out)

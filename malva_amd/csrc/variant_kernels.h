@@ -115,19 +115,6 @@ __device__ __forceinline__ void span_pack(const SpanWords &s, int n, u64 *codes,
     *codes = c;
     *bad = b;
 }
-__device__ __forceinline__ U128 shl128(U128 v, int s) // 0 <= s < 128
-{
-    U128 r;
-    if (s == 0) return v;
-    if (s < 64) {
-        r.hi = (v.hi << s) | (v.lo >> (64 - s));
-        r.lo = v.lo << s;
-    } else {
-        r.hi = v.lo << (s - 64);
-        r.lo = 0;
-    }
-    return r;
-}
 // Fast path: both flanks and the allele are pure ACGT, so the signature is assembled in
 // 2-bit form from flanks packed once per variant (shared by its alleles), canonicalised
 // with integer compares and hashed with the register-resident XXH3 -- the same code the

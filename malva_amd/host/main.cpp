@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "block.hpp"
+#include "kmc_db.hpp"
 extern "C" {
 #include "malva_hip.h"
 }
@@ -53,8 +54,8 @@ const char *USAGE =
     "                                        call: the k-mer table is sharded over them, the per-allele counters\n"
     "                                        are all-reduced over RCCL, the variants are split between them\n"
     "\n"
-    "  <kmc_output_prefix>: <prefix>.txt or <prefix> holding `kmc_tools transform <db> dump` text\n"
-    "  (one `KMER<tab>count` per line).\n"
+    "  <kmc_output_prefix>: a KMC database (<prefix>.kmc_pre + <prefix>.kmc_suf, KMC 2/3 format), read directly;\n"
+    "  or <prefix>.txt / <prefix> holding `kmc_tools transform <db> dump` text (one `KMER<tab>count` per line).\n"
     "  extra sub-command: dump-kmers (prints the signature k-mers of every block; no GPU needed)\n";
 
 struct Options { // argument_parser.hpp:51-66
@@ -680,6 +681,31 @@ void scan_table(std::vector<Device> &devs, const Options &o, const std::string &
     std::cerr << "[malva-geno] scanned " << total << " k-mers" << (devs.size() > 1 ? " on " + std::to_string(devs.size()) + " devices" : std::string()) << std::endl;
 }
 
+// The KMC database itself (main.cpp:444-449, 482-490): the prefix table goes to every device once, then each device
+// takes a contiguous range of the records, straight out of the mapped <db>.kmc_suf -- the host decodes nothing; the
+// library uploads the raw records in pieces beside the scan of the previous piece and rebuilds the k-mers on the device.
+void scan_kmc_db(std::vector<Device> &devs, const Options &o, const std::string &prefix)
+{
+    KmcDb db;
+    db.open(prefix);
+    if (db.k != o.ref_k) throw std::runtime_error("KMC database holds " + std::to_string(db.k) + "-mers, expected -r " + std::to_string(o.ref_k));
+    std::cerr << "[malva-geno] KMC database: " << db.total << " " << db.k << "-mers, counts " << db.min_count << ".." << db.max_count << ", "
+              << db.lut.size() / (1ULL << (2 * db.lut_prefix_len)) << " bin(s) x 4^" << db.lut_prefix_len << " prefixes, " << db.rec_bytes << " B/record" << std::endl;
+    on_all_devices(devs, [&](Device &d, size_t i) {
+        d.check(mg_kmc_set_lut(d.ctx, db.lut.data(), db.lut.size(), db.lut_prefix_len, db.suffix_bytes, db.counter_size, db.min_count, db.max_count, db.total),
+                "mg_kmc_set_lut");
+        const uint64_t a = db.total * i / devs.size(), b = db.total * (i + 1) / devs.size();
+        if (b > a) d.check(mg_kmc_scan_records(d.ctx, db.records + a * db.rec_bytes, b - a, a), "mg_kmc_scan_records");
+    });
+    if (devs.size() > 1) {
+        std::vector<mg_ctx *> ctxs;
+        for (auto &d : devs) ctxs.push_back(d.ctx);
+        devs[0].check(mg_counters_allreduce_all(ctxs.data(), (int)ctxs.size()), "mg_counters_allreduce_all");
+        for (auto &d : devs) d.check(mg_synchronize(d.ctx), "mg_synchronize");
+    }
+    std::cerr << "[malva-geno] scanned " << db.total << " k-mers" << (devs.size() > 1 ? " on " + std::to_string(devs.size()) + " devices" : std::string()) << std::endl;
+}
+
 // one output record waiting for its device results
 struct Rec {
     std::string prefix; // CHROM .. QUAL columns
@@ -729,16 +755,15 @@ int call_main(const Options &o)
         std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
         return 1;
     }
+    // the sample's k-mers: the KMC database the reference opens (main.cpp:444-449), or -- when there is none -- a text dump
     std::string table = o.kmc_path;
-    if (file_exists(o.kmc_path + ".kmc_pre") && !file_exists(o.kmc_path + ".txt") && !file_exists(o.kmc_path)) {
-        std::cerr << "ERROR: " << o.kmc_path << ".kmc_pre is a KMC database; this build reads the text dump -- run\n"
-                  << "       kmc_tools transform " << o.kmc_path << " dump " << o.kmc_path << ".txt" << std::endl;
-        return 1;
-    }
-    if (file_exists(o.kmc_path + ".txt")) table = o.kmc_path + ".txt";
-    if (!file_exists(table)) {
-        std::cerr << "ERROR: cannot open " << o.kmc_path << std::endl;
-        return 1;
+    const bool use_db = KmcDb::present(o.kmc_path);
+    if (!use_db) {
+        if (file_exists(o.kmc_path + ".txt")) table = o.kmc_path + ".txt";
+        if (!file_exists(table)) {
+            std::cerr << "ERROR: cannot open " << o.kmc_path << std::endl;
+            return 1;
+        }
     }
     // --gpus N: one context per device -d .. -d+N-1.  MALVA_GENO_SHARE_DEVICE=1 puts all N contexts on device -d: the
     // N-way layout (sharded scan, exchange, split genotyping) rehearsed on a one-GPU box, the exchange then being a
@@ -760,7 +785,8 @@ int call_main(const Options &o)
     }
     load_index(devs, o);
     pelapsed("Reference processed");
-    scan_table(devs, o, table); // main.cpp:482-500
+    if (use_db) scan_kmc_db(devs, o, o.kmc_path); // main.cpp:482-500
+    else scan_table(devs, o, table);
     pelapsed("BF weights created");
 
     // concatenated reference for the fused isolated path
