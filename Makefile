@@ -12,6 +12,10 @@ CC         ?= gcc
 CXX        ?= g++
 ARCH       ?= gfx950
 REFERENCE  ?= /root/reference
+# zstd for the reference's index container: the image has the runtime library system-wide and the header only under
+# /opt/conda (searched AFTER the system directories, so nothing else is taken from there)
+ZSTD_INC   ?= /opt/conda/include
+ZSTD_LIB   ?= /usr/lib/x86_64-linux-gnu/libzstd.so.1
 
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Imalva_amd/csrc \
               -Wall -Wno-unused-function -Wno-unused-value -fvisibility=hidden
@@ -30,8 +34,8 @@ malva_amd/lib/libmalva_hip.so: $(CSRC) $(CHDR)
 cli: bin/malva-geno
 bin/malva-geno: $(HOSTSRC) $(HOSTHDR) malva_amd/lib/libmalva_hip.so
 	@mkdir -p bin
-	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Imalva_amd/host -o $@ $(HOSTSRC) \
-	    -Lmalva_amd/lib -lmalva_hip -lz -Wl,-rpath,'$$ORIGIN/../malva_amd/lib'
+	$(CXX) -std=c++17 -O2 -Wall -pthread -Iinclude -Imalva_amd/host -idirafter $(ZSTD_INC) -o $@ $(HOSTSRC) \
+	    -Lmalva_amd/lib -lmalva_hip -lz $(ZSTD_LIB) -Wl,-rpath,'$$ORIGIN/../malva_amd/lib'
 
 oracle: oracle/libmalva_oracle.so
 oracle/libmalva_oracle.so: oracle/malva_oracle.c

@@ -1,0 +1,347 @@
+// The index file between `malva-geno index` and `malva-geno call` (main.cpp:406-412 writes, :455-461 reads).
+//
+// Two containers, one payload (context_bf, bf, ref_bf in that order):
+//
+//   <vcf>.c<ref_k>.k<k>.malvax.zst   the reference's own: ONE zstd stream (level 5, zstdstream.h:52) holding, for each
+//       Bloom filter, what BF::operator>> writes (bloom_filter.hpp:127-136): bool _mode, size_t _size, then the
+//       sdsl-lite v2.1.1 serialisation of bit_vector and of int_vector<16> -- each a u64 length IN BITS followed by
+//       the data as whole 64-bit words (sdsl int_vector<t_width>::serialize with t_width > 0 writes no width byte) --
+//       and then what KMAP::operator>> writes (kmap.hpp:52-64): size_t n, n x (size_t length, bytes, int value).
+//       The rank directory is not stored; both sides rebuild it on load (bloom_filter.hpp:143).
+//       sdsl-lite is a third-party library absent from the reference checkout and no index fixture exists there:
+//       FORMAT UNPINNED (restated from sdsl's published serialisation), see DESIGN.md.
+//   <vcf>.c<ref_k>.k<k>.malvax.hipz  this build's compact form (gzip): the filters as sorted bit positions.  A filter
+//       is a few million set bits in 2^33..2^37: the reference's form costs two passes over gigabytes of zeros.
+//
+// `index` writes the reference's container unless MALVA_GENO_INDEX_FORMAT=hipz; `call` reads whichever exists
+// (.zst first).  The payload in memory is sparse either way: that is what mg_bf_import_sparse / export_sparse take.
+#pragma once
+#include <sys/stat.h>
+#include <zlib.h>
+#include <zstd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace malva {
+
+struct IndexPayload {
+    struct Filter {
+        uint64_t mode = 0;
+        std::vector<uint64_t> pos;  // ascending positions of the set bits == counter order
+        std::vector<uint16_t> cnt;  // one per set bit
+    } filt[2];                      // [0] context_bf, [1] bf  (main.cpp:409-410)
+    size_t stride = 0;
+    std::vector<char> rows;         // ref_bf keys, NUL-terminated inside `stride` bytes each
+    std::vector<int32_t> vals;
+};
+
+// ---- reference container -----------------------------------------------------------------------------------------
+class ZstdWriter {
+  public:
+    explicit ZstdWriter(const std::string &path) : out_(ZSTD_CStreamOutSize())
+    {
+        f_ = fopen(path.c_str(), "wb");
+        if (!f_) throw std::runtime_error("cannot write " + path);
+        c_ = ZSTD_createCCtx();
+        if (!c_) throw std::runtime_error("zstd: no context");
+        ZSTD_CCtx_setParameter(c_, ZSTD_c_compressionLevel, 5); // zstd::cstream::defaultLevel
+        ZSTD_CCtx_setParameter(c_, ZSTD_c_nbWorkers, 4);        // same frame format; ignored by a single-threaded libzstd
+    }
+    ~ZstdWriter()
+    {
+        if (c_) ZSTD_freeCCtx(c_);
+        if (f_) fclose(f_);
+    }
+    void put(const void *p, size_t n) { feed(p, n, ZSTD_e_continue); }
+    template <class T> void put_value(const T &v) { put(&v, sizeof v); }
+    void finish()
+    {
+        feed(nullptr, 0, ZSTD_e_end);
+        if (fclose(f_) != 0) {
+            f_ = nullptr;
+            throw std::runtime_error("index file: close failed");
+        }
+        f_ = nullptr;
+    }
+
+  private:
+    void feed(const void *p, size_t n, ZSTD_EndDirective mode)
+    {
+        ZSTD_inBuffer in{p, n, 0};
+        for (;;) {
+            ZSTD_outBuffer o{out_.data(), out_.size(), 0};
+            const size_t left = ZSTD_compressStream2(c_, &o, &in, mode);
+            if (ZSTD_isError(left)) throw std::runtime_error(std::string("zstd: ") + ZSTD_getErrorName(left));
+            if (o.pos && fwrite(out_.data(), 1, o.pos, f_) != o.pos) throw std::runtime_error("index file: write failed");
+            if (mode == ZSTD_e_end ? left == 0 : in.pos == in.size) break;
+        }
+    }
+    FILE *f_ = nullptr;
+    ZSTD_CCtx *c_ = nullptr;
+    std::vector<char> out_;
+};
+
+class ZstdReader { // like zstd::ifstream, a file that is not a zstd frame is read as it is (zstdstream.cpp:156-158)
+  public:
+    explicit ZstdReader(const std::string &path) : in_(ZSTD_DStreamInSize()), out_(ZSTD_DStreamOutSize() * 8)
+    {
+        f_ = fopen(path.c_str(), "rb");
+        if (!f_) throw std::runtime_error("cannot open index " + path);
+        d_ = ZSTD_createDCtx();
+        in_n_ = fread(in_.data(), 1, in_.size(), f_);
+        static const unsigned char magic[4] = {0x28, 0xB5, 0x2F, 0xFD}; // a zstd frame (ZSTD_MAGICNUMBER, little-endian)
+        compressed_ = in_n_ >= 4 && memcmp(in_.data(), magic, 4) == 0;
+    }
+    ~ZstdReader()
+    {
+        if (d_) ZSTD_freeDCtx(d_);
+        if (f_) fclose(f_);
+    }
+    void get(void *p, size_t n)
+    {
+        char *dst = (char *)p;
+        while (n) {
+            if (out_pos_ == out_n_) refill();
+            const size_t take = std::min(n, out_n_ - out_pos_);
+            memcpy(dst, out_.data() + out_pos_, take);
+            out_pos_ += take;
+            dst += take;
+            n -= take;
+        }
+    }
+    template <class T> T get_value()
+    {
+        T v;
+        get(&v, sizeof v);
+        return v;
+    }
+
+  private:
+    void refill()
+    {
+        out_pos_ = out_n_ = 0;
+        while (out_n_ == 0) {
+            if (in_pos_ == in_n_) {
+                in_n_ = fread(in_.data(), 1, in_.size(), f_);
+                in_pos_ = 0;
+                if (in_n_ == 0) throw std::runtime_error("index file: truncated");
+            }
+            if (!compressed_) {
+                out_n_ = std::min(in_n_ - in_pos_, out_.size());
+                memcpy(out_.data(), in_.data() + in_pos_, out_n_);
+                in_pos_ += out_n_;
+                return;
+            }
+            ZSTD_inBuffer in{in_.data(), in_n_, in_pos_};
+            ZSTD_outBuffer o{out_.data(), out_.size(), 0};
+            const size_t rc = ZSTD_decompressStream(d_, &o, &in);
+            if (ZSTD_isError(rc)) throw std::runtime_error(std::string("index file: zstd: ") + ZSTD_getErrorName(rc));
+            in_pos_ = in.pos;
+            out_n_ = o.pos;
+        }
+    }
+    FILE *f_ = nullptr;
+    ZSTD_DCtx *d_ = nullptr;
+    std::vector<char> in_, out_;
+    size_t in_n_ = 0, in_pos_ = 0, out_n_ = 0, out_pos_ = 0;
+    bool compressed_ = false;
+};
+
+// BF::operator>> (bloom_filter.hpp:127-136) from the sparse form
+inline void write_bf_sdsl(ZstdWriter &w, const IndexPayload::Filter &f, uint64_t size_bits)
+{
+    w.put_value<uint8_t>(f.mode ? 1 : 0); // bool _mode
+    w.put_value<uint64_t>(size_bits);     // size_t _size
+    w.put_value<uint64_t>(size_bits);     // bit_vector: length in bits, then ceil(size/64) words
+    const uint64_t n_words = (size_bits + 63) / 64, chunk = 1ULL << 23; // 64 MiB of words at a time
+    std::vector<uint64_t> words;
+    size_t i = 0;
+    for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
+        const uint64_t nw = std::min(chunk, n_words - w0);
+        words.assign(nw, 0);
+        for (; i < f.pos.size() && f.pos[i] < (w0 + nw) * 64; ++i) words[(f.pos[i] >> 6) - w0] |= 1ULL << (f.pos[i] & 63);
+        w.put(words.data(), nw * 8);
+    }
+    // int_vector<16>: length in bits, then whole words.  In write mode the reference's _counts is empty.
+    const uint64_t n = f.mode ? f.cnt.size() : 0;
+    w.put_value<uint64_t>(n * 16);
+    if (n) w.put(f.cnt.data(), n * 2);
+    const uint64_t tail = (8 - (n * 2) % 8) % 8;
+    const char zeros[8] = {0};
+    if (tail) w.put(zeros, tail);
+}
+
+// BF::operator<< (bloom_filter.hpp:138-146) into the sparse form
+inline void read_bf_sdsl(ZstdReader &r, IndexPayload::Filter &f, uint64_t expect_bits, const std::string &path)
+{
+    f.mode = r.get_value<uint8_t>();
+    const uint64_t size = r.get_value<uint64_t>(), bv_bits = r.get_value<uint64_t>();
+    if (f.mode > 1 || size != bv_bits) throw std::runtime_error("index " + path + " is corrupt (filter header)");
+    if (size != expect_bits) throw std::runtime_error("index " + path + " was built with another -b (filters of " + std::to_string(size) + " bits)");
+    const uint64_t n_words = (size + 63) / 64, chunk = 1ULL << 23;
+    std::vector<uint64_t> words;
+    f.pos.clear();
+    for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
+        const uint64_t nw = std::min(chunk, n_words - w0);
+        words.resize(nw);
+        r.get(words.data(), nw * 8);
+        for (uint64_t j = 0; j < nw; ++j) {
+            uint64_t x = words[j];
+            while (x) {
+                f.pos.push_back((w0 + j) * 64 + (uint64_t)__builtin_ctzll(x));
+                x &= x - 1;
+            }
+        }
+        if (f.pos.size() >= 0xFFFFFFFFULL) throw std::runtime_error("index " + path + ": a filter with 2^32 or more set bits");
+    }
+    const uint64_t cnt_bits = r.get_value<uint64_t>();
+    if (cnt_bits % 16 || (f.mode && cnt_bits / 16 != f.pos.size()) || cnt_bits / 16 > f.pos.size())
+        throw std::runtime_error("index " + path + " is corrupt (counter vector of " + std::to_string(cnt_bits) + " bits for " + std::to_string(f.pos.size()) + " set bits)");
+    const uint64_t n = cnt_bits / 16;
+    f.cnt.assign(f.pos.size(), 0);
+    if (n) r.get(f.cnt.data(), n * 2);
+    char pad[8];
+    const uint64_t tail = (8 - (n * 2) % 8) % 8;
+    if (tail) r.get(pad, tail);
+}
+
+inline void save_index_zst(const std::string &path, const IndexPayload &p, uint64_t bf_bits)
+{
+    ZstdWriter w(path);
+    write_bf_sdsl(w, p.filt[0], bf_bits);
+    write_bf_sdsl(w, p.filt[1], bf_bits);
+    const uint64_t n = p.vals.size(); // KMAP::operator>>, kmap.hpp:52-64
+    w.put_value<uint64_t>(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const char *key = &p.rows[i * p.stride];
+        const uint64_t len = strnlen(key, p.stride);
+        w.put_value<uint64_t>(len);
+        w.put(key, len);
+        w.put_value<int32_t>(p.vals[i]);
+    }
+    w.finish();
+}
+
+inline void load_index_zst(const std::string &path, IndexPayload &p, uint64_t bf_bits, size_t stride)
+{
+    ZstdReader r(path);
+    read_bf_sdsl(r, p.filt[0], bf_bits, path);
+    read_bf_sdsl(r, p.filt[1], bf_bits, path);
+    const uint64_t n = r.get_value<uint64_t>(); // KMAP::operator<<, kmap.hpp:66-82
+    if (n > 0xFFFFFFFEULL) throw std::runtime_error("index " + path + " is corrupt (key count)");
+    p.stride = stride;
+    p.rows.clear();
+    p.vals.clear();
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t len = r.get_value<uint64_t>();
+        if (len >= stride) throw std::runtime_error("index " + path + ": key of " + std::to_string(len) + " bytes");
+        p.rows.resize(p.rows.size() + stride, 0);
+        r.get(&p.rows[i * stride], len);
+        p.vals.push_back(r.get_value<int32_t>());
+    }
+}
+
+// ---- this build's compact container ----------------------------------------------------------------------------------
+namespace hipz {
+template <class T> void gz_put(gzFile f, const T *p, size_t n)
+{
+    const char *b = (const char *)p;
+    size_t left = n * sizeof(T);
+    while (left) {
+        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
+        if (gzwrite(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: write failed");
+        b += chunk;
+        left -= chunk;
+    }
+}
+template <class T> void gz_get(gzFile f, T *p, size_t n)
+{
+    char *b = (char *)p;
+    size_t left = n * sizeof(T);
+    while (left) {
+        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
+        if (gzread(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: truncated");
+        b += chunk;
+        left -= chunk;
+    }
+}
+const char MAGIC[8] = {'M', 'G', 'H', 'I', 'P', 'X', '2', '\n'};
+} // namespace hipz
+
+inline void save_index_hipz(const std::string &path, const IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits)
+{
+    using namespace hipz;
+    gzFile f = gzopen(path.c_str(), "wb1");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    try {
+        gz_put(f, MAGIC, 8);
+        const uint64_t hdr[3] = {k, ref_k, bf_bits};
+        gz_put(f, hdr, 3);
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t h2[2] = {p.filt[i].mode, p.filt[i].pos.size()};
+            gz_put(f, h2, 2);
+            gz_put(f, p.filt[i].pos.data(), p.filt[i].pos.size());
+            gz_put(f, p.filt[i].cnt.data(), p.filt[i].cnt.size());
+        }
+        const uint64_t nkeys = p.vals.size(), stride = p.stride;
+        gz_put(f, &nkeys, 1);
+        gz_put(f, &stride, 1);
+        gz_put(f, p.rows.data(), p.rows.size());
+        gz_put(f, p.vals.data(), p.vals.size());
+    } catch (...) {
+        gzclose(f);
+        throw;
+    }
+    if (gzclose(f) != Z_OK) throw std::runtime_error("index file: close failed");
+}
+
+inline void load_index_hipz(const std::string &path, IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits, size_t stride)
+{
+    using namespace hipz;
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open index " + path);
+    struct stat st;
+    const uint64_t file_bytes = stat(path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+    try {
+        char magic[8];
+        gz_get(f, magic, 8);
+        uint64_t hdr[3];
+        gz_get(f, hdr, 3);
+        if (memcmp(magic, MAGIC, 8) != 0 || hdr[0] != k || hdr[1] != ref_k || hdr[2] != bf_bits)
+            throw std::runtime_error("index " + path + " was built with other -k/-r/-b");
+        // a corrupt length must not turn into a huge allocation: a filter holds fewer than 2^32 set bits (mg_bf_finalize),
+        // and no field can promise more bytes than gzip can have packed into the file
+        const uint64_t most = std::min<uint64_t>(bf_bits, 0xFFFFFFFEULL), inflated_cap = file_bytes * 1100 + (1u << 20);
+        for (int i = 0; i < 2; ++i) {
+            uint64_t h2[2];
+            gz_get(f, h2, 2);
+            if (h2[0] > 1 || h2[1] > most || h2[1] * 10 > inflated_cap) throw std::runtime_error("index " + path + " is corrupt (filter header)");
+            p.filt[i].mode = h2[0];
+            p.filt[i].pos.resize(h2[1]);
+            p.filt[i].cnt.resize(h2[1]);
+            gz_get(f, p.filt[i].pos.data(), p.filt[i].pos.size());
+            gz_get(f, p.filt[i].cnt.data(), p.filt[i].cnt.size());
+        }
+        uint64_t nkeys = 0, file_stride = 0;
+        gz_get(f, &nkeys, 1);
+        gz_get(f, &file_stride, 1);
+        if (file_stride != stride || nkeys > 0xFFFFFFFEULL || nkeys * (stride + 4) > inflated_cap) throw std::runtime_error("index " + path + " is corrupt (key table)");
+        p.stride = stride;
+        p.rows.resize(nkeys * stride);
+        p.vals.resize(nkeys);
+        gz_get(f, p.rows.data(), p.rows.size());
+        gz_get(f, p.vals.data(), p.vals.size());
+    } catch (...) {
+        gzclose(f);
+        throw;
+    }
+    gzclose(f);
+}
+
+} // namespace malva

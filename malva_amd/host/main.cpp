@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "block.hpp"
+#include "index_file.hpp"
 #include "kmc_db.hpp"
 extern "C" {
 #include "malva_hip.h"
@@ -56,7 +57,9 @@ const char *USAGE =
     "\n"
     "  <kmc_output_prefix>: a KMC database (<prefix>.kmc_pre + <prefix>.kmc_suf, KMC 2/3 format), read directly;\n"
     "  or <prefix>.txt / <prefix> holding `kmc_tools transform <db> dump` text (one `KMER<tab>count` per line).\n"
-    "  extra sub-command: dump-kmers (prints the signature k-mers of every block; no GPU needed)\n";
+    "  index file: <variants.vcf>.c<r>.k<k>.malvax.zst, the reference's container (sdsl + zstd); `call` also reads this\n"
+    "  build's compact <...>.malvax.hipz (written when MALVA_GENO_INDEX_FORMAT=hipz).\n"
+    "  extra sub-commands (no GPU needed): dump-kmers (signature k-mers of every block); index-convert <fa> <vcf> zst|hipz\n";
 
 struct Options { // argument_parser.hpp:51-66
     unsigned k = 35, ref_k = 43;
@@ -125,6 +128,8 @@ bool parse_arguments(int argc, char **argv, Options &o)
     o.fasta_path = argv[optind++];
     o.vcf_path = argv[optind++];
     o.kmc_path = argv[optind++];
+    if (const char *bits = getenv("MALVA_GENO_BF_BITS")) // tests: filters smaller than -b's 2^33-bit granule
+        if (atoll(bits) > 0) o.bf_size = (uint64_t)atoll(bits);
     return true;
 }
 
@@ -180,9 +185,10 @@ bool file_exists(const std::string &p)
     struct stat st;
     return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
 }
-std::string index_path(const Options &o) // main.cpp:407 with this build's own container suffix
+// main.cpp:407 / :456: <vcf>.c<ref_k>.k<k>.malvax + ".zst" (the reference's container) or ".hipz" (this build's compact one)
+std::string index_path(const Options &o, const char *suffix)
 {
-    return o.vcf_path + ".c" + std::to_string(o.ref_k) + ".k" + std::to_string(o.k) + ".malvax.hipz";
+    return o.vcf_path + ".c" + std::to_string(o.ref_k) + ".k" + std::to_string(o.k) + ".malvax" + suffix;
 }
 
 // The record loop shared by index_main (main.cpp:309-370) and call_main (:522-579).  on_block(block, reference
@@ -228,59 +234,34 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
     return i;
 }
 
-// ---- index file: this build's own container (gzip): parameters, both filters in sparse form, the exact map ----
-template <class T> void gz_put(gzFile f, const T *p, size_t n)
-{
-    const char *b = (const char *)p;
-    size_t left = n * sizeof(T);
-    while (left) {
-        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
-        if (gzwrite(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: write failed");
-        b += chunk;
-        left -= chunk;
-    }
-}
-template <class T> void gz_get(gzFile f, T *p, size_t n)
-{
-    char *b = (char *)p;
-    size_t left = n * sizeof(T);
-    while (left) {
-        const unsigned chunk = (unsigned)std::min<size_t>(left, 1u << 30);
-        if (gzread(f, b, chunk) != (int)chunk) throw std::runtime_error("index file: truncated");
-        b += chunk;
-        left -= chunk;
-    }
-}
-const char MAGIC[8] = {'M', 'G', 'H', 'I', 'P', 'X', '1', '\n'};
-
+// ---- index file (index_file.hpp): payload out of / into the contexts ---------------------------------------------------
 void save_index(Device &dev, const Options &o)
 {
-    gzFile f = gzopen(index_path(o).c_str(), "wb1");
-    if (!f) throw std::runtime_error("cannot write " + index_path(o));
-    gz_put(f, MAGIC, 8);
-    const uint64_t hdr[3] = {o.k, o.ref_k, o.bf_size};
-    gz_put(f, hdr, 3);
-    for (int which : {MG_BF_CTX, MG_BF_ALT}) { // payload order of main.cpp:409-411: context_bf, bf, ref_bf
+    IndexPayload p;
+    const int which[2] = {MG_BF_CTX, MG_BF_ALT}; // payload order of main.cpp:409-411: context_bf, bf, ref_bf
+    for (int i = 0; i < 2; ++i) {
         uint64_t size, nset;
         int mode;
-        dev.check(mg_bf_info(dev.ctx, which, &size, &nset, &mode), "mg_bf_info");
-        std::vector<uint64_t> pos(nset);
-        std::vector<uint16_t> cnt(nset);
-        dev.check(mg_bf_export_sparse(dev.ctx, which, pos.data(), cnt.data()), "mg_bf_export_sparse");
-        const uint64_t h2[2] = {(uint64_t)mode, nset};
-        gz_put(f, h2, 2);
-        gz_put(f, pos.data(), nset);
-        gz_put(f, cnt.data(), nset);
+        dev.check(mg_bf_info(dev.ctx, which[i], &size, &nset, &mode), "mg_bf_info");
+        p.filt[i].mode = (uint64_t)mode;
+        p.filt[i].pos.resize(nset);
+        p.filt[i].cnt.resize(nset);
+        dev.check(mg_bf_export_sparse(dev.ctx, which[i], p.filt[i].pos.data(), p.filt[i].cnt.data()), "mg_bf_export_sparse");
     }
     uint64_t nkeys = 0;
     dev.check(mg_map_size(dev.ctx, &nkeys), "mg_map_size");
-    std::vector<char> rows(nkeys * STRIDE);
-    std::vector<int32_t> vals(nkeys);
-    if (nkeys) dev.check(mg_map_export(dev.ctx, rows.data(), STRIDE, vals.data()), "mg_map_export");
-    gz_put(f, &nkeys, 1);
-    gz_put(f, rows.data(), rows.size());
-    gz_put(f, vals.data(), vals.size());
-    if (gzclose(f) != Z_OK) throw std::runtime_error("index file: close failed");
+    p.stride = STRIDE;
+    p.rows.resize(nkeys * STRIDE);
+    p.vals.resize(nkeys);
+    if (nkeys) dev.check(mg_map_export(dev.ctx, p.rows.data(), STRIDE, p.vals.data()), "mg_map_export");
+    const char *fmt = getenv("MALVA_GENO_INDEX_FORMAT");
+    if (fmt && std::string(fmt) == "hipz") {
+        save_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size);
+        unlink(index_path(o, ".zst").c_str()); // `call` prefers .zst: do not leave a stale one beside the new index
+    } else {
+        save_index_zst(index_path(o, ".zst"), p, o.bf_size);
+        unlink(index_path(o, ".hipz").c_str());
+    }
 }
 
 // every device of a multi-GPU call holds the whole index (the read-only structures are replicated):
@@ -305,56 +286,16 @@ template <class F> void on_all_devices(std::vector<Device> &devs, F f)
 
 void load_index(std::vector<Device> &devs, const Options &o)
 {
-    gzFile f = gzopen(index_path(o).c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open index " + index_path(o) + " (run `malva-geno index` with the same -k -r -b first)");
-    struct stat st;
-    const uint64_t file_bytes = stat(index_path(o).c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
-    char magic[8];
-    gz_get(f, magic, 8);
-    uint64_t hdr[3];
-    gz_get(f, hdr, 3);
-    if (memcmp(magic, MAGIC, 8) != 0 || hdr[0] != o.k || hdr[1] != o.ref_k || hdr[2] != o.bf_size) {
-        gzclose(f);
-        throw std::runtime_error("index " + index_path(o) + " was built with other -k/-r/-b");
-    }
-    // a corrupt length must not turn into a huge allocation: a filter holds at most bf_size set bits and fewer than
-    // 2^32 counters (mg_bf_finalize), and no field can promise more bytes than gzip can have packed into the file
-    const uint64_t most = std::min<uint64_t>(o.bf_size, 0xFFFFFFFEULL), inflated_cap = file_bytes * 1100 + (1u << 20);
-    struct Filter {
-        uint64_t mode = 0;
-        std::vector<uint64_t> pos;
-        std::vector<uint16_t> cnt;
-    } filt[2];
-    for (int i = 0; i < 2; ++i) { // payload order: context_bf, bf
-        uint64_t h2[2];
-        gz_get(f, h2, 2);
-        if (h2[0] > 1 || h2[1] > most || h2[1] * 10 > inflated_cap) {
-            gzclose(f);
-            throw std::runtime_error("index " + index_path(o) + " is corrupt (filter header)");
-        }
-        filt[i].mode = h2[0];
-        filt[i].pos.resize(h2[1]);
-        filt[i].cnt.resize(h2[1]);
-        gz_get(f, filt[i].pos.data(), filt[i].pos.size());
-        gz_get(f, filt[i].cnt.data(), filt[i].cnt.size());
-    }
-    uint64_t nkeys = 0;
-    gz_get(f, &nkeys, 1);
-    if (nkeys > 0xFFFFFFFEULL || nkeys * (STRIDE + 4) > inflated_cap) {
-        gzclose(f);
-        throw std::runtime_error("index " + index_path(o) + " is corrupt (key count)");
-    }
-    std::vector<char> rows(nkeys * STRIDE);
-    std::vector<int32_t> vals(nkeys);
-    gz_get(f, rows.data(), rows.size());
-    gz_get(f, vals.data(), vals.size());
-    gzclose(f);
+    IndexPayload p;
+    if (file_exists(index_path(o, ".zst"))) load_index_zst(index_path(o, ".zst"), p, o.bf_size, STRIDE);
+    else if (file_exists(index_path(o, ".hipz"))) load_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size, STRIDE);
+    else throw std::runtime_error("cannot open index " + index_path(o, ".zst") + " (run `malva-geno index` with the same -k -r -b first)");
     on_all_devices(devs, [&](Device &dev, size_t) {
         const int which[2] = {MG_BF_CTX, MG_BF_ALT};
         for (int i = 0; i < 2; ++i)
-            dev.check(mg_bf_import_sparse(dev.ctx, which[i], (int)filt[i].mode, o.bf_size, filt[i].pos.data(), filt[i].cnt.data(), filt[i].pos.size()),
+            dev.check(mg_bf_import_sparse(dev.ctx, which[i], (int)p.filt[i].mode, o.bf_size, p.filt[i].pos.data(), p.filt[i].cnt.data(), p.filt[i].pos.size()),
                       "mg_bf_import_sparse");
-        if (nkeys) dev.check(mg_map_import(dev.ctx, rows.data(), STRIDE, nkeys, vals.data()), "mg_map_import");
+        if (!p.vals.empty()) dev.check(mg_map_import(dev.ctx, p.rows.data(), STRIDE, p.vals.size(), p.vals.data()), "mg_map_import");
     });
 }
 
@@ -1052,6 +993,24 @@ int call_main(const Options &o)
     return 0;
 }
 
+// index-convert: rewrite the index of <variants.vcf> in the other container (third argument: zst | hipz); host only
+int convert_main(const Options &o)
+{
+    IndexPayload p;
+    const bool to_zst = o.kmc_path == "zst";
+    if (!to_zst && o.kmc_path != "hipz") throw std::runtime_error("index-convert: the third argument names the target container, zst or hipz");
+    if (to_zst) {
+        load_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size, STRIDE);
+        save_index_zst(index_path(o, ".zst"), p, o.bf_size);
+    } else {
+        load_index_zst(index_path(o, ".zst"), p, o.bf_size, STRIDE);
+        save_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size);
+    }
+    std::cerr << "[malva-geno] index rewritten as " << index_path(o, to_zst ? ".zst" : ".hipz") << ": " << p.filt[0].pos.size() << " + " << p.filt[1].pos.size()
+              << " filter bits, " << p.vals.size() << " keys" << std::endl;
+    return 0;
+}
+
 // dump-kmers: host-only view of the enumerator (tests compare it with the oracle's block model)
 int dump_main(const Options &o)
 {
@@ -1100,6 +1059,10 @@ int main(int argc, char **argv)
     Options o;
     const std::string cmd = argv[1];
     try {
+        if (cmd == "index-convert") {
+            if (!parse_arguments(argc - 1, argv + 1, o)) return EXIT_FAILURE;
+            return convert_main(o);
+        }
         if (cmd.compare(0, 5, "index") == 0) {
             if (!parse_arguments(argc - 1, argv + 1, o)) return EXIT_FAILURE;
             return index_main(o);

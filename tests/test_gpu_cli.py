@@ -167,3 +167,37 @@ def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
     assert "enumerated on the host" in r.stderr
     forced = run_cli(["call"] + args, env=dict(os.environ, MALVA_GENO_HOST_ENUM="1"))
     assert forced == want
+
+
+def test_index_file_is_the_references_container_and_interchanges_with_the_oracle(tmp_path):
+    """SURVEY 8(f3): `malva-geno index` writes <vcf>.c43.k35.malvax.zst in the reference's layout (main.cpp:406-412);
+    the oracle's independent reader must find in it exactly the index the oracle pipeline builds itself, and an index
+    file WRITTEN by the oracle must drive `malva-geno call` to the same bytes.  (Format unpinned: oracle/index_file.py.)"""
+    import numpy as np
+    from oracle import index_file
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, 41, haploid=False, k=35, n_clusters=80, vcf_strip_chr=True)
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, 43, 41, table + ".txt")
+    args = ["-k", "35", "-r", "43", "-b", "1", "-p", "-v", prefix + ".fa", prefix + ".vcf", table]
+    run_cli(["index"] + args)
+    zst = prefix + ".vcf.c43.k35.malvax.zst"
+    assert os.path.exists(zst) and not os.path.exists(prefix + ".vcf.c43.k35.malvax.hipz")
+    opt = pipeline.Options(haploid=False, verbose=True, k=35, ref_k=43, bf_size=1 << 33, strip_chr=True)
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    filters, keys = index_file.read_index(zst)
+    for (mode, size, pos, counts), want in zip(filters, (idx.context_bf, idx.bf)):
+        assert (mode, size) == (1, 1 << 33)
+        assert np.array_equal(pos, want.set_positions()) and pos.size > 0
+        assert counts.size == pos.size and not counts.any()             # switch_mode leaves zeroed counters (bloom_filter.hpp:96)
+    assert keys == dict(idx.ref_bf.items())
+    from_own = run_cli(["call"] + args)
+    # the compact container holds the same payload
+    run_cli(["index"] + args, env=dict(os.environ, MALVA_GENO_INDEX_FORMAT="hipz"))
+    assert os.path.exists(prefix + ".vcf.c43.k35.malvax.hipz") and not os.path.exists(zst)
+    assert run_cli(["call"] + args) == from_own
+    os.remove(prefix + ".vcf.c43.k35.malvax.hipz")
+    # an index written by the oracle (as the reference binary would have), read by the product
+    index_file.write_index(zst, idx.context_bf, idx.bf, idx.ref_bf)
+    assert run_cli(["call"] + args) == from_own
+    assert sum(1 for l in from_own.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
