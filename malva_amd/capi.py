@@ -351,8 +351,9 @@ class Context:
         self._ck(self._L.mg_map_import(self.h, _p(rows), rows.shape[1], rows.shape[0], _p(vals)))
 
     # scans
-    def ref_scan(self, contig: bytes):
-        buf = np.frombuffer(contig, dtype=np.uint8)
+    def ref_scan(self, contig):
+        """contig: bytes, or a uint8 array (no copy: a whole-genome contig is gigabytes)"""
+        buf = np.frombuffer(contig, dtype=np.uint8) if isinstance(contig, (bytes, bytearray, memoryview)) else np.ascontiguousarray(contig, dtype=np.uint8)
         self._ck(self._L.mg_ref_scan(self.h, _p(buf), buf.size))
 
     def kmc_scan(self, hi, lo, cnt):

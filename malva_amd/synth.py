@@ -236,29 +236,37 @@ def snp_signature_rows(panel: Panel, k):
     return rows, np.ones(2 * n, dtype=bool)
 
 
-def kmer_table(panel: Panel, n_rows, k, ref_k, seed, offsets=(-2, -1, 0, 1, 2), snp_only=True):
-    """KMC-style table: ref_k-mers of the donor's two haplotypes around every variant site
-    (window offsets around the centred position) topped up to n_rows with uniform random
-    ref_k-mers, all canonical, counts in [2, 63], rows shuffled.  -> (hi, lo, cnt)"""
-    assert snp_only, "donor windows are generated for one-base alleles"
-    rng = np.random.default_rng(seed)
+def site_rows(panel: Panel, k, ref_k, offsets=(-2, -1, 0, 1, 2)):
+    """ref_k-mers of the donor's two haplotypes around every variant site of an snp_panel (window offsets around the
+    centred position) -> (hi, lo, variant index, haplotype, offset) per row, M-form, not canonicalised.  A homozygous
+    donor contributes each window once, as KMC lists distinct k-mers; windows holding a non-ACGT symbol are dropped."""
     off = (ref_k - k) // 2
     centre = off + k // 2                      # column of the variant base in a centred ref_k window
-    his, los = [], []
+    his, los, vs, hs, ds = [], [], [], [], []
+    idx = np.arange(panel.n, dtype=np.int64)
     for h in range(2):
         allele_slot = panel.var_allele_off[:-1].astype(np.int64) + panel.donor_gt[:, h].astype(np.int64)
         base = panel.pool[panel.allele_off[allele_slot]]
         for d in offsets:
             w = windows(panel.genome, panel.pos - centre + d, ref_k).copy()
             w[:, centre - d] = base
+            keep = np.ones(panel.n, dtype=bool)
             if h == 1:
-                # a homozygous donor contributes each window once, as KMC lists distinct k-mers
-                het = panel.donor_gt[:, 0] != panel.donor_gt[:, 1]
-                w = w[het]
-            w = w[(CODE[w] <= 3).all(axis=1)]       # KMC drops windows that hold a non-ACGT symbol
-            a, b = pack_ascii(w)
+                keep &= panel.donor_gt[:, 0] != panel.donor_gt[:, 1]
+            keep &= (CODE[w] <= 3).all(axis=1)       # KMC drops windows that hold a non-ACGT symbol
+            a, b = pack_ascii(w[keep])
             his.append(a); los.append(b)
-    hi = np.concatenate(his); lo = np.concatenate(los)
+            vs.append(idx[keep]); hs.append(np.full(int(keep.sum()), h, dtype=np.int8)); ds.append(np.full(int(keep.sum()), d, dtype=np.int8))
+    return np.concatenate(his), np.concatenate(los), np.concatenate(vs), np.concatenate(hs), np.concatenate(ds)
+
+
+def kmer_table(panel: Panel, n_rows, k, ref_k, seed, offsets=(-2, -1, 0, 1, 2), snp_only=True):
+    """KMC-style table: ref_k-mers of the donor's two haplotypes around every variant site
+    (window offsets around the centred position) topped up to n_rows with uniform random
+    ref_k-mers, all canonical, counts in [2, 63], rows shuffled.  -> (hi, lo, cnt)"""
+    assert snp_only, "donor windows are generated for one-base alleles"
+    rng = np.random.default_rng(seed)
+    hi, lo, _, _, _ = site_rows(panel, k, ref_k, offsets)
     n_site = hi.shape[0]
     if n_site > n_rows:
         sel = rng.permutation(n_site)[:n_rows]

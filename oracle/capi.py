@@ -104,7 +104,10 @@ class BF:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().mo_bf_free(self.h)
+            try:
+                lib().mo_bf_free(self.h)
+            except TypeError:          # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
     def add_key(self, kmer: bytes):
@@ -163,7 +166,10 @@ class KMAP:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().mo_kmap_free(self.h)
+            try:
+                lib().mo_kmap_free(self.h)
+            except TypeError:          # interpreter shutdown
+                pass
             self.h = None
 
     def add_key(self, kmer: bytes):

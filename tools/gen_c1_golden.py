@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/sars_cov2.oracle.malva.vcf.gz: the full expected output of BASELINE config C1
+(example/reference_sarsCov2.fasta + example/sars_cov2.vcf.gz, -1 -k 35 -r 43 -b 1 -f AF, the haploid example's reads
+counted by oracle/kmc_standin.py as the sample) through oracle/pipeline.py -- the CPU restatement of
+main.cpp:251-594.  Run once in the build container (pure Python over 15,154 records x 27,934 samples: slow);
+the committed file is what tests/test_gpu_configs.py compares `bin/malva-geno` with, byte for byte.
+Provenance of the two calls this output must contain (17747 C>T 1:94, 17858 A>G 1:100): the compiled reference,
+SURVEY.md section 8(c) item 3."""
+import gzip
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import kmc_standin, pipeline  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def main(verbose):
+    opt = pipeline.Options(haploid=True, verbose=verbose, k=35, ref_k=43, bf_size=1 << 33, freq_key="AF")
+    t0 = time.time()
+    fa, vcf = os.path.join(G, "reference_sarsCov2.fasta"), os.path.join(G, "sars_cov2.vcf.gz")
+    idx = pipeline.index(fa, vcf, opt)
+    print("index: %.0f s" % (time.time() - t0), file=sys.stderr, flush=True)
+    kmers = list(kmc_standin.count_fastq(os.path.join(G, "haploid.fq"), 43))
+    t0 = time.time()
+    out = pipeline.call(fa, vcf, idx, kmers, opt)
+    print("call: %.0f s, %d lines" % (time.time() - t0, out.count("\n")), file=sys.stderr, flush=True)
+    name = "sars_cov2.oracle.malva%s.vcf.gz" % (".verbose" if verbose else "")
+    with gzip.GzipFile(os.path.join(G, name), "wb", compresslevel=9, mtime=0) as fh:
+        fh.write(out.encode())
+    print("wrote", name, file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main("-v" in sys.argv)
