@@ -274,7 +274,8 @@ int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *rows_out);
 /* 0 disables the cache-resident summary bitmaps (A/B switch; results identical) */
 int mg_set_option(mg_ctx *ctx, const char *name, int64_t value);
 /* reads an option back, plus "pregate_k" (0: single-level gate), "scan_bins" (slices the
- * most recent scan partitioned its second level into; 0: direct form) and "scan_spilled" */
+ * most recent scan partitioned its second level into; 0: direct form), "scan_tickets" (gate slices the most
+ * recent scan filed tickets under; 0: it did not) and "scan_spilled" */
 int mg_get_option(mg_ctx *ctx, const char *name, int64_t *value);
 
 #ifdef __cplusplus

@@ -98,9 +98,15 @@ struct mg_ctx {
     bool pre_skip = false; // the coarse gate is saturated at this index size (decided at finalize): scans go straight to the fine gate
     int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
     int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
+    int probe_grid = 2048, hits_grid = 1024; // workgroups of the two list kernels (swept)
+    int use_tickets = 1;     // gates beyond L2: file 8-byte tickets by gate slice instead of probing HBM at random (scan_ticket_kernel)
+    int ticket_min_log2 = 26; // smallest fine gate (log2 bits) that takes the ticket form
+    Scratch s_tk[2];
+    unsigned long long *d_tk_meta = nullptr; // spill count, then u32 [TK_MAXP][BIN_SEGS] segment fills
     int bin_ring = 0, bin_rows = 4; // A/B: staging ring per bin (0 = as large as LDS allows), rows per thread of the binning kernel
     u64 bin_cap = 0;       // rows per bin segment; 0 = 1.5x an even share of the chunk (tests set it small to reach the spill path)
     int last_bins = 0;     // bins used by the most recent scan (0: direct form)
+    int last_tickets = 0;  // gate slices the most recent scan filed tickets under (0: it did not)
     Scratch s_bin[3], s_spill[3];
     unsigned long long *d_bin_meta = nullptr; // spill count, then u32 [BIN_MAXP][BIN_SEGS] segment fills
     int gate_k = 4;     // gate bits per entry (blocked Bloom filter inside one 64-bit word; swept 2..4)
@@ -527,6 +533,8 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     for (auto &s : c->s_bin) hipFree(s.p);
     for (auto &s : c->s_spill) hipFree(s.p);
     hipFree(c->d_bin_meta);
+    hipFree(c->d_tk_meta);
+    for (auto &q : c->s_tk) hipFree(q.p);
     for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
     hipFree(c->d_hit_count);
@@ -567,6 +575,10 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "blocks_set_limit")) c->blocks_set_limit = (u32)std::min<int64_t>(std::max<int64_t>(value, 0), BK_SET_CAP / 2);
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
+    else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
+    else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
+    else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
+    else if (!strcmp(name, "hits_grid")) c->hits_grid = value > 0 ? (int)value : 1024;
     else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
     else if (!strcmp(name, "scan_bin_ring")) {
         if (value != 0 && value != 64 && value != 128 && value != 256) return fail(c, MG_ERR_ARG, "scan_bin_ring must be 0, 64, 128 or 256");
@@ -608,11 +620,13 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "pregate_log2")) *value = c->pregate_log2;
     else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate && pregate_on(c) ? c->pre_k : 0;
     else if (!strcmp(name, "scan_bins")) *value = c->last_bins;
+    else if (!strcmp(name, "scan_tickets")) *value = c->last_tickets;
+    else if (!strcmp(name, "use_tickets")) *value = c->use_tickets;
     else if (!strcmp(name, "scan_spilled")) { // rows of the last chunk that took the spill list
         unsigned long long t = 0;
-        if (c->last_bins) {
+        if (c->last_bins || c->last_tickets) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, hipMemcpy(&t, c->d_bin_meta, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&t, c->last_tickets ? c->d_tk_meta : c->d_bin_meta, 8, hipMemcpyDeviceToHost));
         }
         *value = (int64_t)t;
     }
@@ -922,10 +936,16 @@ void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *
 }
 template <int KC, int RC>
 void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed,
-                       const BinSet *bins)
+                       const BinSet *bins, const TicketSet *tickets)
 {
     if (timed) hipEventRecord(c->ev[0], c->stream);
-    if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
+    if (tickets) { // whole-genome index: tickets filed by gate slice, then the gate slice by slice out of L2
+        TicketSet ts = *tickets;
+        ts.nseg = (u32)std::min<u64>((n + 4 * TPB - 1) / (4 * TPB), tickets->nseg);
+        hipLaunchKernelGGL((scan_ticket_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), (size_t)ts.nbins * ts.ring * 8, c->stream, d_hi, d_lo, n, (int)c->k,
+                           (int)c->ref_k, view(c, MG_BF_ALT), ts);
+        hipLaunchKernelGGL((scan_ticket_gate_kernel<KC, RC>), dim3(2048), dim3(TPB), 0, c->stream, d_hi, d_lo, view(c, MG_BF_ALT), ts, open, c->d_hit_count);
+    } else if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
         BinSet bs = *bins; // the last chunk may need fewer workgroups than segments were laid out for
         bs.nseg = (u32)std::min<u64>((n + 2 * TPB - 1) / (2 * TPB), bins->nseg);
         bins = &bs;
@@ -945,11 +965,11 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
         }
     if (timed) hipEventRecord(c->ev[1], c->stream);
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
-    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), 2048u);
+    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
     hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
-                       view(c), open, hits, c->d_hit_count);
+                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt);
     if (timed) hipEventRecord(c->ev[2], c->stream);
-    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, 1024u)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
+    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
     if (timed) hipEventRecord(c->ev[3], c->stream);
 }
@@ -965,7 +985,15 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.slots) TRY(map_reserve(c, 0));
-    const u64 chunk = 1ULL << 27; // rows per launch triple (bounds the two lists' worst-case size)
+    // large index: tickets by gate slice (takes precedence over the row-moving partition below)
+    const BFState &alt = c->bf[MG_BF_ALT];
+    const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6); // slices of half the L2-resident size: 2 MiB
+    const u64 TP = (((alt.n_gate_bits + 63) / 64) + (1ULL << word_shift) - 1) >> word_shift;
+    u32 idx_bits = 1;
+    while (idx_bits < 64 && (alt.size - 1) >> idx_bits) ++idx_bits;
+    const bool tickets = c->use_summary && c->use_tickets && alt.gate && c->gate_log2 >= c->ticket_min_log2 && TP >= 2 && TP <= (u64)TK_MAXP && idx_bits <= 44;
+    const u32 row_bits = std::min<u32>(27, 64 - idx_bits);
+    const u64 chunk = tickets ? 1ULL << row_bits : 1ULL << 27; // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
@@ -974,9 +1002,25 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     c->stats_valid = false;
     // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
     BinSet bins{};
-    const BFState &alt = c->bf[MG_BF_ALT];
-    const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6);
-    const u64 P = alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
+    TicketSet tks{};
+    if (tickets) {
+        tks.nbins = (u32)TP;
+        tks.word_shift = word_shift;
+        tks.row_bits = row_bits;
+        tks.nseg = (u32)std::min<u64>((cap + 4 * TPB - 1) / (4 * TPB), BIN_SEGS);
+        tks.segcap = c->bin_cap ? c->bin_cap : ((cap / TP / tks.nseg) * 3 / 2 + 64 + 15) / 16 * 16; // 1.5x an even share, whole 128-byte lines
+        tks.ring = 16;
+        while (tks.ring < 64 && tks.ring * 2 * TP <= (u64)TK_LDS_TICKETS) tks.ring *= 2;
+        void *q[2];
+        TRY(scratch(c, c->s_tk[0], TP * tks.nseg * tks.segcap * 8, &q[0]));
+        TRY(scratch(c, c->s_tk[1], cap * 8, &q[1]));
+        tks.tickets = (u64 *)q[0];
+        tks.spill = (u64 *)q[1];
+        if (!c->d_tk_meta) HIP_TRY(c, hipMalloc(&c->d_tk_meta, 8 + (size_t)TK_MAXP * BIN_SEGS * 4));
+        tks.spill_count = c->d_tk_meta;
+        tks.counts = (u32 *)(c->d_tk_meta + 1);
+    }
+    const u64 P = !tickets && alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
     const bool partition = c->use_summary && c->use_pregate && c->use_partition && P >= 2 && P <= BIN_MAXP;
     if (partition) {
         bins.nbins = (u32)P;
@@ -1003,13 +1047,15 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         const u32 *pc = (const u32 *)d_cnt + r0;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
         if (partition) HIP_TRY(c, hipMemsetAsync(c->d_bin_meta, 0, 8, c->stream));
+        if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, 8, c->stream));
         // the reference's defaults (k35 r43, argument_parser.hpp:57-58) and config C5 (k35 r63) get fixed-length hashing
-        if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
-        else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
-        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr);
+        if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
+        else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
+        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
     c->last_bins = partition ? (int)P : 0;
+    c->last_tickets = tickets ? (int)TP : 0;
     c->stats_valid = true;
     return MG_OK;
 }

@@ -150,22 +150,21 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
     const int off = (r - k) / 2;
     struct Tile {
         U128 m[ROWS];
-        u32 count[ROWS];
+        u32 count[ROWS]; // not the count: the row's index in this launch's table.  Only ~2 % of the rows survive the gate, so
+                         // the counts are fetched for those alone, by the probe kernel (16 streamed bytes per row instead of 20)
         u64 idx[ROWS], gate[ROWS];
         bool valid[ROWS];
     };
     auto load_rows = [&](u64 base, Tile &t) { // A (block-uniform base; nothing is loaded past the table)
         if (VEC && base + (u64)TPB * 2 <= n) { // whole tile inside the table (table bases are 16-byte aligned)
             typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
-            typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
             const u64 i = base + 2 * (u64)threadIdx.x;
             const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
             const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
-            const v2u32 c2 = __builtin_nontemporal_load((const v2u32 *)(cnt + i));
             t.m[0] = U128{l2.x, h2.x};
             t.m[ROWS - 1] = U128{l2.y, h2.y};
-            t.count[0] = c2.x;
-            t.count[ROWS - 1] = c2.y;
+            t.count[0] = (u32)i;
+            t.count[ROWS - 1] = (u32)i + 1;
             t.valid[0] = t.valid[ROWS - 1] = true;
         } else {
 #pragma unroll
@@ -174,7 +173,7 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
                 t.valid[j] = base < n && i < n && (!VEC || i < base + (u64)TPB * 2);
                 t.m[j].lo = t.valid[j] ? __builtin_nontemporal_load(lo + i) : 0;
                 t.m[j].hi = t.valid[j] ? __builtin_nontemporal_load(hi + i) : 0;
-                t.count[j] = t.valid[j] ? __builtin_nontemporal_load(cnt + i) : 0;
+                t.count[j] = (u32)i;
             }
         }
     };
@@ -416,11 +415,194 @@ __global__ void __launch_bounds__(TPB) scan_bin_gate_kernel(int k_rt, int r_rt, 
 }
 
 
+// ---- tickets: the partitioned second level for whole-genome indexes ------------------------------------------------
+// With 1e8 index entries the fine gate is hundreds of MiB and no L2-sized gate in front of it can reject anything
+// (it saturates), so the direct form pays one random HBM line for EVERY table row and runs at a quarter of the
+// roofline.  What a row needs from the gate is a function of its slot idx alone, so the first pass does not move
+// rows at all: it streams the table (16 B per row), hashes, and files an 8-byte TICKET {idx, row number} under the
+// 2 MiB slice of the fine gate that idx falls into.  The second pass gives XCD x the slices x, x + 8, ... : its
+// workgroups read the tickets of one slice (sequential, 8 B each) while that slice sits in the XCD's L2, test the
+// gate, and fetch from the table only the rows that pass (~1-5 %), which go to the usual open list.
+// Traffic per row: 16 (stream) + 8 (ticket out) + 8 (ticket in) = 32 B sequential and one L2 probe, against
+// 20 B + one random HBM line (4-5x an L2 read).
+constexpr int TK_MAXP = 256;       // slices: fine gates up to 512 MiB
+constexpr int TK_LDS_TICKETS = 4096; // staging tickets per workgroup over all slices (32 KB)
+struct TicketSet {
+    u64 *tickets;               // [nbins][nseg] segments of `segcap` tickets
+    u32 *counts;                // [nbins][nseg]
+    u64 *spill;                 // tickets that did not fit their segment
+    unsigned long long *spill_count;
+    u64 segcap;
+    u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift
+    u32 ring;                    // staging tickets per bin (power of two); tickets leave in units of ring / 2
+    u32 row_bits;                // ticket = idx << row_bits | row
+};
+
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_ticket_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, u64 n, int k_rt, int r_rt, BFView bf,
+                                                          TicketSet ts)
+{
+    constexpr int ROWS = 4;
+    extern __shared__ u64 sh_tk[]; // nbins * ring tickets
+    __shared__ u32 sh_n[TK_MAXP], sh_head[TK_MAXP], sh_pos[TK_MAXP]; // staged so far / flushed so far / tickets in the segment
+    __shared__ u32 sh_lut[256];
+    const int P = (int)ts.nbins;
+    const u32 ring = ts.ring, unit = ring / 2;
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ascii_lut_fill(sh_lut);
+    for (int b = threadIdx.x; b < P; b += TPB) sh_n[b] = sh_head[b] = sh_pos[b] = 0;
+    __syncthreads();
+    // every thread of the workgroup calls this, between barriers; `all`: also the last partial unit of every bin
+    auto flush_bins = [&](bool all) {
+        for (int b = wave; b < P; b += TPB / 64) {
+            const u32 head = sh_head[b];
+            const u32 staged = min(sh_n[b], head + ring); // lanes that found the ring full bumped the counter past it
+            const u32 c = all ? staged - head : (staged - head) / unit * unit;
+            if (lane == 0) sh_n[b] = staged;
+            if (c == 0) continue;
+            const u32 pos = sh_pos[b];
+            u64 *dst = ts.tickets;
+            unsigned long long at = ((unsigned long long)b * ts.nseg + blockIdx.x) * ts.segcap + pos;
+            const bool fits = pos + c <= ts.segcap;
+            if (!fits) { // the segment is full: this flush goes to the spill list
+                if (lane == 0) at = atomicAdd(ts.spill_count, (unsigned long long)c);
+                at = __shfl(at, 0, 64);
+                dst = ts.spill;
+            }
+            for (u32 o = lane; o < c; o += 64) dst[at + o] = sh_tk[b * ring + ((head + o) & (ring - 1))];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                sh_head[b] = head + c;
+                if (fits) sh_pos[b] = pos + c;
+            }
+        }
+    };
+    typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
+    const bool vec_ok = ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
+    const u64 step = (u64)gridDim.x * TPB * ROWS;
+    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
+        U128 m[ROWS];
+        u64 tk[ROWS];
+        u32 bin[ROWS];
+        bool pending[ROWS];
+        // A: rows base + {2t, 2t+1} and base + 2 TPB + {2t, 2t+1}: two 16-byte loads per array and thread (counts are not read here)
+#pragma unroll
+        for (int g = 0; g < ROWS / 2; ++g) {
+            const u64 i = base + (u64)g * 2 * TPB + 2 * (u64)threadIdx.x;
+            if (vec_ok && i + 1 < n) {
+                const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
+                const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
+                m[2 * g] = U128{l2.x, h2.x};
+                m[2 * g + 1] = U128{l2.y, h2.y};
+                pending[2 * g] = pending[2 * g + 1] = true;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pending[2 * g + j] = i + j < n;
+                    m[2 * g + j].lo = pending[2 * g + j] ? __builtin_nontemporal_load(lo + i + j) : 0;
+                    m[2 * g + j].hi = pending[2 * g + j] ? __builtin_nontemporal_load(hi + i + j) : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // B: canonical centre k-mer, XXH3, slot -> ticket
+            const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+            const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
+            const u64 row = base + (u64)(j / 2) * 2 * TPB + 2 * (u64)threadIdx.x + (j & 1);
+            tk[j] = (idx << ts.row_bits) | row;
+            bin[j] = (u32)(gate_word(bf, idx) >> ts.word_shift);
+        }
+        // C: tickets into their bin's ring; a full ring defers the lane until the flush that follows
+        bool again;
+        do {
+            bool mine = false;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                if (pending[j]) {
+                    const u32 slot = atomicAdd(&sh_n[bin[j]], 1u);
+                    if (slot - sh_head[bin[j]] < ring) {
+                        sh_tk[bin[j] * ring + (slot & (ring - 1))] = tk[j];
+                        pending[j] = false;
+                    } else
+                        mine = true;
+                }
+            again = __syncthreads_or(mine);
+            flush_bins(false);
+            __syncthreads();
+        } while (again);
+    }
+    flush_bins(true);
+    __syncthreads();
+    for (int b = threadIdx.x; b < P; b += TPB) ts.counts[b * ts.nseg + blockIdx.x] = sh_pos[b];
+}
+
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, BFView bf, TicketSet ts,
+                                                               RowList open, unsigned long long *counters)
+{
+    constexpr int CAP = 2 * TPB + 256;
+    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
+    __shared__ u32 sh_cnt[CAP];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int P = (int)ts.nbins;
+    const u64 row_mask = (1ULL << ts.row_bits) - 1;
+    auto take = [&](const u64 *src, u64 first, u64 np) { // block-uniform arguments
+        for (u64 base = 0; base < np; base += 2 * TPB) {
+            u64 t[2], word[2];
+            bool live[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u64 j = base + q * TPB + threadIdx.x;
+                live[q] = j < np;
+                t[q] = live[q] ? __builtin_nontemporal_load(src + first + j) : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) word[q] = live[q] ? bf.gate[gate_word(bf, t[q] >> ts.row_bits)] : 0; // the slice in this XCD's L2
+            bool pass[2];
+            U128 m[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u64 gm = gate_mask(bf, t[q] >> ts.row_bits);
+                pass[q] = live[q] && (word[q] & gm) == gm;
+                // the table row itself, only for the few that pass (two random lines)
+                m[q] = pass[q] ? U128{__builtin_nontemporal_load(lo + (t[q] & row_mask)), __builtin_nontemporal_load(hi + (t[q] & row_mask))} : U128{0, 0};
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st.push(pass[q], m[q], (u32)(t[q] & row_mask)); // listed with its row number: the probe kernel fetches the count
+            st.flush_if_above(CAP - 2 * TPB, open, &counters[0]);
+        }
+    };
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch) and each XCD has its own L2: XCD x takes slices x,
+    // x + 8, ...; with fewer than 8 slices, slice x mod P, its segments split between the XCDs that share it.
+    // Placement only decides speed, never the result.
+    const u32 xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3; // the grid is a multiple of 8
+    if (P >= 8) {
+        for (int p = (int)xcd; p < P; p += 8)
+            for (u32 w = local; w < ts.nseg; w += nlocal) take(ts.tickets, ((u64)p * ts.nseg + w) * ts.segcap, ts.counts[p * ts.nseg + w]);
+    } else {
+        const int p = (int)(xcd % (u32)P);
+        const u32 share = xcd / (u32)P, nshare = (8 - (u32)p + (u32)P - 1) / (u32)P; // XCDs p, p + P, ... hold this slice
+        for (u32 w = local * nshare + share; w < ts.nseg; w += nlocal * nshare) take(ts.tickets, ((u64)p * ts.nseg + w) * ts.segcap, ts.counts[p * ts.nseg + w]);
+    }
+    {
+        const u64 ns = *ts.spill_count, chunk = (ns + gridDim.x - 1) / gridDim.x;
+        const u64 lo_ = min(ns, chunk * blockIdx.x), hi_ = min(ns, lo_ + chunk);
+        take(ts.spill, lo_, hi_ - lo_);
+    }
+    st.flush_if_above(0, open, &counters[0]);
+}
+
 // (Probe and hit pass fused in one kernel -- no second list, no re-hash -- was measured: 0.276 ms against 0.100 +
 // 0.050 ms; a third of the lanes running a second XXH3 while the others idle costs more than the list.)
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
-                                                         unsigned long long *counters)
+                                                         unsigned long long *counters, const u32 *__restrict__ cnt_table)
 {
     constexpr int CAP = TPB + 256;
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
@@ -444,6 +626,7 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         if (j < n_open) {
             m = U128{open.lo[j], open.hi[j]};
             count = open.cnt[j];
+            if (cnt_table) count = __builtin_nontemporal_load(cnt_table + count); // the filter kernel listed the row's index (requested beside the record below)
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);

@@ -156,10 +156,10 @@ def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
         assert n_map == n_vars
         _scan(ctx, tab)
         whole = _snap(counters)
-        if expect == "two-level":        # fine gate beyond L2 -> coarse gate in front, survivors partitioned by fine-gate slice
-            assert ctx.get_option("pregate_k") >= 1 and ctx.get_option("gate_log2") > 25 and ctx.get_option("scan_bins") >= 2
-        else:                            # 1.6e8 entries saturate a 4 MiB coarse gate: decided at finalize, scans skip it
-            assert ctx.get_option("pregate_k") == 0 and ctx.get_option("gate_log2") >= 30
+        # fine gate far beyond L2 (32 MiB / 256 MiB): tickets filed by 2 MiB gate slice, slices walked out of L2
+        assert ctx.get_option("gate_log2") == (28 if expect == "two-level" else 31)
+        assert ctx.get_option("scan_tickets") == (16 if expect == "two-level" else 128) and ctx.get_option("scan_bins") == 0
+        assert ctx.get_option("scan_spilled") == 0
         _check_expected(ctx, panel, tab, whole, n_bf, n_check=plant)
         _scan(ctx, tab)
         assert torch.equal(counters, whole * 2)                                           # linearity

@@ -65,11 +65,27 @@ def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
         assert ctx.get_option("pregate_k") > 0 and ctx.get_option("scan_bins") == n_bins
         assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
-               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
+               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap), ("use_tickets", 0)])
     def direct(ctx):
         assert ctx.get_option("scan_bins") == 0
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=direct,
                options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("use_partition", 0)])
+
+
+@pytest.mark.parametrize("k,ref_k,bits,gate_log2,slices,bin_cap", [(35, 43, 1 << 33, 14, 32, 0), (35, 43, 1 << 17, 14, 32, 0), (35, 63, 1 << 20, 13, 16, 0),
+                                                                  (31, 41, (1 << 18) + 77, 14, 32, 0), (35, 43, 1 << 33, 12, 8, 0),
+                                                                  (35, 43, 1 << 33, 11, 4, 0),      # fewer slices than XCDs: slices shared
+                                                                  (35, 43, 1 << 33, 14, 32, 16), (35, 43, 1 << 17, 13, 16, 16)])
+def test_scan_ticket_form(k, ref_k, bits, gate_log2, slices, bin_cap):
+    """whole-genome-sized indexes file an 8-byte ticket per table row under the slice of the fine gate it will probe and
+    then walk the slices out of L2 (scan_ticket_kernel / scan_ticket_gate_kernel); forced here on small gates: slices of
+    2^9 bits (pregate_log2 = 10), a fine gate of 2^gate_log2 bits.  bin_cap > 0 shrinks the segments so that most
+    tickets take the spill list.  Counters must equal the oracle's, as in every other form."""
+    def check(ctx):
+        assert ctx.get_option("scan_tickets") == slices and ctx.get_option("scan_bins") == 0
+        assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
+    _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
+               options=[("pregate_log2", 10), ("gate_log2", gate_log2), ("ticket_min_log2", 11), ("scan_bin_cap", bin_cap)])
 
 
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17)])

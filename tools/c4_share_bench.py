@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""One GPU's share of BASELINE config C4 (3.75e8 of 3e9 k-mers, b=16) against a replicated index of --variants
+SNPs: times the scan forms against each other (tickets by gate slice / coarse gate + row partition / direct).
+Table per SURVEY 8(d): 20 % of the rows are windows around variant sites (a fifth of those centred = true hits),
+the rest uniform random; drawn on the GPU (tests/big_cases.py).  Prints one JSON line per form."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from big_cases import DeviceTable, build_device_index  # noqa: E402
+from malva_amd import Context, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", type=float, default=8e7)
+ap.add_argument("--rows", type=float, default=3.75e8)
+ap.add_argument("--b", type=int, default=16)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--forms", default="tickets,legacy")
+args = ap.parse_args()
+K, R = 35, 43
+n_vars, n_rows = int(args.variants), int(args.rows)
+t0 = time.time()
+panel = synth.snp_panel(n_vars, 4242, spacing=40)
+plant = min(n_vars, n_rows // 5 * 2 // 15)          # 7.5 windows per planted variant on average -> 20 % of the rows
+tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
+print("[c4] panel + table: %.0f s, %d site rows (%.1f %%)" % (time.time() - t0, tab.n_site, 100.0 * tab.n_site / n_rows), file=sys.stderr)
+forms = {"tickets": [], "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)]}
+for form in args.forms.split(","):
+    with Context(K, R, args.b << 33) as ctx:
+        for name, value in forms[form]:
+            ctx.set_option(name, value)
+        t0 = time.time()
+        build_device_index(ctx, panel, K)
+        build_s = time.time() - t0
+        ms = []
+        for _ in range(args.reps + 1):
+            ctx.counters_reset()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.kmc_scan_device(*tab.ptrs())
+            ctx.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+        f, p, h, n_open, n_hit = ctx.scan_stats()
+        first = min(n_rows, 1 << 27)
+        print(json.dumps({"form": form, "variants": n_vars, "rows": n_rows, "b": args.b, "gate_log2": ctx.get_option("gate_log2"),
+                          "pregate_k": ctx.get_option("pregate_k"), "scan_tickets": ctx.get_option("scan_tickets"), "scan_bins": ctx.get_option("scan_bins"),
+                          "spilled": ctx.get_option("scan_spilled"), "scan_ms_whole_table": round(min(ms[1:]), 3),
+                          "first_chunk_rows": first, "first_chunk_ms": {"filter": round(f, 3), "probe": round(p, 3), "hits": round(h, 3)},
+                          "filter_frac_of_8TBs": round(44 * first / (f * 1e-3) / 8e12, 3),
+                          "scan_frac_of_8TBs": round(44 * n_rows / (min(ms[1:]) * 1e-3) / 8e12, 3),
+                          "open_rows_last_chunk": n_open, "bf_hit_rows": n_hit, "index_build_s": round(build_s, 1)}), flush=True)
