@@ -99,7 +99,8 @@ struct mg_ctx {
     int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
     int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
     int probe_grid = 2048, hits_grid = 1024; // workgroups of the two list kernels (swept)
-    int use_tickets = 1;     // gates beyond L2: file 8-byte tickets by gate slice instead of probing HBM at random (scan_ticket_kernel)
+    int use_tickets = 0;     // gates beyond L2: file 8-byte tickets by gate slice instead of probing HBM at random (scan_ticket_kernel);
+                             // measured slower than the direct forms at both 1e7 and 8e7 SNPs (profiles/r02_c4share_forms.txt): off, kept for A/B
     int ticket_min_log2 = 26; // smallest fine gate (log2 bits) that takes the ticket form
     Scratch s_tk[2];
     unsigned long long *d_tk_meta = nullptr; // spill count, then u32 [TK_MAXP][BIN_SEGS] segment fills
@@ -944,7 +945,7 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
         ts.nseg = (u32)std::min<u64>((n + 4 * TPB - 1) / (4 * TPB), tickets->nseg);
         hipLaunchKernelGGL((scan_ticket_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), (size_t)ts.nbins * ts.ring * 8, c->stream, d_hi, d_lo, n, (int)c->k,
                            (int)c->ref_k, view(c, MG_BF_ALT), ts);
-        hipLaunchKernelGGL((scan_ticket_gate_kernel<KC, RC>), dim3(2048), dim3(TPB), 0, c->stream, d_hi, d_lo, view(c, MG_BF_ALT), ts, open, c->d_hit_count);
+        hipLaunchKernelGGL((scan_ticket_gate_kernel<KC, RC>), dim3(2048), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), ts, RowList{nullptr, nullptr, open.cnt}, c->d_hit_count);
     } else if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
         BinSet bs = *bins; // the last chunk may need fewer workgroups than segments were laid out for
         bs.nseg = (u32)std::min<u64>((n + 2 * TPB - 1) / (2 * TPB), bins->nseg);
@@ -967,7 +968,7 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
     hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
-                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt);
+                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt, tickets ? d_hi : (const u64 *)nullptr, tickets ? d_lo : (const u64 *)nullptr);
     if (timed) hipEventRecord(c->ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);

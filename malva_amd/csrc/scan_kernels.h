@@ -105,8 +105,10 @@ template <int CAP> struct BlockStage {
             __syncthreads();
             const unsigned long long b = *base;
             for (u32 j = threadIdx.x; j < c; j += TPB) {
-                g.hi[b + j] = hi[j];
-                g.lo[b + j] = lo[j];
+                if (g.hi) { // (a list of row numbers only has no hi / lo arrays)
+                    g.hi[b + j] = hi[j];
+                    g.lo[b + j] = lo[j];
+                }
                 g.cnt[b + j] = cnt[j];
             }
             __syncthreads();
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(TPB) scan_ticket_kernel(const u64 *__restrict_
 }
 
 template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, BFView bf, TicketSet ts,
+__global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(BFView bf, TicketSet ts,
                                                                RowList open, unsigned long long *counters)
 {
     constexpr int CAP = 2 * TPB + 256;
@@ -564,17 +566,12 @@ __global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(const u64 *__rest
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) word[q] = live[q] ? bf.gate[gate_word(bf, t[q] >> ts.row_bits)] : 0; // the slice in this XCD's L2
-            bool pass[2];
-            U128 m[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const u64 gm = gate_mask(bf, t[q] >> ts.row_bits);
-                pass[q] = live[q] && (word[q] & gm) == gm;
-                // the table row itself, only for the few that pass (two random lines)
-                m[q] = pass[q] ? U128{__builtin_nontemporal_load(lo + (t[q] & row_mask)), __builtin_nontemporal_load(hi + (t[q] & row_mask))} : U128{0, 0};
+                // listed by row number alone: the probe kernel, which has no stream to disturb, fetches the row and its count
+                st.push(live[q] && (word[q] & gm) == gm, U128{0, 0}, (u32)(t[q] & row_mask));
             }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) st.push(pass[q], m[q], (u32)(t[q] & row_mask)); // listed with its row number: the probe kernel fetches the count
             st.flush_if_above(CAP - 2 * TPB, open, &counters[0]);
         }
     };
@@ -602,7 +599,8 @@ __global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(const u64 *__rest
 // 0.050 ms; a third of the lanes running a second XXH3 while the others idle costs more than the list.)
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
-                                                         unsigned long long *counters, const u32 *__restrict__ cnt_table)
+                                                         unsigned long long *counters, const u32 *__restrict__ cnt_table,
+                                                         const u64 *__restrict__ row_hi, const u64 *__restrict__ row_lo)
 {
     constexpr int CAP = TPB + 256;
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
@@ -624,9 +622,14 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         U128 m{0, 0};
         u32 count = 0;
         if (j < n_open) {
-            m = U128{open.lo[j], open.hi[j]};
             count = open.cnt[j];
-            if (cnt_table) count = __builtin_nontemporal_load(cnt_table + count); // the filter kernel listed the row's index (requested beside the record below)
+            if (row_hi) { // ticket form: the list holds row numbers only; the row's three words are requested together
+                m = U128{__builtin_nontemporal_load(row_lo + count), __builtin_nontemporal_load(row_hi + count)};
+                count = __builtin_nontemporal_load(cnt_table + count);
+            } else {
+                m = U128{open.lo[j], open.hi[j]};
+                if (cnt_table) count = __builtin_nontemporal_load(cnt_table + count); // the filter kernel listed the row's index (requested beside the record below)
+            }
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);

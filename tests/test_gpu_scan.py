@@ -65,7 +65,7 @@ def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
         assert ctx.get_option("pregate_k") > 0 and ctx.get_option("scan_bins") == n_bins
         assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
-               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap), ("use_tickets", 0)])
+               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
     def direct(ctx):
         assert ctx.get_option("scan_bins") == 0
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=direct,
@@ -81,11 +81,17 @@ def test_scan_ticket_form(k, ref_k, bits, gate_log2, slices, bin_cap):
     then walk the slices out of L2 (scan_ticket_kernel / scan_ticket_gate_kernel); forced here on small gates: slices of
     2^9 bits (pregate_log2 = 10), a fine gate of 2^gate_log2 bits.  bin_cap > 0 shrinks the segments so that most
     tickets take the spill list.  Counters must equal the oracle's, as in every other form."""
+    shift = 6                                    # the gate holds one bit per 2^shift filter bits, at most 2^gate_log2 of them
+    while ((bits + (1 << shift) - 1) >> shift) > (1 << gate_log2):
+        shift += 1
+    words = (((bits + (1 << shift) - 1) >> shift) + 63) // 64
+    slices = (words + 7) // 8 if slices else 0   # slices of 8 words (pregate_log2 = 10)
+
     def check(ctx):
-        assert ctx.get_option("scan_tickets") == slices and ctx.get_option("scan_bins") == 0
+        assert ctx.get_option("scan_tickets") == slices >= 2 and ctx.get_option("scan_bins") == 0
         assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
-               options=[("pregate_log2", 10), ("gate_log2", gate_log2), ("ticket_min_log2", 11), ("scan_bin_cap", bin_cap)])
+               options=[("pregate_log2", 10), ("gate_log2", gate_log2), ("use_tickets", 1), ("ticket_min_log2", 11), ("scan_bin_cap", bin_cap)])
 
 
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17)])
