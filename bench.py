@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--b", type=int, default=4, help="filter size in units of 2^33 bits (malva-geno -b)")
     ap.add_argument("--k", type=int, default=35, help="signature k-mer length (malva-geno -k)")
     ap.add_argument("--r", type=int, default=43, help="context k-mer length of the KMC table (malva-geno -r); 63 = config C5's")
+    ap.add_argument("--layout", choices=["compact", "soa"], default="compact",
+                    help="table layout in HBM: compact = 12-byte rows (count << 2r | r-mer; needs 33 <= r <= 44), soa = {hi[], lo[], cnt[]} 20 B/row")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --kmers is the WHOLE table, sharded over the ranks (north_star's 8-GPU claim: "
                          "--strong --kmers 3e9 --variants 8e7 --b 16); default is weak scaling, --kmers rows per GPU")
@@ -160,6 +162,18 @@ def main():
 
     d_hi, d_lo = dev_i64(hi), dev_i64(lo)
     d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+    compact = args.layout == "compact" and 33 <= R <= 44
+    d_rows = None
+    if compact:                     # the table as it stays resident: packed once, outside the timed region
+        d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.kmc_pack_rows_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows, d_rows.data_ptr())
+
+    def scan(n):
+        if compact:
+            ctx.kmc_scan_rows_device(d_rows.data_ptr(), n)
+        else:
+            ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n)
     ctx.reference_upload(panel.genome)
     d_pos = dev_i64(sub.pos.astype(np.uint64))
     d_vo = torch.from_numpy(sub.var_allele_off.astype(np.uint32).view(np.int32)).to(dev)
@@ -206,7 +220,7 @@ def main():
 
     def step(record=False):
         ctx.counters_reset()
-        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
+        scan(n_rows)
         if world > 1 and native:
             ctx.counters_allreduce()
         elif world > 1:
@@ -244,7 +258,7 @@ def main():
     geno_ms = []
     for _ in range(max(3, args.steps)):
         ctx.counters_reset()
-        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows)
+        scan(n_rows)
         scan_ms.append(ctx.scan_stats())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -287,7 +301,7 @@ def main():
         cpu_scan_s = time.perf_counter() - t0
         # parity of the same sample through the device path
         ctx.counters_reset()
-        ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), ns)
+        scan(ns)
         ctx.synchronize()
         _, _, _, counts = ctx.bf_export(BF_ALT)
         keys, vals = ctx.map_export()
@@ -320,7 +334,8 @@ def main():
                                       "sample": "first %d rows, the same loop on %d threads sharing one index (atomic adds)" % (ns_all, cores)}}
 
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_scan_filter.json")
+    tname = "traffic_scan_filter12.json" if compact else "traffic_scan_filter.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and not args.scan_ablate:
         # HBM bytes per launch cannot be counted from inside this process: it comes from the rocprofv3 PMC passes
         # of tools/profile_gpu.sh on this same command (FETCH_SIZE calibrated on the kernel's own 8-byte-per-lane
@@ -358,13 +373,14 @@ def main():
                                        n_rows, total_rows, n_vars_total, K, R, args.b),
                        "kmers_per_gpu": n_rows, "kmers_total": total_rows, "panel_variants": n_vars_total, "variants_genotyped_per_gpu": n_vars,
                        "k": K, "ref_k": R, "bf_bits": bf_bits,
+                       "table_layout": "12-byte rows (count << 2r | r-mer)" if compact else "SoA hi[] lo[] cnt[] (20 B/row)",
                        "parallelism": "table rows x%d (%s), panel genotyping split x%d, index replicated" % (world, "strong" if args.strong else "weak", world),
                        "summary_bitmaps": not args.no_summary,
                        "exchange": ("none" if world == 1 else "%s over %d counters%s" % (
                            exchange, n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
             "roofline": {"kernel": ("scan_bin_kernel<%s,4> + scan_bin_gate_kernel<%s> (partitioned second level, %d slices)" % (spec, spec, ctx.get_option("scan_bins"))
-                                    if ctx.get_option("scan_bins") else "scan_filter_kernel<%s,2>" % spec), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/traffic_scan_filter.json (rocprofv3 PMC)" if traffic else None,
+                                    if ctx.get_option("scan_bins") else ("scan_filter12_kernel<%s>" if compact else "scan_filter_kernel<%s,2>") % spec), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 PMC)" % tname if traffic else None,
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": rows_per_launch, "avg_launch_ms": filt_ms},
             # the whole H10 loop (filter + probe + hit kernels, summed): the fraction SURVEY 8(d)'s 44 B/k-mer budget is about

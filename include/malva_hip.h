@@ -117,6 +117,15 @@ int mg_ref_scan(mg_ctx *ctx, const char *contig, size_t len);
 int mg_kmc_scan(mg_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n);
 int mg_kmc_scan_device(mg_ctx *ctx, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n);
 
+/* The same scan over COMPACT rows: 12 bytes per row instead of 20 -- three little-endian dwords holding the 96-bit
+ * value  count << (2 ref_k) | ref_k-mer (2-bit string as above).  For 33 <= ref_k <= 44 (the reference's default is 43)
+ * and counts below 2^(96 - 2 ref_k) (1024 at ref_k 43; KMC caps counts at 255, MALVA:107).  mg_kmc_pack_rows_device
+ * builds them from an SoA table (n rounded up to a multiple of four rows: mg_kmc_rows_bytes(n) bytes, zero padded)
+ * and returns MG_ERR_LIMIT when a count does not fit; the scan is asynchronous like mg_kmc_scan_device. */
+size_t mg_kmc_rows_bytes(size_t n);
+int mg_kmc_pack_rows_device(mg_ctx *ctx, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n, void *d_rows_out);
+int mg_kmc_scan_rows_device(mg_ctx *ctx, const void *d_rows, size_t n);
+
 /* KMC database feed: CKMCFile::OpenForListing / ReadNextKmer / CKmerAPI::to_string (main.cpp:444-449, 482-490; the KMC
  * API is a third-party library the reference links, absent from its checkout: format restated from KMC's published
  * database layout, "parity unpinned" -- DESIGN.md).  The host hands over what the two files hold and parses nothing:

@@ -81,6 +81,8 @@ def lib():
         "mg_ref_scan": [vp, vp, sz],
         "mg_kmc_scan": [vp, vp, vp, vp, sz],
         "mg_kmc_scan_device": [vp, vp, vp, vp, sz],
+        "mg_kmc_pack_rows_device": [vp, vp, vp, vp, sz, vp],
+        "mg_kmc_scan_rows_device": [vp, vp, sz],
         "mg_host_alloc": [C.POINTER(vp), sz],
         "mg_host_free": [vp],
         "mg_kmc_set_lut": [vp, vp, sz, u32, u32, u32, u32, u64, u64],
@@ -120,6 +122,8 @@ def lib():
         f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         f.argtypes = args
         f.restype = C.c_int
+    L.mg_kmc_rows_bytes.argtypes = [sz]
+    L.mg_kmc_rows_bytes.restype = C.c_size_t
     L.mg_last_error.argtypes = [vp]
     L.mg_last_error.restype = cp
     _LIB = L
@@ -128,7 +132,7 @@ def lib():
 
 EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_synchronize", "mg_bf_insert", "mg_bf_test",
             "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
-            "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device",
+            "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device", "mg_kmc_rows_bytes", "mg_kmc_pack_rows_device", "mg_kmc_scan_rows_device",
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
@@ -384,6 +388,15 @@ class Context:
         hi, lo, cnt = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
         self._ck(self._L.mg_kmc_decode_records(self.h, _p(records), n, first_record, _p(hi), _p(lo), _p(cnt)))
         return hi, lo, cnt
+
+    def kmc_rows_bytes(self, n):
+        return self._L.mg_kmc_rows_bytes(n)
+
+    def kmc_pack_rows_device(self, d_hi, d_lo, d_cnt, n, d_rows_out):
+        self._ck(self._L.mg_kmc_pack_rows_device(self.h, C.c_void_p(d_hi), C.c_void_p(d_lo), C.c_void_p(d_cnt), n, C.c_void_p(d_rows_out)))
+
+    def kmc_scan_rows_device(self, d_rows, n):
+        self._ck(self._L.mg_kmc_scan_rows_device(self.h, C.c_void_p(d_rows), n))
 
     def scan_stats(self):
         """-> (filter ms, probe ms, hits ms, open rows, bf-hit rows)"""

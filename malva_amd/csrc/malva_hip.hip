@@ -1061,6 +1061,84 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     return MG_OK;
 }
 
+// ---- compact (12-byte) table rows --------------------------------------------------------------------------------
+namespace {
+template <int KC, int RC>
+void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowList hits, bool timed)
+{
+    if (timed) hipEventRecord(c->ev[0], c->stream);
+    const unsigned fgrid = (unsigned)std::min<u64>(((n + 1) / 2 + TPB - 1) / TPB, (u64)c->scan_grid);
+    hipLaunchKernelGGL((scan_filter12_kernel<KC, RC>), dim3(fgrid), dim3(TPB), 0, c->stream, (const u32 *)rows, n, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), open,
+                       c->d_hit_count);
+    if (timed) hipEventRecord(c->ev[1], c->stream);
+    const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
+    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits,
+                       c->d_hit_count, (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr);
+    if (timed) hipEventRecord(c->ev[2], c->stream);
+    hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
+                       view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
+    if (timed) hipEventRecord(c->ev[3], c->stream);
+}
+int rows12_ok(mg_ctx *c)
+{
+    if (c->ref_k < 33 || c->ref_k > 44)
+        return fail(c, MG_ERR_LIMIT, "packed 12-byte rows hold a ref_k-mer of 33..44 bases and a count of 96 - 2 ref_k bits (ref_k = %u): use the SoA table", c->ref_k);
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT size_t mg_kmc_rows_bytes(size_t n) { return (n + 3) / 4 * 4 * 12; }
+
+MG_EXPORT int mg_kmc_pack_rows_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n, void *d_rows_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    TRY(rows12_ok(c));
+    if (n == 0) return MG_OK;
+    if (!d_hi || !d_lo || !d_cnt || !d_rows_out) return fail(c, MG_ERR_ARG, "NULL pointer");
+    int *d_bad = (int *)(c->d_hit_count + 3);
+    HIP_TRY(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    hipLaunchKernelGGL(pack_rows12_kernel, dim3(nblocks((n + 3) / 4 * 4)), dim3(TPB), 0, c->stream, (const u64 *)d_hi, (const u64 *)d_lo, (const u32 *)d_cnt,
+                       (u64)n, (int)c->ref_k, (u32 *)d_rows_out, d_bad);
+    HIP_TRY(c, hipGetLastError());
+    int bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) return fail(c, MG_ERR_LIMIT, "a count of 2^%u or more (or a k-mer wider than ref_k) does not fit a packed row: use the SoA table", 96 - 2 * c->ref_k);
+    return MG_OK;
+}
+
+MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
+    TRY(rows12_ok(c));
+    if (n == 0) return MG_OK;
+    if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(c, MG_ERR_ARG, "packed rows must be 16-byte aligned");
+    if (!c->map.slots) TRY(map_reserve(c, 0));
+    const u64 chunk = 1ULL << 27;
+    const u64 cap = n < chunk ? n : chunk;
+    void *p[6];
+    Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
+    for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
+    const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    c->stats_valid = false;
+    HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
+    for (u64 r0 = 0; r0 < n; r0 += chunk) {
+        const u64 nr = n - r0 < chunk ? n - r0 : chunk;
+        const uint4 *pr = (const uint4 *)d_rows + r0 / 4 * 3;
+        if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
+        if (c->k == 35 && c->ref_k == 43) launch_rows12_chunk<35, 43>(c, pr, nr, open, hits, r0 == 0);
+        else launch_rows12_chunk<0, 0>(c, pr, nr, open, hits, r0 == 0);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->last_bins = 0;
+    c->last_tickets = 0;
+    c->stats_valid = true;
+    return MG_OK;
+}
+
 namespace {
 // Host-fed scans stream the table through the device in pieces.  Two staging slots: while the scan kernels work
 // on one, the copy stream fills the other (PCIe and HBM work overlap; with pinned host memory -- mg_host_alloc --

@@ -210,9 +210,10 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
             const u64 gm = gate_mask(bf, t.idx[j]);
             const bool take = open_j[j] && !(ablate & 2) && (t.gate[j] & gm) == gm;
             if (ablate) asm volatile("" ::"v"((u32)t.idx[j]), "v"((u32)t.m[j].hi));
-            st.push(take, t.m[j], t.count[j]);
+            if (ablate & 16) asm volatile("" ::"v"((u32)take)); // 16 = no staging, no barriers (is the per-tile rendezvous what costs?)
+            else st.push(take, t.m[j], t.count[j]);
         }
-        st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
+        if (!(ablate & 16)) st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]); // room for one more full iteration
     };
     // (A software pipeline over the tiles -- tile i+1 hashed while tile i waits for its gate words -- was tried and
     // changed nothing: with the gate loads present the kernel takes ~0.75 ms per 1e8 rows whatever the hashing
@@ -225,6 +226,116 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
         finish(t);
     }
     st.flush_if_above(0, open, &counters[0]);
+}
+
+// ---- compact table rows ------------------------------------------------------------------------------------------
+// The SoA table streams 16 B per row through the filter kernel (plus a random count fetch per open row).  A 43-mer is
+// 86 bits and a KMC count at most 255 (-cs255, MALVA:107): a row fits 12 bytes, which is also what a KMC database
+// spends (10).  Packed rows: three little-endian dwords per row, the 96-bit value  count << 2 ref_k | k-mer (M-form);
+// valid while 2 ref_k + 8 <= 96 and every count < 2^(96 - 2 ref_k)  (mg_kmc_pack_rows checks).  The open rows are listed
+// with their counts, so the probe kernel fetches nothing extra; everything after the load is scan_filter_kernel's.
+// Measured and dropped on this kernel (round 2, C3, all at 0.70 +- 0.02 ms per 1e8 rows -- the same as the 16-byte SoA
+// stream, so the kernel is not bound by its stream): four rows per thread with 16-byte loads (0.74); a variant with the
+// filter shape fixed at compile time (60 instead of 106 SGPRs, 8 instead of 6 workgroups per CU: 0.70); the row stream
+// prefetched two tiles ahead into rotating register buffers with the gate probes issued first (0.72); no staging and
+// no barriers at all (timing only: 0.76).  Without the gate probe the loop takes 0.51 ms: the probe's 0.2 ms is what a
+// random L2 word per row costs on top of the hashing, whatever surrounds it.
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_filter12_kernel(const u32 *__restrict__ rows, u64 n, int k_rt, int r_rt, BFView bf, RowList open,
+                                                            unsigned long long *counters)
+{
+    constexpr int ROWS = 2, CAP = TPB * ROWS + 256; // two adjacent rows per thread: three 8-byte loads
+    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
+    __shared__ u32 sh_cnt[CAP];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const u32 kbits_hi = (u32)(2 * r - 64); // bits of the k-mer in the third dword (2 ref_k > 64 is checked by the host)
+    const u32 kmask_hi = (1u << kbits_hi) - 1;
+    const u64 n_groups = ((n + 3) / 4 * 4) / ROWS; // the buffer is padded to whole quads (mg_kmc_pack_rows)
+    const u64 step = (u64)gridDim.x * TPB;
+    typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
+    for (u64 qbase = (u64)blockIdx.x * TPB; qbase < n_groups; qbase += step) {
+        const u64 q = qbase + threadIdx.x;
+        const bool in = q < n_groups;
+        u32 w[3 * ROWS];
+#pragma unroll
+        for (int i = 0; i < 3 * ROWS; ++i) w[i] = 0;
+        if (in) { // A: 24 contiguous bytes, the only HBM stream
+            const v2u32 *src = (const v2u32 *)rows + 3 * q;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const v2u32 v = __builtin_nontemporal_load(src + i);
+                w[2 * i] = v.x;
+                w[2 * i + 1] = v.y;
+            }
+        }
+        U128 m[ROWS];
+        u32 count[ROWS];
+        u64 idx[ROWS], gate[ROWS];
+        bool valid[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            m[j] = U128{w[3 * j] | (u64)w[3 * j + 1] << 32, (u64)(w[3 * j + 2] & kmask_hi)};
+            count[j] = w[3 * j + 2] >> kbits_hi;
+            valid[j] = in && ROWS * q + j < n;
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // B
+            const U128 cn = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+            idx[j] = mod_size(xxh3_packed_k<KC>(cn, k, sh_lut), bf.mod);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) // C
+            gate[j] = !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
+        bool open_j[ROWS];
+        if (bf.pregate && bf.use_gate) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const u64 pm = pre_mask(bf, idx[j]);
+                open_j[j] = valid[j] && (gate[j] & pm) == pm;
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) gate[j] = open_j[j] ? bf.gate[gate_word(bf, idx[j])] : 0ULL;
+        } else {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) open_j[j] = valid[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { // D
+            const u64 gm = gate_mask(bf, idx[j]);
+            st.push(open_j[j] && (gate[j] & gm) == gm, m[j], count[j]);
+        }
+        st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]);
+    }
+    st.flush_if_above(0, open, &counters[0]);
+}
+
+// SoA rows -> packed rows (the producer side of the layout above); *bad is set when a count does not fit
+__global__ void __launch_bounds__(TPB) pack_rows12_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ cnt, u64 n,
+                                                          int ref_k, u32 *__restrict__ out, int *bad)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 n_pad = (n + 3) / 4 * 4;
+    if (i >= n_pad) return;
+    const u32 kbits_hi = (u32)(2 * ref_k - 64);
+    u64 l = 0, h = 0;
+    u32 c = 0;
+    if (i < n) {
+        l = lo[i];
+        h = hi[i];
+        c = cnt[i];
+        if ((c >> (32 - kbits_hi)) != 0 || (h >> kbits_hi) != 0) *bad = 1;
+    }
+    out[3 * i] = (u32)l;
+    out[3 * i + 1] = (u32)(l >> 32);
+    out[3 * i + 2] = (u32)h | (c << kbits_hi);
 }
 
 // ---- partitioned second level -------------------------------------------------------------------------------

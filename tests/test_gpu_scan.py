@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from gpu_util import build_index_pair, map_values_by_key
-from malva_amd import BF_ALT, BF_CTX, Context, synth
+from malva_amd import BF_ALT, BF_CTX, Context, MalvaError, synth
 from oracle import capi as ocapi
 
 pytestmark = pytest.mark.gpu
@@ -176,3 +176,39 @@ def test_coarse_gate_is_chosen_or_skipped_at_finalize(pregate_log2, expect_k):
     def check(ctx):
         assert ctx.get_option("pregate_k") == expect_k and ctx.get_option("scan_bins") == 0
     _scan_case(35, 43, 1 << 33, 3000, 100000, 71, after=check, options=[("pregate_log2", pregate_log2)])
+
+
+@pytest.mark.parametrize("k,ref_k,n_rows,bits", [(35, 43, 120001, 1 << 33), (35, 43, 150003, 1 << 17), (31, 41, 60002, (1 << 18) + 77), (33, 44, 50000, 1 << 20),
+                                                 (17, 33, 50001, 1 << 20)])
+def test_scan_compact_rows_equals_oracle(k, ref_k, n_rows, bits):
+    """12-byte rows (count << 2 ref_k | k-mer): packed on the device from the SoA table, scanned by scan_filter12_kernel;
+    every counter equals the oracle's scan of the SoA rows"""
+    import torch
+    panel = synth.snp_panel(3000, 70 + k)
+    hi, lo, cnt = synth.kmer_table(panel, n_rows, k, ref_k, 71)
+    cnt[:] = 1 + (cnt * 37) % ((1 << (96 - 2 * ref_k)) - 1)          # the whole range a packed row can hold (ref_k 44: 1..254)
+    with Context(k, ref_k, bits) as ctx:
+        obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
+        ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        dev = torch.device("cuda", 0)
+        d_hi, d_lo = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (hi, lo))
+        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+        d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.kmc_pack_rows_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows, d_rows.data_ptr())
+        w = d_rows.cpu().numpy().view(np.uint32).reshape(-1, 3)[:n_rows].astype(np.uint64)
+        kb = 2 * ref_k - 64
+        assert np.array_equal(w[:, 0] | (w[:, 1] << np.uint64(32)), lo) and np.array_equal(w[:, 2] & np.uint64((1 << kb) - 1), hi)
+        assert np.array_equal(w[:, 2] >> np.uint64(kb), cnt.astype(np.uint64))
+        ctx.kmc_scan_rows_device(d_rows.data_ptr(), n_rows)
+        ctx.synchronize()
+        assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
+        assert map_values_by_key(ctx) == dict(omap.items())
+        # a count that does not fit is refused, not truncated
+        d_cnt[7] = 1 << (96 - 2 * ref_k)
+        torch.cuda.synchronize()
+        with pytest.raises(MalvaError):
+            ctx.kmc_pack_rows_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows, d_rows.data_ptr())
+    with Context(35, 63, 1 << 20) as ctx:                              # 126-bit k-mers leave no room for a count
+        with pytest.raises(MalvaError):
+            ctx.kmc_scan_rows_device(1 << 20, 4)
