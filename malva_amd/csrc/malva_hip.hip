@@ -1069,7 +1069,7 @@ void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowL
     if (timed) hipEventRecord(c->ev[0], c->stream);
     const unsigned fgrid = (unsigned)std::min<u64>(((n + 1) / 2 + TPB - 1) / TPB, (u64)c->scan_grid);
     hipLaunchKernelGGL((scan_filter12_kernel<KC, RC>), dim3(fgrid), dim3(TPB), 0, c->stream, (const u32 *)rows, n, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), open,
-                       c->d_hit_count);
+                       c->d_hit_count, c->scan_ablate);
     if (timed) hipEventRecord(c->ev[1], c->stream);
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
     hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits,

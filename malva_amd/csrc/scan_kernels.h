@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(TPB) scan_filter_kernel(const u64 *__restrict_
 // random L2 word per row costs on top of the hashing, whatever surrounds it.
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_filter12_kernel(const u32 *__restrict__ rows, u64 n, int k_rt, int r_rt, BFView bf, RowList open,
-                                                            unsigned long long *counters)
+                                                            unsigned long long *counters, int ablate) // ablate: timing / counter calibration only, as in scan_filter_kernel (1, 2)
 {
     constexpr int ROWS = 2, CAP = TPB * ROWS + 256; // two adjacent rows per thread: three 8-byte loads
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(TPB) scan_filter12_kernel(const u32 *__restric
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) // C
-            gate[j] = !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
+            gate[j] = (ablate & 1) ? 0ULL : !bf.use_gate ? ~0ULL : bf.pregate ? bf.pregate[pre_word(bf, idx[j])] : bf.gate[gate_word(bf, idx[j])];
         bool open_j[ROWS];
         if (bf.pregate && bf.use_gate) {
 #pragma unroll
@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(TPB) scan_filter12_kernel(const u32 *__restric
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { // D
             const u64 gm = gate_mask(bf, idx[j]);
-            st.push(open_j[j] && (gate[j] & gm) == gm, m[j], count[j]);
+            if (ablate) asm volatile("" ::"v"((u32)idx[j]), "v"((u32)m[j].hi));
+            st.push(open_j[j] && !(ablate & 2) && (gate[j] & gm) == gm, m[j], count[j]);
         }
         st.flush_if_above(CAP - TPB * ROWS, open, &counters[0]);
     }

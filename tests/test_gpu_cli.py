@@ -188,9 +188,10 @@ def test_index_file_is_the_references_container_and_interchanges_with_the_oracle
     filters, keys = index_file.read_index(zst)
     for (mode, size, pos, counts), want in zip(filters, (idx.context_bf, idx.bf)):
         assert (mode, size) == (1, 1 << 33)
-        assert np.array_equal(pos, want.set_positions()) and pos.size > 0
+        assert np.array_equal(pos, want.set_positions())
         assert counts.size == pos.size and not counts.any()             # switch_mode leaves zeroed counters (bloom_filter.hpp:96)
-    assert keys == dict(idx.ref_bf.items())
+    assert filters[1][2].size > 100                                      # (context_bf may well be empty on a panel this small)
+    assert keys == dict(idx.ref_bf.items()) and len(keys) > 100
     from_own = run_cli(["call"] + args)
     # the compact container holds the same payload
     run_cli(["index"] + args, env=dict(os.environ, MALVA_GENO_INDEX_FORMAT="hipz"))

@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- python3 $BENCH > /dev/null 2> "$OUT/pmc_$name.log" || { echo "pmc pass $grp failed"; tail -3 "$OUT/pmc_$name.log"; }
 done
 # calibration of FETCH_SIZE on this kernel's own access pattern: with --scan-ablate 3 the filter kernel issues only
-# its table stream (20 B per row, known exactly), no gate loads, no list writes
+# its table stream (12 B per row with the compact layout, 16 B with the SoA one: known exactly), no gate loads, no list writes
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_FETCH_SIZE" -- python3 $BENCH --scan-ablate 3 > /dev/null 2> "$OUT/cal_FETCH_SIZE.log" || echo "calibration pass failed"
 cd - > /dev/null
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1

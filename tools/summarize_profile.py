@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key in ("scan_filter_kernel", "scan_probe_kernel", "scan_hits_kernel", "scan_bin_gate_kernel", "scan_bin_kernel", "iso_cover_kernel<false>",
+    for key in ("scan_filter12_kernel", "scan_ticket_gate_kernel", "scan_ticket_kernel", "kmc_decode_kernel", "pack_rows12_kernel", "scan_filter_kernel", "scan_probe_kernel", "scan_hits_kernel", "scan_bin_gate_kernel", "scan_bin_kernel", "iso_cover_kernel<false>",
                 "iso_cover_kernel<true>", "iso_genotype_kernel", "ref_scan_kernel", "rows_kernel", "map_insert_kernel", "genotype_kernel",
                 "cover_kernel", "blk_pop_kernel", "summary_kernel"):
         if key in name:
@@ -49,7 +49,8 @@ for f in glob.glob(os.path.join(out, "cal_FETCH_SIZE", "**", "*counter_collectio
     for r in csv.DictReader(open(f)):
         if "scan_filter" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
             cal.append(float(r["Counter_Value"]))
-k = next((x for x in acc if x.startswith("scan_filter_kernel")), "scan_filter_kernel")
+k = next((x for x in acc if x.startswith("scan_filter12_kernel")), None) or next((x for x in acc if x.startswith("scan_filter_kernel")), "scan_filter_kernel")
+compact = k.startswith("scan_filter12")
 if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
     rows = None
     try:
@@ -58,7 +59,7 @@ if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
     except Exception:
         pass
     if rows:
-        stream = 20.0 * rows
+        stream = (12.0 if compact else 16.0) * rows      # what the kernel streams per row: packed rows, or hi + lo of the SoA table
         fetch_cal_kb = sum(cal) / len(cal)
         factor = stream / (fetch_cal_kb * 1024.0)
         fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
@@ -68,6 +69,6 @@ if cal and k in acc and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         print("== filter-kernel HBM traffic per launch ==")
         print("stream-only FETCH_SIZE %.6g KB for a known %.6g B stream -> calibration factor %.3f" % (fetch_cal_kb, stream, factor))
         print("FETCH_SIZE %.6g KB, WRITE_SIZE %.6g KB -> %.4g B per launch (algorithmic %.4g B)" % (fetch_kb, write_kb, traffic, 44.0 * rows))
-        json.dump({"kernel": "scan_filter_kernel", "units_per_launch": rows, "bf_bits": bf_bits, "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb,
-                   "write_size_kb": write_kb, "fetch_calibration_factor": factor, "calibration": "FETCH_SIZE of the same kernel with only its 20 B/row stream (scan_ablate=3)",
-                   "algorithmic_bytes_per_launch": 44.0 * rows}, open(os.path.join(out, "traffic_scan_filter.json"), "w"), indent=1)
+        json.dump({"kernel": k, "units_per_launch": rows, "bf_bits": bf_bits, "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch_kb,
+                   "write_size_kb": write_kb, "fetch_calibration_factor": factor, "calibration": "FETCH_SIZE of the same kernel with only its %d B/row stream (scan_ablate=3)" % (12 if compact else 16),
+                   "algorithmic_bytes_per_launch": 44.0 * rows}, open(os.path.join(out, "traffic_scan_filter12.json" if compact else "traffic_scan_filter.json"), "w"), indent=1)
