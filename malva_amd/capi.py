@@ -146,6 +146,20 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def host_alloc(n_bytes):
+    """pinned host memory (mg_host_alloc) as a uint8 array; the array must be passed to host_free() when done"""
+    ptr = C.c_void_p()
+    rc = lib().mg_host_alloc(C.byref(ptr), n_bytes)
+    if rc != 0:
+        raise MalvaError(rc, "mg_host_alloc(%d) failed" % n_bytes)
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n_bytes,))
+    return arr, ptr
+
+
+def host_free(ptr):
+    lib().mg_host_free(ptr)
+
+
 def comm_unique_id() -> bytes:
     """ncclGetUniqueId through the library: rank 0 calls it and ships the bytes to the other ranks"""
     buf = C.create_string_buffer(COMM_ID_BYTES)
