@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--b", type=int, default=4, help="filter size in units of 2^33 bits (malva-geno -b)")
     ap.add_argument("--k", type=int, default=35, help="signature k-mer length (malva-geno -k)")
     ap.add_argument("--r", type=int, default=43, help="context k-mer length of the KMC table (malva-geno -r); 63 = config C5's")
+    ap.add_argument("--table", choices=["auto", "host", "device"], default="auto",
+                    help="where the synthetic table is drawn: host = numpy (malva_amd.synth.kmer_table, SURVEY 8(d)), device = random rows drawn on the "
+                         "GPU with the windows around 20 %% / 7.5 of the rows' worth of variant sites planted (minutes -> seconds); auto: device above 2e8 rows")
     ap.add_argument("--layout", choices=["compact", "soa"], default="compact",
                     help="table layout in HBM: compact = 12-byte rows (count << 2r | r-mer; needs 33 <= r <= 44), soa = {hi[], lo[], cnt[]} 20 B/row")
     ap.add_argument("--strong", action="store_true",
@@ -142,7 +145,7 @@ def main():
         ctx.bf_insert(BF_ALT, rows[1::2])   # others   -> bf     (main.cpp:139)
     del sig
     ctx.bf_finalize(BF_ALT)
-    ctx.ref_scan(panel.genome.tobytes())
+    ctx.ref_scan(panel.genome)
     ctx.bf_finalize(BF_CTX)
     _, n_alt, _ = ctx.bf_info(BF_ALT)
     _, n_ctx, _ = ctx.bf_info(BF_CTX)
@@ -154,14 +157,22 @@ def main():
                       allele_off=panel.allele_off[2 * v0:2 * v1 + 1] - panel.allele_off[2 * v0], pool=panel.pool[2 * v0:2 * v1],
                       freq=panel.freq[2 * v0:2 * v1], present_mask=panel.present_mask[v0:v1], flags=panel.flags[v0:v1],
                       donor_gt=panel.donor_gt[v0:v1])
-    hi, lo, cnt = synth.kmer_table(sub, n_rows, K, R, seed=777 + rank)
-    log(rank, "table: %d rows per GPU (%.1fs)" % (n_rows, time.time() - t0))
-
     def dev_i64(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
 
-    d_hi, d_lo = dev_i64(hi), dev_i64(lo)
-    d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+    device_table = args.table == "device" or (args.table == "auto" and n_rows > 200_000_000)
+    if device_table:
+        plant = max(1, min(n_vars, int(n_rows * 0.2 / 7.5)))      # 5 windows x 1.5 haplotypes per planted variant -> 20 % of the rows
+        tb = synth.device_table(sub, n_rows, K, R, 777 + rank, dev, plant_variants=plant)
+        d_hi, d_lo, d_cnt = tb["d_hi"], tb["d_lo"], tb["d_cnt"]
+        ns_cpu = int(min(args.cpu_sample, n_rows))
+        hi, lo, cnt = (d_hi[:ns_cpu].cpu().numpy().view(np.uint64), d_lo[:ns_cpu].cpu().numpy().view(np.uint64),
+                       d_cnt[:ns_cpu].cpu().numpy().view(np.uint32))             # what the CPU leg scans
+    else:
+        hi, lo, cnt = synth.kmer_table(sub, n_rows, K, R, seed=777 + rank)
+        d_hi, d_lo = dev_i64(hi), dev_i64(lo)
+        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+    log(rank, "table: %d rows per GPU, drawn on the %s (%.1fs)" % (n_rows, "device" if device_table else "host", time.time() - t0))
     compact = args.layout == "compact" and 33 <= R <= 44
     d_rows = None
     if compact:                     # the table as it stays resident: packed once, outside the timed region
@@ -322,7 +333,7 @@ def main():
         # tests/test_synth_cpu.py shows the results equal the single-threaded ones) -- after the parity check,
         # because it adds to the same oracle counters
         cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-        ns_all = int(min(n_rows, ns * max(1, cores // 2)))
+        ns_all = int(min(len(hi), ns * max(1, cores // 2)))
         t0 = time.perf_counter()
         ocapi.kmc_scan_packed_mt(octx, obf, omap, hi[:ns_all], lo[:ns_all], cnt[:ns_all], K, R, cores)
         cpu_all_s = time.perf_counter() - t0

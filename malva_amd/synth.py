@@ -281,3 +281,56 @@ def kmer_table(panel: Panel, n_rows, k, ref_k, seed, offsets=(-2, -1, 0, 1, 2), 
     perm = rng.permutation(n_rows)
     cnt = (2 + rng.integers(0, 62, size=n_rows)).astype(np.uint32)
     return hi[perm], lo[perm], cnt
+
+
+def head(panel: Panel, n):
+    """the first n variants of an snp_panel (biallelic, one base per allele) as a Panel of their own"""
+    return Panel(genome=panel.genome, pos=panel.pos[:n], var_allele_off=panel.var_allele_off[:n + 1], allele_off=panel.allele_off[:2 * n + 1],
+                 pool=panel.pool[:2 * n], freq=panel.freq[:2 * n], present_mask=panel.present_mask[:n], flags=panel.flags[:n],
+                 donor_gt=panel.donor_gt[:n])
+
+
+def device_table(panel: Panel, n_rows, k, ref_k, seed, device, plant_variants=None):
+    """kmer_table for tables of 1e8..4e9 rows: the uniform random rows are drawn ON THE GPU (torch: random bits and a
+    scatter; numpy needs minutes per 1e8 rows), the windows around the first `plant_variants` variant sites come from
+    site_rows() and are scattered to distinct random places.  Rows are not canonicalised (the scan does that itself,
+    main.cpp:491-499 via BF/KMAP).  -> dict: d_hi, d_lo (int64 bit patterns), d_cnt (int32), and for the planted rows
+    their place, variant, haplotype, window offset and count (numpy), so a test knows what every counter must hold."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    sub = panel if plant_variants is None else head(panel, plant_variants)
+    hi, lo, var, hap, off = site_rows(sub, k, ref_k)
+    n_site = int(hi.size)
+    if n_site > n_rows:
+        keep = np.random.default_rng(seed).permutation(n_site)[:n_rows]
+        hi, lo, var, hap, off = hi[keep], lo[keep], var[keep], hap[keep], off[keep]
+        n_site = n_rows
+
+    def bits32():
+        return torch.randint(0, 1 << 32, (n_rows,), dtype=torch.int64, device=dev, generator=g)
+    top = 2 * ref_k - 64                                      # bits of the 2-bit string that live in `hi`
+    d_lo = (bits32() << 32) | bits32()                        # 64 random bits as an int64 bit pattern
+    if top >= 64:
+        d_hi = (bits32() << 32) | bits32()
+    elif top > 0:
+        d_hi = ((bits32() << 32) | bits32()) & ((1 << top) - 1)
+    else:
+        d_hi = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+        if top < 0:
+            d_lo = d_lo & ((1 << (2 * ref_k)) - 1)
+    d_cnt = torch.randint(2, 64, (n_rows,), dtype=torch.int32, device=dev, generator=g)
+    # distinct places for the planted rows: one per stride of n_rows / n_site rows, at a random offset inside it
+    stride = n_rows // max(n_site, 1)
+    where = torch.arange(n_site, dtype=torch.int64, device=dev) * stride
+    if stride > 1:
+        where += torch.randint(0, stride, (n_site,), dtype=torch.int64, device=dev, generator=g)
+    if 1 < n_site < (1 << 31):          # site_rows() lists haplotype by haplotype, offset by offset: deal them over the places
+        where = where[torch.randperm(n_site, device=dev, generator=g)]
+    d_hi[where] = torch.from_numpy(hi.view(np.int64)).to(dev)
+    d_lo[where] = torch.from_numpy(lo.view(np.int64)).to(dev)
+    out = {"d_hi": d_hi, "d_lo": d_lo, "d_cnt": d_cnt, "n": n_rows, "n_site": n_site, "site_where": where.cpu().numpy(),
+           "site_cnt": d_cnt[where].cpu().numpy().astype(np.int64), "site_var": var, "site_hap": hap, "site_off": off}
+    torch.cuda.synchronize()
+    return out

@@ -11,31 +11,10 @@ class DeviceTable:
     """SoA k-mer table resident in HBM: d_hi / d_lo (int64 bit patterns of the u64 halves), d_cnt (int32)"""
 
     def __init__(self, panel, n_rows, k, ref_k, seed, plant_variants=None, device=0):
-        dev = torch.device("cuda", device)
-        g = torch.Generator(device=dev)
-        g.manual_seed(seed)
-        sub = panel if plant_variants is None else synth.Panel(
-            genome=panel.genome, pos=panel.pos[:plant_variants], var_allele_off=panel.var_allele_off[:plant_variants + 1],
-            allele_off=panel.allele_off[:2 * plant_variants + 1], pool=panel.pool[:2 * plant_variants], freq=panel.freq[:2 * plant_variants],
-            present_mask=panel.present_mask[:plant_variants], flags=panel.flags[:plant_variants], donor_gt=panel.donor_gt[:plant_variants])
-        hi, lo, var, hap, off = synth.site_rows(sub, k, ref_k)
-        self.n_site = int(hi.size)
-        assert self.n_site <= n_rows
-        self.site_var, self.site_hap, self.site_off = var, hap, off
-        top = 2 * ref_k - 64                                  # bits of the 2-bit string that live in `hi`
-        def bits32():
-            return torch.randint(0, 1 << 32, (n_rows,), dtype=torch.int64, device=dev, generator=g)
-        self.d_lo = (bits32() << 32) | bits32()              # 64 random bits as an int64 bit pattern
-        self.d_hi = torch.randint(0, 1 << top, (n_rows,), dtype=torch.int64, device=dev, generator=g) if top > 0 else torch.zeros(n_rows, dtype=torch.int64, device=dev)
-        self.d_cnt = torch.randint(2, 64, (n_rows,), dtype=torch.int32, device=dev, generator=g)
-        # planted rows at random places (distinct): a random permutation's head
-        where = torch.randperm(n_rows, device=dev, generator=g)[: self.n_site]
-        self.d_hi[where] = torch.from_numpy(hi.view(np.int64)).to(dev)
-        self.d_lo[where] = torch.from_numpy(lo.view(np.int64)).to(dev)
-        self.site_where = where.cpu().numpy()
-        self.site_cnt = self.d_cnt[where].cpu().numpy().astype(np.int64)
-        self.n = n_rows
-        torch.cuda.synchronize()
+        t = synth.device_table(panel, n_rows, k, ref_k, seed, device, plant_variants)
+        self.d_hi, self.d_lo, self.d_cnt, self.n, self.n_site = t["d_hi"], t["d_lo"], t["d_cnt"], t["n"], t["n_site"]
+        self.site_where, self.site_cnt = t["site_where"], t["site_cnt"]
+        self.site_var, self.site_hap, self.site_off = t["site_var"], t["site_hap"], t["site_off"]
 
     def ptrs(self, a=0, b=None):
         b = self.n if b is None else b
