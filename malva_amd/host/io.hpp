@@ -28,17 +28,305 @@
 
 namespace malva {
 
-// gzopen() reads plain files transparently, so one reader serves .vcf/.vcf.gz/.fa/.fa.gz
+// gzopen() reads plain files transparently, so one reader serves .vcf/.vcf.gz/.fa/.fa.gz -- and .bcf: a BCF2 file
+// (BGZF = concatenated gzip members, which gzread walks through; magic "BCF\2\2") is translated record by record into
+// the VCF text lines it encodes, so everything downstream reads one format.  The reference gets BCF through htslib's
+// bcf_open / bcf_read (main.cpp:261-272, 309-314; variant.hpp:66-211), third party and absent here: the binary layout is
+// restated from the published VCF/BCF specification (v4.3, section 6), "parity unpinned" -- tests/bcf_writer.py is the
+// independent second reading the tests use.
 class LineReader {
     gzFile f = nullptr;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
+    // ---- BCF ----
+    bool bcf = false;
+    std::vector<std::string> bcf_header; // header text, line by line, handed out first
+    size_t bcf_hdr_at = 0;
+    std::vector<std::string> dict, contigs; // string dictionary (FILTER / INFO / FORMAT ids) and contig names
+    std::vector<char> rec;
+
+    bool fill()
+    {
+        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) return false;
+        pos = 0;
+        end = (size_t)n;
+        return true;
+    }
+    bool raw(void *dst, size_t n) // n bytes of the (inflated) stream; false at a clean end of file before the first byte
+    {
+        char *d = (char *)dst;
+        size_t got = 0;
+        while (got < n) {
+            if (pos == end && !fill()) {
+                if (got == 0) return false;
+                throw std::runtime_error("BCF: truncated file");
+            }
+            const size_t t = std::min(n - got, end - pos);
+            memcpy(d + got, buf.data() + pos, t);
+            pos += t;
+            got += t;
+        }
+        return true;
+    }
+    static std::string attr(const std::string &line, const char *key) // value of key= inside <...>, unquoted
+    {
+        const std::string k = std::string(key) + "=";
+        size_t at = line.find("<");
+        while (at != std::string::npos) {
+            at = line.find(k, at);
+            if (at == std::string::npos) break;
+            if (line[at - 1] == '<' || line[at - 1] == ',') {
+                size_t b = at + k.size(), e = b;
+                if (b < line.size() && line[b] == '"') {
+                    e = line.find('"', ++b);
+                } else
+                    while (e < line.size() && line[e] != ',' && line[e] != '>') ++e;
+                return line.substr(b, e == std::string::npos ? std::string::npos : e - b);
+            }
+            ++at;
+        }
+        return std::string();
+    }
+    void bcf_open()
+    {
+        uint32_t l_text;
+        if (!raw(&l_text, 4)) throw std::runtime_error("BCF: no header");
+        std::string text(l_text, '\0');
+        raw(&text[0], l_text);
+        while (!text.empty() && text.back() == '\0') text.pop_back();
+        size_t a = 0;
+        while (a < text.size()) {
+            size_t b = text.find('\n', a);
+            if (b == std::string::npos) b = text.size();
+            if (b > a) bcf_header.push_back(text.substr(a, b - a));
+            a = b + 1;
+        }
+        // dictionaries (VCF 4.3 section 6.2.1): PASS is entry 0 unless declared elsewhere; ids in order of first
+        // appearance over FILTER / INFO / FORMAT lines, an explicit IDX= wins; contigs likewise from ##contig lines
+        auto put = [](std::vector<std::string> &d, const std::string &id, const std::string &idx, size_t next) {
+            const size_t at = idx.empty() ? next : (size_t)strtoul(idx.c_str(), nullptr, 10);
+            if (d.size() <= at) d.resize(at + 1);
+            d[at] = id;
+        };
+        dict.push_back("PASS");
+        size_t next_contig = 0;
+        for (const std::string &line : bcf_header) {
+            const bool sd = line.rfind("##INFO=", 0) == 0 || line.rfind("##FORMAT=", 0) == 0 || line.rfind("##FILTER=", 0) == 0;
+            if (sd) {
+                const std::string id = attr(line, "ID"), idx = attr(line, "IDX");
+                if (std::find(dict.begin(), dict.end(), id) != dict.end() && idx.empty()) continue;
+                if (id == "PASS" && idx.empty()) continue;
+                put(dict, id, idx, dict.size());
+            } else if (line.rfind("##contig=", 0) == 0) {
+                const std::string idx = attr(line, "IDX");
+                put(contigs, attr(line, "ID"), idx, next_contig);
+                next_contig = contigs.size();
+            }
+        }
+    }
+    // one typed value descriptor: type in the low nibble, count in the high one (15 = a typed integer follows)
+    struct Cur {
+        const unsigned char *p, *e;
+        void need(size_t n) const
+        {
+            if ((size_t)(e - p) < n) throw std::runtime_error("BCF: record overruns its length");
+        }
+        uint32_t u8() { need(1); return *p++; }
+        int32_t i_of(int type)
+        {
+            if (type == 1) { need(1); const int8_t v = (int8_t)*p; p += 1; return v; }
+            if (type == 2) { need(2); int16_t v; memcpy(&v, p, 2); p += 2; return v; }
+            if (type == 3) { need(4); int32_t v; memcpy(&v, p, 4); p += 4; return v; }
+            throw std::runtime_error("BCF: integer expected");
+        }
+        void desc(int &type, uint32_t &n)
+        {
+            const uint32_t d = u8();
+            type = (int)(d & 15);
+            n = d >> 4;
+            if (n == 15) {
+                int t2;
+                uint32_t one;
+                desc(t2, one);
+                n = (uint32_t)i_of(t2);
+            }
+        }
+        int32_t typed_int()
+        {
+            int t;
+            uint32_t n;
+            desc(t, n);
+            if (n != 1) throw std::runtime_error("BCF: scalar expected");
+            return i_of(t);
+        }
+        std::string typed_str()
+        {
+            int t;
+            uint32_t n;
+            desc(t, n);
+            if (n && t != 7) throw std::runtime_error("BCF: string expected");
+            need(n);
+            std::string s((const char *)p, n);
+            p += n;
+            return s;
+        }
+    };
+    static bool int_missing(int type, int32_t v) { return type == 1 ? v == -128 : type == 2 ? v == -32768 : v == INT32_MIN; }
+    static bool int_eov(int type, int32_t v) { return type == 1 ? v == -127 : type == 2 ? v == -32767 : v == INT32_MIN + 1; }
+    static void put_float(std::string &out, uint32_t bits)
+    {
+        if (bits == 0x7F800001u) { out += '.'; return; }
+        float v;
+        memcpy(&v, &bits, 4);
+        char b[40];
+        snprintf(b, sizeof b, "%.9g", (double)v);
+        out += b;
+    }
+    // values of one vector (INFO value, or one sample's FORMAT value) as VCF text
+    void put_vector(std::string &out, Cur &c, int type, uint32_t n)
+    {
+        if (type == 7) {
+            c.need(n);
+            size_t len = n;
+            while (len && c.p[len - 1] == 0) --len;
+            out.append((const char *)c.p, len);
+            if (len == 0) out += '.';
+            c.p += n;
+            return;
+        }
+        bool first = true;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (type == 5) {
+                c.need(4);
+                uint32_t bits;
+                memcpy(&bits, c.p, 4);
+                c.p += 4;
+                if (bits == 0x7F800002u) continue; // end of vector
+                if (!first) out += ',';
+                put_float(out, bits);
+            } else {
+                const int32_t v = c.i_of(type);
+                if (int_eov(type, v)) continue;
+                if (!first) out += ',';
+                if (int_missing(type, v)) out += '.';
+                else out += std::to_string(v);
+            }
+            first = false;
+        }
+        if (first) out += '.';
+    }
+    bool bcf_next(std::string &line)
+    {
+        uint32_t len[2];
+        if (!raw(len, 8)) return false;
+        rec.resize((size_t)len[0] + len[1]);
+        if (!rec.empty() && !raw(rec.data(), rec.size())) throw std::runtime_error("BCF: truncated record");
+        Cur c{(const unsigned char *)rec.data(), (const unsigned char *)rec.data() + len[0]};
+        c.need(24);
+        int32_t chrom, p0, rlen;
+        uint32_t qual_bits, nai, nfs;
+        memcpy(&chrom, c.p, 4); memcpy(&p0, c.p + 4, 4); memcpy(&rlen, c.p + 8, 4); memcpy(&qual_bits, c.p + 12, 4);
+        memcpy(&nai, c.p + 16, 4); memcpy(&nfs, c.p + 20, 4);
+        c.p += 24;
+        const uint32_t n_allele = nai >> 16, n_info = nai & 0xFFFF, n_fmt = nfs >> 24, n_sample = nfs & 0xFFFFFF;
+        if (chrom < 0 || (size_t)chrom >= contigs.size()) throw std::runtime_error("BCF: contig index outside the header's ##contig lines");
+        line = contigs[(size_t)chrom];
+        line += '\t';
+        line += std::to_string((long)p0 + 1);
+        line += '\t';
+        const std::string id = c.typed_str();
+        line += id.empty() ? "." : id;
+        for (uint32_t a = 0; a < n_allele; ++a) {
+            line += a < 2 ? '\t' : ',';
+            line += c.typed_str();
+        }
+        if (n_allele < 2) line += "\t.";
+        line += '\t';
+        put_float(line, qual_bits);
+        line += '\t';
+        {
+            int t;
+            uint32_t n;
+            c.desc(t, n);
+            if (n == 0) line += '.';
+            for (uint32_t i = 0; i < n; ++i) {
+                const int32_t v = c.i_of(t);
+                if (i) line += ';';
+                line += (size_t)v < dict.size() ? dict[(size_t)v] : ".";
+            }
+        }
+        line += '\t';
+        if (n_info == 0) line += '.';
+        for (uint32_t i = 0; i < n_info; ++i) {
+            const int32_t key = c.typed_int();
+            if (i) line += ';';
+            line += (size_t)key < dict.size() ? dict[(size_t)key] : ".";
+            int t;
+            uint32_t n;
+            c.desc(t, n);
+            if (n == 0 || t == 0) continue; // a flag
+            line += '=';
+            put_vector(line, c, t, n);
+        }
+        if (n_fmt == 0 || n_sample == 0) return true;
+        // individual block: per FORMAT field a key, one descriptor, then n_sample vectors
+        Cur d{(const unsigned char *)rec.data() + len[0], (const unsigned char *)rec.data() + rec.size()};
+        struct Fmt {
+            int key, type;
+            uint32_t n;
+            const unsigned char *data;
+        };
+        std::vector<Fmt> fmts;
+        line += '\t';
+        for (uint32_t i = 0; i < n_fmt; ++i) {
+            Fmt fm;
+            fm.key = d.typed_int();
+            d.desc(fm.type, fm.n);
+            const size_t w = fm.type == 1 || fm.type == 7 ? 1 : fm.type == 2 ? 2 : 4;
+            fm.data = d.p;
+            d.need((size_t)n_sample * fm.n * w);
+            d.p += (size_t)n_sample * fm.n * w;
+            if (i) line += ':';
+            line += (size_t)fm.key < dict.size() ? dict[(size_t)fm.key] : ".";
+            fmts.push_back(fm);
+        }
+        for (uint32_t s_ = 0; s_ < n_sample; ++s_) {
+            line += '\t';
+            for (size_t i = 0; i < fmts.size(); ++i) {
+                const Fmt &fm = fmts[i];
+                const size_t w = fm.type == 1 || fm.type == 7 ? 1 : fm.type == 2 ? 2 : 4;
+                Cur v{fm.data + (size_t)s_ * fm.n * w, fm.data + (size_t)(s_ + 1) * fm.n * w};
+                if (i) line += ':';
+                if ((size_t)fm.key < dict.size() && dict[(size_t)fm.key] == "GT") { // (allele + 1) << 1 | phased; 0 = missing
+                    bool any = false;
+                    for (uint32_t q = 0; q < fm.n; ++q) {
+                        const int32_t g = v.i_of(fm.type);
+                        if (int_eov(fm.type, g)) break;
+                        if (q) line += (g & 1) ? '|' : '/';
+                        if ((g >> 1) == 0) line += '.';
+                        else line += std::to_string((g >> 1) - 1);
+                        any = true;
+                    }
+                    if (!any) line += '.';
+                } else
+                    put_vector(line, v, fm.type, fm.n);
+            }
+        }
+        return true;
+    }
 
   public:
     explicit LineReader(const std::string &path) : buf(1 << 20)
     {
         f = gzopen(path.c_str(), "rb");
-        if (f) gzbuffer(f, 1 << 20);
+        if (!f) return;
+        gzbuffer(f, 1 << 20);
+        if (fill() && end >= 5 && memcmp(buf.data(), "BCF\2\2", 5) == 0) {
+            bcf = true;
+            pos = 5;
+            bcf_open();
+        }
     }
     ~LineReader()
     {
@@ -50,16 +338,20 @@ class LineReader {
     // next line without its terminator ('\n' or "\r\n"); false at end of file
     bool next(std::string &line)
     {
+        if (bcf) {
+            if (bcf_hdr_at < bcf_header.size()) {
+                line = bcf_header[bcf_hdr_at++];
+                return true;
+            }
+            return bcf_next(line);
+        }
         line.clear();
         for (;;) {
             if (pos == end) {
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n <= 0) {
+                if (!fill()) {
                     if (line.empty()) return false;
                     break;
                 }
-                pos = 0;
-                end = (size_t)n;
             }
             const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
             if (nl) {

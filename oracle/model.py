@@ -369,48 +369,51 @@ class VB:
 
     def extract_kmers(self, reference: str, haploid: bool) -> VK_GROUP:
         """var_block.hpp:95-219"""
+        return {vi: self.extract_one(vi, reference, haploid) for vi in range(len(self.variants))}
+
+    def extract_one(self, vi: int, reference: str, haploid: bool) -> Dict[int, List[List[str]]]:
+        """the body of extract_kmers' loop over the block's variants (var_block.hpp:100-216): the signatures of variant vi.
+        Variants are enumerated independently of one another, which is what lets tools/gen_c1_golden.py spread a block of
+        thousands of variants x tens of thousands of samples over processes without touching the restated logic."""
         k = self.k
-        kmers: VK_GROUP = {}
-        for vi, v in enumerate(self.variants):
-            per_allele: Dict[int, List[List[str]]] = {}
-            if (not v.is_present) or v.ref_pos < k or v.ref_pos > len(reference) - k:
-                kmers[vi] = per_allele
-                continue
-            combs = self.combine(self._chains(vi, -1), self._chains(vi, +1), vi)
-            for comb in combs:
-                rsubs = self.ref_subs(comb, reference)
-                for aac in self.allele_combs(comb, vi, haploid):
-                    sig: List[str] = []
-                    if len(aac) == 1 and len(aac[0]) >= k:
-                        mid_allele = aac[0]
-                        sig = [mid_allele[p:p + k] for p in range(len(mid_allele) - k + 1)]
+        v = self.variants[vi]
+        per_allele: Dict[int, List[List[str]]] = {}
+        if (not v.is_present) or v.ref_pos < k or v.ref_pos > len(reference) - k:
+            return per_allele
+        combs = self.combine(self._chains(vi, -1), self._chains(vi, +1), vi)
+        for comb in combs:
+            rsubs = self.ref_subs(comb, reference)
+            for aac in self.allele_combs(comb, vi, haploid):
+                sig: List[str] = []
+                if len(aac) == 1 and len(aac[0]) >= k:
+                    mid_allele = aac[0]
+                    sig = [mid_allele[p:p + k] for p in range(len(mid_allele) - k + 1)]
+                else:
+                    kmer, mid_pos, mid_allele = "", 0, ""
+                    for j, allele in enumerate(aac):
+                        if comb[j] == vi:
+                            mid_pos, mid_allele = len(kmer), allele
+                        kmer += allele + (rsubs[j] if j < len(rsubs) else "")
+                    first_part = mid_pos + len(mid_allele) // 2
+                    second_part = len(kmer) - first_part
+                    missing_prefix = k // 2 - first_part
+                    missing_suffix = math.ceil(k / 2) - second_part
+                    if missing_prefix >= 0:
+                        fv = self.variants[comb[0]]
+                        kmer = substr(reference, fv.ref_pos - missing_prefix, missing_prefix) + kmer
                     else:
-                        kmer, mid_pos, mid_allele = "", 0, ""
-                        for j, allele in enumerate(aac):
-                            if comb[j] == vi:
-                                mid_pos, mid_allele = len(kmer), allele
-                            kmer += allele + (rsubs[j] if j < len(rsubs) else "")
-                        first_part = mid_pos + len(mid_allele) // 2
-                        second_part = len(kmer) - first_part
-                        missing_prefix = k // 2 - first_part
-                        missing_suffix = math.ceil(k / 2) - second_part
-                        if missing_prefix >= 0:
-                            fv = self.variants[comb[0]]
-                            kmer = substr(reference, fv.ref_pos - missing_prefix, missing_prefix) + kmer
-                        else:
-                            kmer = kmer[-missing_prefix:]
-                        if missing_suffix >= 0:
-                            lv = self.variants[comb[-1]]
-                            kmer += substr(reference, lv.ref_pos + lv.ref_size, missing_suffix)
-                        else:
-                            if -missing_suffix > len(kmer):
-                                raise IndexError("std::out_of_range in erase")
-                            kmer = kmer[:len(kmer) + missing_suffix]
-                        sig = [kmer]
-                    ai = v.get_allele_index(mid_allele)
-                    per_allele.setdefault(ai, []).append(sig)
-                kmers[vi] = per_allele
-        return kmers
+                        kmer = kmer[-missing_prefix:]
+                    if missing_suffix >= 0:
+                        lv = self.variants[comb[-1]]
+                        kmer += substr(reference, lv.ref_pos + lv.ref_size, missing_suffix)
+                    else:
+                        if -missing_suffix > len(kmer):
+                            raise IndexError("std::out_of_range in erase")
+                        kmer = kmer[:len(kmer) + missing_suffix]
+                    sig = [kmer]
+                ai = v.get_allele_index(mid_allele)
+                per_allele.setdefault(ai, []).append(sig)
+        return per_allele
 
 
 def flatten_vk(kmers: VK_GROUP, var_n_alleles: List[int]):

@@ -1,0 +1,52 @@
+"""BCF input: malva_amd/host/io.hpp translates BCF2 records into the VCF lines they encode, so the panel
+decoder sees one format.  Host code only (`malva-geno dump-kmers` prints every block's variants and signature k-mers):
+the same panel as text and as BCF (written by tests/bcf_writer.py, an independent reading of the published layout --
+parity unpinned, no htslib here) must enumerate identically."""
+import os
+import subprocess
+
+import pytest
+
+import bcf_writer
+import vcf_synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin", "malva-geno")
+
+
+def _dump(args):
+    r = subprocess.run([BIN, "dump-kmers"] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("with_idx", [False, True])
+def test_haploid_example_as_bcf(tmp_path, golden_dir, with_idx):
+    fa, vcf = os.path.join(golden_dir, "haploid.fa"), os.path.join(golden_dir, "haploid.vcf.gz")
+    bcf = str(tmp_path / "haploid.bcf")
+    bcf_writer.vcf_to_bcf(vcf, bcf, with_idx=with_idx)
+    assert open(bcf, "rb").read(4) == b"\x1f\x8b\x08\x04"                      # BGZF
+    for mode in ("index", "call"):
+        want = _dump(["-1", "-k", "35", "-f", "AF", fa, vcf, mode])
+        assert _dump(["-1", "-k", "35", "-f", "AF", fa, bcf, mode]) == want and want.count("VAR ") > 400
+
+
+@pytest.mark.parametrize("seed,haploid", [(3, False), (4, True)])
+def test_clustered_multiallelic_panel_as_bcf(tmp_path, seed, haploid):
+    """phased and unphased genotypes, missing alleles, multi-allelic records, indels, several contigs"""
+    prefix = str(tmp_path / "case")
+    vcf_synth.make_case(prefix, seed, haploid=haploid, k=35, n_clusters=120, vcf_strip_chr=True)
+    bcf = prefix + ".bcf"
+    bcf_writer.vcf_to_bcf(prefix + ".vcf", bcf, with_idx=bool(seed & 1))
+    args = ["-k", "35", "-p"] + (["-1"] if haploid else [])
+    want = _dump(args + [prefix + ".fa", prefix + ".vcf", "call"])
+    assert _dump(args + [prefix + ".fa", bcf, "call"]) == want and want.count("SIG ") > 500
+
+
+def test_truncated_bcf_is_an_error(tmp_path, golden_dir):
+    bcf = str(tmp_path / "t.bcf")
+    bcf_writer.vcf_to_bcf(os.path.join(golden_dir, "haploid.vcf.gz"), bcf)
+    data = open(bcf, "rb").read()
+    open(bcf, "wb").write(data[:len(data) * 2 // 3])
+    r = subprocess.run([BIN, "dump-kmers", "-1", os.path.join(golden_dir, "haploid.fa"), bcf, "call"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

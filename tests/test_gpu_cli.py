@@ -202,3 +202,24 @@ def test_index_file_is_the_references_container_and_interchanges_with_the_oracle
     index_file.write_index(zst, idx.context_bf, idx.bf, idx.ref_bf)
     assert run_cli(["call"] + args) == from_own
     assert sum(1 for l in from_own.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
+
+
+def test_bcf_panel_gives_the_same_records_as_the_vcf(tmp_path, golden_dir):
+    """a .bcf panel (what htslib's bcf_open reads for the reference, main.cpp:261-272) through index + call:
+    the records equal those of the text panel byte for byte (the header differs by what a BCF must declare: contigs, PASS)"""
+    import bcf_writer
+    fa = os.path.join(golden_dir, "haploid.fa")
+    vcf = str(tmp_path / "haploid.vcf.gz")
+    shutil.copy(os.path.join(golden_dir, "haploid.vcf.gz"), vcf)
+    bcf = str(tmp_path / "haploid.bcf")
+    bcf_writer.vcf_to_bcf(vcf, bcf, with_idx=True)
+    prefix = str(tmp_path / "haploid_malva43.kmercount")
+    with open(prefix + ".txt", "w") as fh:
+        for km, c in kmc_standin.count_fastq(os.path.join(golden_dir, "haploid.fq"), 43):
+            fh.write("%s\t%d\n" % (km.decode(), c))
+    opts = ["-1", "-k", "35", "-r", "43", "-b", "1", "-f", "AF", fa]
+    run_cli(["index"] + opts + [bcf, prefix])
+    out = run_cli(["call"] + opts + [bcf, prefix])
+    recs = lambda s: [l for l in s.split("\n") if l and not l.startswith("##")]
+    want = open(os.path.join(golden_dir, "haploid.malva.vcf")).read()        # the reference's own golden
+    assert recs(out) == recs(want) and len(recs(out)) == 419

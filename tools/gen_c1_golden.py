@@ -11,11 +11,43 @@ import os
 import sys
 import time
 
+import multiprocessing as mp
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import kmc_standin, pipeline  # noqa: E402
+from oracle import kmc_standin, model, pipeline  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
+
+# The panel's three giant blocks (up to 8,724 variants x 27,934 samples) take the pure-Python model hours on one core.
+# VB.extract_kmers enumerates a block's variants independently of one another (oracle/model.py: extract_one), so a large
+# block is spread over forked worker processes here -- the restated logic runs unchanged, one variant at a time.
+_JOB = {}
+
+
+def _work(vis):
+    vb, reference, haploid = _JOB["vb"], _JOB["reference"], _JOB["haploid"]
+    return [(vi, vb.extract_one(vi, reference, haploid)) for vi in vis]
+
+
+def _parallel_extract(self, reference, haploid):
+    n = len(self.variants)
+    workers = max(1, min(int(os.environ.get("GEN_WORKERS", "7")), n // 32))
+    if workers == 1:
+        return {vi: self.extract_one(vi, reference, haploid) for vi in range(n)}
+    _JOB.update(vb=self, reference=reference, haploid=haploid)
+    chunks = [list(range(i, n, workers * 4)) for i in range(workers * 4)]        # interleaved: chain counts vary along a block
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_work, chunks)
+    out = {}
+    for part in parts:
+        out.update(part)
+    print("  block of %d variants enumerated by %d processes (%.0f s since start)" % (n, workers, time.time() - T0), file=sys.stderr, flush=True)
+    return {vi: out[vi] for vi in range(n)}
+
+
+T0 = time.time()
+model.VB.extract_kmers = _parallel_extract
 
 
 def main(verbose):
