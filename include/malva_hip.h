@@ -210,6 +210,20 @@ int mg_cover_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, 
                     const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
                     const uint16_t *gt, uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out);
 
+/* The same enumeration at INDEX time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for blocks of any
+ * shape -- every signature k-mer of allele 0 is added to the exact map (KMAP::add_key), every other one sets its bit of
+ * `bf` (BF::add_key).  Arguments as mg_cover_blocks (the panel genotypes decide which alleles have signatures); the
+ * blocks hold only the variants `index` keeps (has_alts and is_present, main.cpp:332).  overflow_out[v] = 1: nothing of
+ * that variant was inserted (a device capacity, a window clipped by a contig end, or a REF k-mer the packed table cannot
+ * hold) -- enumerate its block on the host and insert with mg_map_insert / mg_bf_insert.  Before mg_bf_finalize.
+ * Counter ids of keys inserted here follow the order the device reached them in; ranks of a multi-GPU call agree on
+ * the layout by loading the same index file. */
+int mg_index_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                    const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                    const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                    const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                    const uint16_t *gt, uint32_t n_samples, int haploid, uint8_t *overflow_out);
+
 /* Result codes of mg_genotype / mg_call_isolated per variant */
 #define MG_GT_NORMAL 0   /* likelihood list computed                              */
 #define MG_GT_OVERCOV 1  /* some allele > max_cov: (best_geno,0) per such allele  */

@@ -1731,22 +1731,18 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
     return MG_OK;
 }
 
-MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
-                              const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
-                              const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
-                              const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
-                              uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
+namespace {
+// the flat description of a batch of blocks on the device (shared by the call-time and the index-time enumerator)
+int prepare_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                   const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                   const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples, int haploid,
+                   BlockBatch *out)
 {
-    const DeviceGuard on_device(c);
-    if (!c) return MG_ERR_ARG;
-    if (n_vars == 0) return MG_OK;
-    if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off ||
-        !pool || !canon || (n_samples && !gt) || !cov_out || !overflow_out)
+    if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off || !pool || !canon ||
+        (n_samples && !gt))
         return fail(c, MG_ERR_ARG, "NULL argument");
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
-    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     if (blk_var_off[n_blocks] != n_vars) return fail(c, MG_ERR_ARG, "block offsets do not close");
-    if (!c->map.slots) TRY(map_reserve(c, 0));
     const size_t na = var_allele_off[n_vars];
     if (allele_off[na] > pool_len) return fail(c, MG_ERR_ARG, "allele offsets exceed the pool");
     std::vector<u32> var_block(n_vars);
@@ -1780,9 +1776,6 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     void *d_sorted, *d_gain;
     TRY(upload(c, c->s_bin[0], blk_sorted.data(), n_blocks, &d_sorted));
     TRY(upload(c, c->s_bin[1], blk_max_gain.data(), 4 * n_blocks, &d_gain));
-    void *d_cov, *d_ovf;
-    TRY(scratch(c, c->s_out, 4 * na, &d_cov));
-    TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
     B.reference = c->d_ref;
     B.blk_ref_base = (const u64 *)d[0]; B.blk_ref_len = (const u32 *)d[1]; B.blk_var_off = (const u32 *)d[2];
     B.var_block = (const u32 *)d[3]; B.pos = (const i32 *)d[4]; B.ref_size = (const u32 *)d[5]; B.min_size = (const u32 *)d[6];
@@ -1791,12 +1784,77 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     B.blk_sorted = (const u8 *)d_sorted; B.blk_max_gain = (const u32 *)d_gain;
     B.n_samples = n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
-    hipLaunchKernelGGL(cover_blocks_kernel, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
-                       (u32 *)d_cov, (u8 *)d_ovf);
+    *out = B;
+    return MG_OK;
+}
+} // namespace
+
+MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                              const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                              const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                              const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
+                              uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!cov_out || !overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (!c->map.slots) TRY(map_reserve(c, 0));
+    BlockBatch B{};
+    TRY(prepare_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool,
+                       pool_len, canon, gt, n_samples, haploid, &B));
+    const size_t na = var_allele_off[n_vars];
+    void *d_cov, *d_ovf;
+    TRY(scratch(c, c->s_out, 4 * na, &d_cov));
+    TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
+    hipLaunchKernelGGL(cover_blocks_kernel<0>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
+                       (u32 *)d_cov, (u8 *)d_ovf, IndexEmit{nullptr, nullptr, 0u});
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * na, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+
+// index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for a batch of blocks, on the device
+MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                              const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                              const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                              const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
+                              uint32_t n_samples, int haploid, uint8_t *overflow_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_index_blocks after mg_bf_finalize");
+    if (!c->map.slots) TRY(map_reserve(c, 0));
+    BlockBatch B{};
+    TRY(prepare_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool,
+                       pool_len, canon, gt, n_samples, haploid, &B));
+    void *d_ovf;
+    TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
+    unsigned long long *d_cursor = c->d_hit_count; // a free word outside any scan
+    // pass 1: how many exact-map insertion rows the batch needs, and which variants exceed a device capacity
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
+    hipLaunchKernelGGL(cover_blocks_kernel<1>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c), (u32 *)nullptr,
+                       (u8 *)d_ovf, IndexEmit{nullptr, d_cursor, 0u});
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long rows = 0;
+    HIP_TRY(c, hipMemcpyAsync(&rows, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(map_reserve(c, rows)); // may grow and re-hash the table: between the passes, never under a kernel
+    // pass 2: insert.  Every REF k-mer takes the next insertion row of the batch (ids are then whatever order the
+    // device reached them in: the index FILE, which every GPU of a call loads alike, is what fixes the counter layout)
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
+    c->gate_dirty = true;
+    hipLaunchKernelGGL(cover_blocks_kernel<2>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c), (u32 *)nullptr,
+                       (u8 *)d_ovf, IndexEmit{nullptr, d_cursor, (u32)c->map.rows_total});
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->map.rows_total += rows;
     return MG_OK;
 }
 

@@ -80,29 +80,17 @@ __global__ void __launch_bounds__(TPB) rows_kernel(const u8 *rows, size_t stride
     if (OP == OP_WEIGHT) ((i32 *)out)[i] = bf.counts ? (i32)(uint16_t)bf_count_at(bf, idx) : 0;
 }
 
-// KMAP::add_key (kmap.hpp:108-112) for regular keys.  row0 = number of rows
-// inserted by earlier calls (ids are global insertion rows).
-__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, BFView bf,
-                                                         u32 row0, u8 *irregular)
+// KMAP::add_key (kmap.hpp:108-112) for one regular key (canonical L-form, its XXH3): my_id = this insertion's row
+// number, row0 = first row number of the current batch (a key met again from an EARLIER batch has its value reset,
+// `kmers[ckmer] = 0`).  Callable from any kernel: a lane that finds a slot "being written" waits for the owner, which is
+// always a lane inside this same loop (it won the CAS in this iteration and publishes before the iteration ends).
+__device__ __forceinline__ void map_insert_key(const MapView &map, const BFView &bf, U128 key, u64 h, u32 my_id, u32 row0)
 {
-    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const u8 *row = rows + i * stride;
-    const int k = row_len(row, (int)stride);
-    CanonBytes<RowIn> can(RowIn{row}, k);
-    U128 key;
-    const bool regular = pack_regular(can, k, (int)map.klen, &key);
-    irregular[i] = regular ? 0 : 1;
-    if (!regular) return;
-    const u64 h = xxh3_bytes(can, k);
     gate_set(bf, mod_size(h, bf.mod));
     const u32 tag = map_tag(h);
     const u64 mask = (1ULL << map.cap_log2) - 1;
     u64 s = map_home(map, mod_size(h, bf.mod));
-    const u32 my_id = row0 + (u32)i;
     bool done = false;
-    // every lane retries inside one common loop, so a lane that owns a slot in
-    // the "being written" state always finishes its publish before anyone spins on it
     for (int guard = 0; !done && guard < (1 << 30); ++guard) {
         u32 t = __hip_atomic_load(&map.slots[s].tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == 0) {
@@ -131,6 +119,23 @@ __global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t 
         }
         s = (s + 1) & mask;
     }
+}
+
+// KMAP::add_key for a batch of ASCII rows.  row0 = number of rows
+// inserted by earlier calls (ids are global insertion rows).
+__global__ void __launch_bounds__(TPB) map_insert_kernel(const u8 *rows, size_t stride, size_t n, MapView map, BFView bf,
+                                                         u32 row0, u8 *irregular)
+{
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const u8 *row = rows + i * stride;
+    const int k = row_len(row, (int)stride);
+    CanonBytes<RowIn> can(RowIn{row}, k);
+    U128 key;
+    const bool regular = pack_regular(can, k, (int)map.klen, &key);
+    irregular[i] = regular ? 0 : 1;
+    if (!regular) return;
+    map_insert_key(map, bf, key, xxh3_bytes(can, k), row0 + (u32)i, row0);
 }
 
 __global__ void __launch_bounds__(TPB) map_clear_kernel(MapSlot *slots, u64 cap)

@@ -376,7 +376,55 @@ __device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, co
     return weight_bytes(LdsBytes{buf}, len, is_ref, bf, map);
 }
 
-__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow)
+// index time (add_kmers_to_bf, main.cpp:122-144): the k-mer in buf[0, len) goes into the exact map (REF allele) or sets
+// its bit of `bf` (any other allele).  MODE 1 only counts the REF k-mers (the host sizes the map before MODE 2 inserts).
+// false: a REF k-mer the packed table cannot hold (a non-ACGT base, or a clipped window: KMAP::canonical's NUL
+// truncation, kmap.hpp:95) -- the variant's block goes to the host enumerator.
+struct IndexEmit {
+    u32 *sh_emit;               // REF k-mers of this variant (MODE 1)
+    unsigned long long *cursor; // insertion rows handed out so far in this batch (MODE 2)
+    u32 row0;
+};
+template <int MODE> __device__ __forceinline__ bool bk_index_emit(const u8 *buf, int len, bool is_ref, const BFView &bf, const MapView &map, const IndexEmit &e)
+{
+    U128 L{0, 0};
+    bool ok = len <= MG_MAX_PACKED_K;
+    if (ok)
+        for (int i = 0; i < len; ++i) {
+            bool o;
+            const u64 code = acgt_code(buf[i], &o);
+            ok &= o;
+            if (i < 32) L.lo |= code << (2 * i);
+            else L.hi |= code << (2 * (i - 32));
+        }
+    U128 key{0, 0};
+    if (ok) {
+        const U128 mk = mask128(2 * len);
+        const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - len));
+        const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+        key = lt128(L, rc) ? L : rc;
+    }
+    if (is_ref) {
+        if (!ok || len != (int)map.klen) return false;
+        if (MODE == 1) {
+            atomicAdd(e.sh_emit, 1u);
+            return true;
+        }
+        const u32 my_id = e.row0 + (u32)atomicAdd(e.cursor, 1ULL);
+        map_insert_key(map, bf, key, xxh3_lform(key, len), my_id, e.row0);
+        return true;
+    }
+    if (MODE == 1) return true;
+    const u64 idx = mod_size(ok ? xxh3_lform(key, len) : xxh3_bytes(CanonBytes<LdsBytes>(LdsBytes{buf}, len), len), bf.mod);
+    atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
+    gate_set(bf, idx);
+    return true;
+}
+
+// MODE 0: call time, coverage of every allele (set_coverages).  MODE 1 / 2: index time, see bk_index_emit; `overflow` then
+// carries MODE 1's verdict into MODE 2 (a variant flagged there is skipped here and left to the host).
+template <int MODE>
+__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit)
 {
     __shared__ BkChains sh_left, sh_right;
     __shared__ int sh_comb[BK_MAXC * BK_MAXC][BK_MAXCOMB];
@@ -387,8 +435,12 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
     __shared__ unsigned long long sh_set[BK_SET_CAP]; // distinct picks of the chain in hand: code + 1, 0 = free
     __shared__ u32 sh_set_n;
+    __shared__ u32 sh_emit;
     const int g = blockIdx.x;
     if ((u64)g >= n_vars) return;
+    if (MODE == 2 && overflow[g]) return; // flagged by the counting pass: the host enumerates this variant's block
+    emit.sh_emit = &sh_emit;
+    if (threadIdx.x == 0) sh_emit = 0;
     const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
     const u32 blk = B.var_block[g];
     const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
@@ -424,7 +476,8 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     __syncthreads();
     if (sh_bad) {
         if (threadIdx.x == 0) overflow[g] = 1;
-        for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
+        if (MODE == 0)
+            for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
         return;
     }
     u8 *buf = sh_buf[threadIdx.x];
@@ -481,8 +534,11 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
                 }
             }
             for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
-            const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
-            if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+            if (MODE == 0) {
+                const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
+                if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
+            } else if (!bk_index_emit<MODE>(buf, k, mid_canon == 0, bf, map, emit))
+                bad = true;
         };
         // The picks of all samples are first reduced to the DISTINCT ones (the reference's unordered_set, var_block.hpp
         // :734-786): a pick is a code of a few bits per member, collected in an LDS hash set by the pass over the
@@ -572,16 +628,22 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
         i32 n = 0;
         for (int p = 0; p + k <= al; ++p) {
             for (int x = 0; x < k; ++x) buf[x] = ap[p + x];
+            if (MODE != 0) {
+                if (!bk_index_emit<MODE>(buf, k, a == 0, bf, map, emit)) sh_bad = 1;
+                continue;
+            }
             const i32 w = bk_weight(buf, k, a == 0, bf, map);
             if (w > 0) {
                 curr = (curr * (u32)n + (u32)w) / (u32)(n + 1);
                 ++n;
             }
         }
-        atomicMax(&sh_cov[a], curr);
+        if (MODE == 0) atomicMax(&sh_cov[a], curr);
     }
     __syncthreads();
-    if (threadIdx.x == 0) overflow[g] = sh_bad ? 1 : 0;
-    for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
+    if (MODE != 2 && threadIdx.x == 0) overflow[g] = sh_bad ? 1 : 0;
+    if (MODE == 1 && threadIdx.x == 0 && !sh_bad && sh_emit) atomicAdd(emit.cursor, (unsigned long long)sh_emit); // rows the insert pass will need
+    if (MODE == 0)
+        for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
 }
 

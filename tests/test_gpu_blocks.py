@@ -112,3 +112,58 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
     # variants flagged overflow must be genuinely beyond a device capacity or clipped by a contig end -- never wrong
     print("fallback variants: %d of %d" % (int(ovf.sum()), len(ovf)))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,haploid,k,ref_k,dense", [(61, False, 35, 43, False), (62, True, 35, 43, False), (63, False, 31, 41, False),
+                                                        (64, False, 35, 63, False), (65, False, 35, 43, True), (66, True, 35, 43, True)])
+def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k, dense):
+    """mg_index_blocks: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) on the device.  The blocks `index`
+    keeps (present variants only) go through it; what it hands back (overflow) is enumerated by the oracle's model and
+    inserted through the batch calls, exactly as the CLI does with its host enumerator.  The resulting `bf` bits and
+    exact-map key set must equal the index the oracle pipeline builds -- and most variants must stay on the device."""
+    prefix = str(tmp_path / "case")
+    vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=40 if dense else 150, vcf_strip_chr=True, dense=dense,
+                        n_samples=4 if dense else 5)
+    opt = pipeline.Options(haploid=haploid, k=k, ref_k=ref_k, bf_size=1 << 24, strip_chr=True)
+    fa, vcf = prefix + ".fa", prefix + ".vcf"
+    idx = pipeline.index(fa, vcf, opt)
+    refs = read_fasta(fa, True)
+    names = list(refs)
+    base, off = {}, 0
+    for n in names:
+        base[n] = off; off += len(refs[n])
+    with Context(k, ref_k, opt.bf_size) as ctx:
+        ctx.reference_upload("".join(refs[n] for n in names).encode())
+        blocks = []
+        for vb, reference, used in pipeline._blocks(VCFReader(vcf, "-"), opt, refs, True):       # for_index: main.cpp:332
+            if vb is None:
+                break
+            name = next((n for n in names if refs[n] is reference or refs[n] == reference), names[0])
+            blocks.append((vb, name, reference))
+        args = pack_blocks([(vb, name) for vb, name, _ in blocks], base, {n: len(refs[n]) for n in names})
+        ovf = ctx.index_blocks(**args, haploid=haploid)
+        assert ovf.mean() < (0.7 if dense else 0.1), "too many variants fell back: %.2f" % ovf.mean()
+        # the host side of the contract: blocks holding a flagged variant are enumerated by the model and inserted in batch
+        ref_rows, alt_rows = [], []
+        bo = args["blk_var_off"]
+        for b, (vb, name, reference) in enumerate(blocks):
+            if not ovf[bo[b]:bo[b + 1]].any():
+                continue
+            for per in vb.extract_kmers(reference, haploid).values():
+                for a, sigs in per.items():
+                    for sig in sigs:
+                        (ref_rows if a == 0 else alt_rows).extend(km.encode() for km in sig)
+        if ref_rows:
+            ctx.map_insert(rows_of(ref_rows, 136))
+        if alt_rows:
+            ctx.bf_insert(BF_ALT, rows_of(alt_rows, 136))
+        ctx.bf_finalize(BF_ALT)
+        assert np.array_equal(ctx.bf_export_sparse(BF_ALT)[2], idx.bf.set_positions()) and idx.bf.popcount() > 200
+        keys, vals = ctx.map_export()
+        assert sorted(keys) == sorted(k_ for k_, _ in idx.ref_bf.items()) and len(keys) > 200 and not vals.any()
+        assert ctx.map_size() == len(keys) == len(set(keys))
+        # and the index works: reference scan + finalize, then the scan's counters equal the oracle's
+        for n in dict.fromkeys(name for _, name, _ in blocks):
+            ctx.ref_scan(refs[n].encode())
+        ctx.bf_finalize(BF_CTX)
+        assert np.array_equal(ctx.bf_export_sparse(BF_CTX)[2], idx.context_bf.set_positions())
