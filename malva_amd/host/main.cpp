@@ -331,37 +331,109 @@ int index_main(const Options &o)
         }
     };
     std::vector<std::string> used;
-    // General blocks are enumerated by all host cores, a few thousand at a time, and their k-mers appended in block
-    // order: the insertion order (which decides the exact map's counter ids) stays a function of the input alone.
+    // General blocks are enumerated ON THE DEVICE, a few thousand at a time (mg_index_blocks: chains, distinct haplotype
+    // picks, signature assembly, exact-map insert / filter bit -- extract_kmers + add_kmers_to_bf, main.cpp:349-350);
+    // blocks the device hands back (a capacity exceeded, a window clipped by a contig end, a REF k-mer with a base
+    // outside ACGT) are enumerated by all host cores and inserted through the batch calls.
+    std::map<std::string, uint64_t> contig_base;
+    {
+        std::string all;
+        for (const auto &name : refs.names) {
+            contig_base[name] = all.size();
+            all += refs.seqs.at(name);
+        }
+        dev.check(mg_reference_upload(dev.ctx, all.data(), all.size()), "mg_reference_upload");
+    }
+    const bool host_only = o.k > MG_MAX_PACKED_K || getenv("MALVA_GENO_HOST_ENUM"); // the variable forces the host enumerator (tests)
     std::vector<Block> waiting;
     std::vector<const std::string *> waiting_ref;
+    std::vector<uint64_t> waiting_base;
+    size_t waiting_cells = 0, n_host_blocks = 0, n_general_blocks = 0;
     auto enumerate_waiting = [&]() {
         const size_t nb = waiting.size();
         if (!nb) return;
-        std::vector<std::vector<AlleleSignatures>> sigs(nb);
-        const unsigned n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, nb}));
+        n_general_blocks += nb;
+        std::vector<uint8_t> redo(nb, host_only ? 1 : 0);
+        if (!host_only) {
+            std::vector<uint64_t> blk_base;
+            std::vector<uint32_t> blk_len, blk_var_off{0}, ref_size, min_size, var_allele_off{0}, allele_off{0};
+            std::vector<int32_t> ipos;
+            std::vector<uint8_t> is_present, canon;
+            std::vector<char> pool;
+            bool device_ok = true;
+            for (size_t b = 0; b < nb; ++b) {
+                blk_base.push_back(waiting_base[b]);
+                blk_len.push_back((uint32_t)waiting_ref[b]->size());
+                for (const Variant &v : waiting[b].vars) {
+                    const uint32_t A = (uint32_t)v.n_alleles();
+                    if (A > 127) device_ok = false;
+                    ipos.push_back(v.ref_pos);
+                    ref_size.push_back((uint32_t)v.ref_size);
+                    min_size.push_back((uint32_t)v.min_size);
+                    is_present.push_back(v.is_present);
+                    for (uint32_t a = 0; a < A; ++a) {
+                        const std::string &al = v.allele((int)a);
+                        pool.insert(pool.end(), al.begin(), al.end());
+                        allele_off.push_back((uint32_t)pool.size());
+                        canon.push_back((uint8_t)std::min(255, v.allele_index(al)));
+                    }
+                    var_allele_off.push_back(var_allele_off.back() + A);
+                }
+                blk_var_off.push_back((uint32_t)ipos.size());
+            }
+            const size_t nv = ipos.size();
+            const uint32_t n_samples = (uint32_t)vcf.keep.size();
+            std::vector<uint16_t> gt(nv * n_samples, 0);
+            size_t g = 0;
+            for (const Block &b : waiting)
+                for (const Variant &v : b.vars) {
+                    for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
+                        const auto &p2 = v.genotypes[s_];
+                        if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
+                            throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
+                                                     " (the reference reads out of bounds here)");
+                        gt[g * n_samples + s_] = (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
+                    }
+                    ++g;
+                }
+            std::vector<uint8_t> overflow(nv, 1);
+            if (device_ok)
+                dev.check(mg_index_blocks(dev.ctx, nb, blk_base.data(), blk_len.data(), blk_var_off.data(), nv, ipos.data(), ref_size.data(), min_size.data(),
+                                          is_present.data(), var_allele_off.data(), allele_off.data(), pool.data(), pool.size(), canon.data(), gt.data(),
+                                          n_samples, o.haploid, overflow.data()),
+                          "mg_index_blocks");
+            for (size_t b = 0; b < nb; ++b)
+                for (uint32_t v = blk_var_off[b]; v < blk_var_off[b + 1]; ++v) redo[b] = redo[b] || overflow[v];
+        }
+        std::vector<size_t> todo;
+        for (size_t b = 0; b < nb; ++b)
+            if (redo[b]) todo.push_back(b);
+        n_host_blocks += todo.size();
+        const size_t nt = todo.size();
+        std::vector<std::vector<AlleleSignatures>> sigs(nt);
+        const unsigned n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, std::max<size_t>(nt, 1)}));
         std::vector<std::exception_ptr> errs(n_threads);
         std::vector<size_t> err_at(n_threads, SIZE_MAX);
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_threads; ++t)
-            pool.emplace_back([&, t]() {
-                for (size_t b = t; b < nb; b += n_threads) {
+        std::vector<std::thread> pool_t;
+        for (unsigned t = 0; t < n_threads && nt; ++t)
+            pool_t.emplace_back([&, t]() {
+                for (size_t q = t; q < nt; q += n_threads) {
                     try {
-                        sigs[b] = waiting[b].extract(*waiting_ref[b], o.haploid); // main.cpp:349
+                        sigs[q] = waiting[todo[q]].extract(*waiting_ref[todo[q]], o.haploid); // main.cpp:349
                     } catch (...) {
                         errs[t] = std::current_exception();
-                        err_at[t] = b;
+                        err_at[t] = q;
                         return;
                     }
                 }
             });
-        for (auto &th : pool) th.join();
+        for (auto &th : pool_t) th.join();
         size_t first = SIZE_MAX;
         for (unsigned t = 0; t < n_threads; ++t)
             if (errs[t] && (first == SIZE_MAX || err_at[t] < err_at[first])) first = t;
         if (first != SIZE_MAX) std::rethrow_exception(errs[first]);
-        for (size_t b = 0; b < nb; ++b) {
-            for (const auto &per_allele : sigs[b]) // add_kmers_to_bf, main.cpp:122-144
+        for (size_t q = 0; q < nt; ++q) {
+            for (const auto &per_allele : sigs[q]) // add_kmers_to_bf, main.cpp:122-144
                 for (const auto &as : per_allele)
                     for (const auto &sig : as.second)
                         for (const auto &kmer : sig) (as.first == 0 ? ref_rows : alt_rows).add(kmer);
@@ -369,20 +441,28 @@ int index_main(const Options &o)
         }
         waiting.clear();
         waiting_ref.clear();
+        waiting_base.clear();
+        waiting_cells = 0;
     };
-    const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &, const std::string &reference) {
-        if (vb.is_lone_short()) { // nearly every block of a SNP panel: no containers
+    const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
+        if (vb.is_lone_short()) { // nearly every block of a SNP panel: one k-mer per carried allele, no containers
             vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
             flush(false);
             return;
         }
+        auto cb = contig_base.find(seq_name);
+        waiting_base.push_back(cb == contig_base.end() ? 0 : cb->second);
         waiting_ref.push_back(&reference);
+        for (const Variant &v : vb.vars) waiting_cells += v.genotypes.size();
         waiting.push_back(std::move(vb));
         vb = Block((int)o.k);
-        if (waiting.size() >= 4096) enumerate_waiting();
+        if (waiting.size() >= 4096 || waiting_cells >= (200u << 20)) enumerate_waiting(); // bound the panel genotypes held in memory
     });
     enumerate_waiting();
     flush(true);
+    if (n_general_blocks)
+        std::cerr << "[malva-geno] " << n_general_blocks << " general block(s): " << n_general_blocks - n_host_blocks << " enumerated on the device, " << n_host_blocks
+                  << " on the host" << std::endl;
     pelapsed("Processed " + std::to_string(n) + " variants");
     dev.check(mg_bf_finalize(dev.ctx, MG_BF_ALT), "mg_bf_finalize(bf)"); // main.cpp:378
     pelapsed("BF creation complete");
