@@ -252,9 +252,8 @@ struct BlockBatch {
     int haploid, k;
     u32 set_limit; // distinct picks per chain held in the LDS set (<= BK_SET_CAP / 2; tests shrink it to reach the direct form)
 };
-constexpr int BK_MAXC = 8;   // chains per side
-constexpr int BK_MAXL = 12;  // members per chain
-constexpr int BK_MAXCOMB = 2 * BK_MAXL + 1;
+constexpr int BK_MAXC = 16;  // chains per side
+constexpr int BK_MAXL = 32;  // members per chain side (a combined chain: left + the variant + right <= 65 members)
 constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
 constexpr int BK_CODE_BITS = 63; // a chain's pick as a code: bits per member = ceil(log2(alleles))
 constexpr int BK_SET_CAP = 2048; // distinct picks of one chain held in the LDS set (16 KB); more: every pick evaluated directly
@@ -427,9 +426,7 @@ template <int MODE>
 __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit)
 {
     __shared__ BkChains sh_left, sh_right;
-    __shared__ int sh_comb[BK_MAXC * BK_MAXC][BK_MAXCOMB];
-    __shared__ int sh_comb_len[BK_MAXC * BK_MAXC], sh_comb_mid[BK_MAXC * BK_MAXC];
-    __shared__ int sh_ncomb, sh_bad;
+    __shared__ int sh_bad, sh_eligible;
     __shared__ u32 sh_cov[128];
     __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
     __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
@@ -450,29 +447,14 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     for (u32 a = threadIdx.x; a < 128; a += TPB) sh_cov[a] = 0;
     if (threadIdx.x < 4) sh_slide[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-        sh_bad = 0;
-        sh_ncomb = 0;
-        const bool eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
-        if (A > 127 || k > MG_MAX_PACKED_K) sh_bad = 1;
-        else if (eligible) {
-            if (!bk_chains(B, b0, b1, g, -1, &sh_left) || !bk_chains(B, b0, b1, g, +1, &sh_right)) sh_bad = 1;
-            else { // combine_combs
-                const int nl = sh_left.n ? sh_left.n : 1, nrr = sh_right.n ? sh_right.n : 1;
-                for (int l = 0; l < nl; ++l)
-                    for (int r = 0; r < nrr; ++r) {
-                        int *comb = sh_comb[sh_ncomb];
-                        int len = 0;
-                        if (sh_left.n)
-                            for (int q = sh_left.len[l] - 1; q >= 0; --q) comb[len++] = sh_left.mem[l][q];
-                        sh_comb_mid[sh_ncomb] = len;
-                        comb[len++] = g;
-                        if (sh_right.n)
-                            for (int q = 0; q < sh_right.len[r]; ++q) comb[len++] = sh_right.mem[r][q];
-                        sh_comb_len[sh_ncomb++] = len;
-                    }
-            }
-        }
+        sh_bad = (A > 127 || k > MG_MAX_PACKED_K) ? 1 : 0;
+        sh_eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
+        sh_left.n = sh_right.n = 0;
     }
+    __syncthreads();
+    // the two walks (get_combs_on_the_left / _right) are independent: one lane of wave 0 and one of wave 1 take one each
+    if (sh_eligible && !sh_bad && (threadIdx.x == 0 || threadIdx.x == 64))
+        if (!bk_chains(B, b0, b1, g, threadIdx.x == 0 ? -1 : +1, threadIdx.x == 0 ? &sh_left : &sh_right)) atomicOr(&sh_bad, 1);
     __syncthreads();
     if (sh_bad) {
         if (threadIdx.x == 0) overflow[g] = 1;
@@ -482,9 +464,21 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     }
     u8 *buf = sh_buf[threadIdx.x];
     bool bad = false;
-    for (int c = 0; c < sh_ncomb; ++c) {
-        const int *comb = sh_comb[c];
-        const int m = sh_comb_len[c], jm = sh_comb_mid[c];
+    // combine_combs (var_block.hpp:630-677): every left chain (reversed) + the variant + every right chain; a chain is
+    // read member by member straight from the two walks' results, nothing is materialised
+    const int nl = sh_eligible ? (sh_left.n ? sh_left.n : 1) : 0, nrr = sh_right.n ? sh_right.n : 1;
+    for (int c = 0; c < nl * nrr; ++c) {
+        const int cl = c / nrr, cr = c % nrr;
+        const int len_l = sh_left.n ? sh_left.len[cl] : 0, len_r = sh_right.n ? sh_right.len[cr] : 0;
+        const int m = len_l + 1 + len_r, jm = len_l;
+        struct {
+            const BkChains *L, *R;
+            int cl, cr, len_l, g;
+            __device__ __forceinline__ int operator[](int j) const
+            {
+                return j < len_l ? L->mem[cl][len_l - 1 - j] : j == len_l ? g : R->mem[cr][j - len_l - 1];
+            }
+        } comb{&sh_left, &sh_right, cl, cr, len_l, g};
         const int first_pos = B.pos[comb[0]];
         const int last_end = B.pos[comb[m - 1]] + (int)B.ref_size[comb[m - 1]];
         // one haplotype pick along the chain -> its signature k-mer -> weight -> max into the mid allele's coverage;

@@ -104,11 +104,11 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
     args = pack_blocks(blocks, base, {n: len(refs[n]) for n in names})
     cov, ovf = ctx.cover_blocks(**args, haploid=haploid)
     ok = np.repeat(ovf == 0, np.diff(np.array(args["var_allele_off"])))
-    assert ok.mean() > (0.3 if dense else 0.9), "too many variants fell back: %.2f" % (1 - ok.mean())
+    assert ok.mean() > (0.6 if dense else 0.9), "too many variants fell back: %.2f" % (1 - ok.mean())
     assert np.array_equal(cov[ok], want[ok])
     assert (want[ok] > 0).sum() > 50
-    if dense:
-        assert ovf.sum() > 0                   # the capacities were actually reached somewhere
+    # (with 16 chains per side and 32 members per chain side the dense clusters mostly fit: what still comes back is
+    #  unphased runs beyond 2^10 mixes and windows clipped by a contig end)
     # variants flagged overflow must be genuinely beyond a device capacity or clipped by a contig end -- never wrong
     print("fallback variants: %d of %d" % (int(ovf.sum()), len(ovf)))
     ctx.close()

@@ -133,9 +133,10 @@ def test_c5_like_panel_many_batches(tmp_path):
 
 
 def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
-    """a run of SNPs at consecutive positions gives chains longer than the device kernel's 12 members: those blocks must
-    come back flagged and be redone by the host enumerator, with the same output as the oracle; forcing the host
-    enumerator for everything (MALVA_GENO_HOST_ENUM) must not change a byte either"""
+    """a run of 14 SNPs at consecutive positions with UNPHASED genotypes gives chains of up to 14 unphased members: 2^14
+    haplotype mixes per sample, beyond the device kernel's 2^10 -- those blocks must come back flagged and be redone by the
+    host enumerator, with the same output as the oracle; the phased runs (chains of up to 35 members) stay on the device;
+    forcing the host enumerator for everything (MALVA_GENO_HOST_ENUM) must not change a byte either"""
     import numpy as np
     rng = np.random.default_rng(5)
     seq = "".join(rng.choice(list("ACGT"), size=3000))
@@ -144,11 +145,11 @@ def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
     lines = ["##fileformat=VCFv4.2", '##INFO=<ID=AF,Number=A,Type=Float,Description="af">', '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
              "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\tS2"]
     recs = []
-    for start, n in ((500, 30), (1500, 6), (2200, 20)):
+    for start, n, sep in ((500, 14, "/"), (1500, 6, "|"), (2200, 30, "|")):
         for p in range(start, start + n):
             ref = seq[p]
             alt = "ACGT"[("ACGT".index(ref) + 1 + p % 3) % 4]
-            gts = ["%d|%d" % (rng.integers(0, 2), rng.integers(0, 2)) for _ in range(3)]
+            gts = ["%d%s%d" % (rng.integers(0, 2), sep, rng.integers(0, 2)) for _ in range(3)]
             lines.append("1\t%d\t.\t%s\t%s\t.\t.\tAF=0.%d\tGT\t%s" % (p + 1, ref, alt, 1 + p % 8, "\t".join(gts)))
             recs.append(("1", p, ref, [alt]))
     vcf = str(tmp_path / "d.vcf")
@@ -164,7 +165,7 @@ def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
     run_cli(["index"] + args)
     r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout == want
-    assert "enumerated on the host" in r.stderr
+    assert "1 block(s) enumerated on the host" in r.stderr          # the unphased run, and only it
     forced = run_cli(["call"] + args, env=dict(os.environ, MALVA_GENO_HOST_ENUM="1"))
     assert forced == want
 
