@@ -202,7 +202,7 @@ int mg_lookup_cover(mg_ctx *ctx, const char *rows, size_t stride, size_t n_rows,
  * the variant with the same text (variant.hpp:228); gt[v * n_samples + s] = a1 | a2 << 7 | phased << 14
  * for the kept panel samples (variant.hpp:158-211).  cov_out as in mg_lookup_cover, one slot per
  * (variant, allele).  overflow_out[v] = 1 where a fixed device capacity (16 chains per side, 32 members per
- * chain side, 10 unphased members, 127 alleles, k <= 64) or a window clipped by a contig end was hit: redo
+ * chain side, 14 unphased members, 127 alleles, k <= 64) or a window clipped by a contig end was hit: redo
  * that variant's block through the host enumerator + mg_lookup_cover. */
 int mg_cover_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
                     const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,

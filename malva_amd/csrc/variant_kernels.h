@@ -254,7 +254,7 @@ struct BlockBatch {
 };
 constexpr int BK_MAXC = 16;  // chains per side
 constexpr int BK_MAXL = 32;  // members per chain side (a combined chain: left + the variant + right <= 65 members)
-constexpr int BK_MAXU = 10;  // unphased chain length (2^10 picks)
+constexpr int BK_MAXU = 14;  // unphased chain length (2^14 haplotype mixes per sample)
 constexpr int BK_CODE_BITS = 63; // a chain's pick as a code: bits per member = ceil(log2(alleles))
 constexpr int BK_SET_CAP = 2048; // distinct picks of one chain held in the LDS set (16 KB); more: every pick evaluated directly
 

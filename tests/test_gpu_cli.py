@@ -133,8 +133,8 @@ def test_c5_like_panel_many_batches(tmp_path):
 
 
 def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
-    """a run of 14 SNPs at consecutive positions with UNPHASED genotypes gives chains of up to 14 unphased members: 2^14
-    haplotype mixes per sample, beyond the device kernel's 2^10 -- those blocks must come back flagged and be redone by the
+    """a run of 18 SNPs at consecutive positions with UNPHASED genotypes gives chains of up to 18 unphased members: 2^18
+    haplotype mixes per sample, beyond the device kernel's 2^14 -- those blocks must come back flagged and be redone by the
     host enumerator, with the same output as the oracle; the phased runs (chains of up to 35 members) stay on the device;
     forcing the host enumerator for everything (MALVA_GENO_HOST_ENUM) must not change a byte either"""
     import numpy as np
@@ -145,7 +145,7 @@ def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
     lines = ["##fileformat=VCFv4.2", '##INFO=<ID=AF,Number=A,Type=Float,Description="af">', '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
              "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\tS2"]
     recs = []
-    for start, n, sep in ((500, 14, "/"), (1500, 6, "|"), (2200, 30, "|")):
+    for start, n, sep in ((500, 18, "/"), (1500, 6, "|"), (2200, 30, "|")):
         for p in range(start, start + n):
             ref = seq[p]
             alt = "ACGT"[("ACGT".index(ref) + 1 + p % 3) % 4]
