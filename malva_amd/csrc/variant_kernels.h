@@ -226,12 +226,13 @@ __global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32
 // ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
 // VB::extract_kmers (var_block.hpp:95-219) with get_combs_on_the_right/left (:436-624), combine_combs (:630-677),
 // get_ref_subs (:682-702) and build_alleles_combs / combine_haplotypes (:709-786), fused with set_coverages
-// (main.cpp:151-184).  One workgroup per variant.  The reference builds the SET of distinct haplotype picks per
-// chain and takes, per allele, the max over signatures; a max does not care about duplicates, so here every
-// (chain, panel sample, haplotype pick) is simply evaluated and max-reduced -- thousands of redundant hashes
-// are cheaper on this machine than a device-side set.
+// (main.cpp:151-184), or at index time with add_kmers_to_bf (main.cpp:122-144).  One workgroup per variant.  Like the
+// reference (build_alleles_combs' unordered_set), the kernel reduces the picks of all panel samples along a chain to the
+// DISTINCT ones first -- a code of a few bits per member in an LDS hash set -- and evaluates each once; only a chain
+// whose code exceeds 63 bits or whose set exceeds its LDS capacity has every sample's pick evaluated directly (a max,
+// and a set insert, do not care about duplicates).
 // Fixed capacities (chains per side, chain length, unphased fan-out): a variant that exceeds one is flagged in
-// `overflow` and its block is redone by the host enumerator + mg_lookup_cover, so results never depend on them.
+// `overflow` and its block is redone by the host enumerator + mg_lookup_cover / mg_*_insert, so results never depend on them.
 struct BlockBatch {
     const u8 *reference;      // concatenated contigs (mg_reference_upload)
     const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
