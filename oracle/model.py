@@ -202,15 +202,18 @@ class VCFReader:
         for s in self.keep:
             fields = c[9 + s].split(":")
             gt = fields[gi] if gi < len(fields) else "."
-            alleles, phased, cur, ph = [], [], "", False
-            for ch in gt:
-                if ch in "/|":
-                    alleles.append(cur); phased.append(ph)
-                    cur, ph = "", (ch == "|")
-                else:
-                    cur += ch
-            alleles.append(cur); phased.append(ph)
-            parsed.append(([-1 if a in (".", "") else int(a) for a in alleles], phased))
+            hit = _GT_CACHE.get(gt)      # a panel repeats a handful of GT strings tens of thousands of times per record
+            if hit is None:
+                alleles, phased, cur, ph = [], [], "", False
+                for ch in gt:
+                    if ch in "/|":
+                        alleles.append(cur); phased.append(ph)
+                        cur, ph = "", (ch == "|")
+                    else:
+                        cur += ch
+                alleles.append(cur); phased.append(ph)
+                hit = _GT_CACHE[gt] = ([-1 if a in (".", "") else int(a) for a in alleles], phased)
+            parsed.append(hit)
         ploidy = max(len(a) for a, _ in parsed)
         flat = []   # ploidy values per sample: (allele or None for vector_end, phased bit)
         for al, ph in parsed:
@@ -232,8 +235,12 @@ class VCFReader:
                 is_ph = bool(nxt[1])
             a1 = 0 if a1 is None or a1 < 0 else a1
             a2 = 0 if a2 is None or a2 < 0 else a2
-            v.genotypes.append((a1, a2))
+            v.genotypes.append(_PAIRS.setdefault((a1, a2), (a1, a2)))   # one tuple object per distinct pair (27,934 samples a record)
             v.phasing.append(is_ph)
+
+
+_GT_CACHE: Dict[str, tuple] = {}     # memoisation only: GT string -> (alleles, phased flags), never mutated
+_PAIRS: Dict[tuple, tuple] = {}
 
 
 # ---------------------------------------------------------------------------

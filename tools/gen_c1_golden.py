@@ -49,6 +49,23 @@ def _parallel_extract(self, reference, haploid):
 T0 = time.time()
 model.VB.extract_kmers = _parallel_extract
 
+# index and call each decode the whole panel (850 MB of GT text): decode it once per (samples, key) and hand the records out again
+_records = model.VCFReader.records
+_decoded = {}
+
+
+def _records_once(self, freq_key="AF", uniform=False):
+    key = (self.path if hasattr(self, "path") else id(self), tuple(self.keep), freq_key, uniform)
+    if key not in _decoded:
+        _decoded[key] = list(_records(self, freq_key, uniform))
+        print("  panel decoded: %d records (%.0f s since start)" % (len(_decoded[key]), time.time() - T0), file=sys.stderr, flush=True)
+    for v in _decoded[key]:
+        v.coverages = []
+        yield v
+
+
+model.VCFReader.records = _records_once
+
 
 def main(verbose):
     opt = pipeline.Options(haploid=True, verbose=verbose, k=35, ref_k=43, bf_size=1 << 33, freq_key="AF")
