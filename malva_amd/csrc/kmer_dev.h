@@ -220,8 +220,11 @@ __device__ __forceinline__ u32 mul24(u32 a, u32 c)
 __device__ __forceinline__ u64 gate_mask_sk(u64 idx, u32 shift, u32 k)
 {
     u64 m = 1ULL << ((idx >> shift) & 63);
-    // the other positions: bits 26..31 of 24-bit products (v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter)
-    const u32 t = (u32)idx & (u32)((1ULL << (shift < 24 ? shift : 24)) - 1);
+    // the other positions: bits 26..31 of 24-bit products (v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter) of
+    // the low shift + 6 bits of idx -- everything in which two entries of the same gate word can differ.  (Taking only the
+    // `shift` bits below the first position's six made the three extra positions a function of 6 bits at whole-genome
+    // gates, shift = 6: 5.6 % of random rows passed a 13-bit-per-entry gate instead of ~1 %.)
+    const u32 t = (u32)idx & (u32)((1ULL << (shift + 6 < 24 ? shift + 6 : 24)) - 1);
     if (k > 1) m |= 1ULL << (mul24(t, 0x9E3779u) >> 26);
     if (k > 2) m |= 1ULL << (mul24(t, 0xEBCA77u) >> 26);
     if (k > 3) m |= 1ULL << (mul24(t, 0xB2AE3Du) >> 26);
