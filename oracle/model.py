@@ -380,7 +380,7 @@ class VB:
 
     def extract_one(self, vi: int, reference: str, haploid: bool) -> Dict[int, List[List[str]]]:
         """the body of extract_kmers' loop over the block's variants (var_block.hpp:100-216): the signatures of variant vi.
-        Variants are enumerated independently of one another, which is what lets tools/gen_c1_golden.py spread a block of
+        Variants are enumerated independently of one another, which is what lets tests/gen_c1_golden.py spread a block of
         thousands of variants x tens of thousands of samples over processes without touching the restated logic."""
         k = self.k
         v = self.variants[vi]

@@ -13,7 +13,7 @@ import time
 
 import multiprocessing as mp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> the repository root
 sys.path.insert(0, ROOT)
 from oracle import kmc_standin, model, pipeline  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Every BASELINE.json config that fits one GPU, at its stated size, against the oracle.
 
   C1  SARS-CoV-2 panel (15,154 records x 27,934 samples), k35 r43 b1, haploid: `bin/malva-geno` vs the oracle pipeline's
-      full output (tests/golden/sars_cov2.oracle.malva.verbose.vcf.gz, tools/gen_c1_golden.py), byte for byte
+      full output (tests/golden/sars_cov2.oracle.malva.verbose.vcf.gz, tests/gen_c1_golden.py), byte for byte
   C2  chr20: inputs absent from the reference checkout (.MISSING_LARGE_BLOBS) -- cannot be run by anyone here
   C3  1e8 k-mers x 1e6 biallelic SNPs, b=4: the oracle cannot scan 1e8 rows in seconds, so the full-size run is held by
       size-independent properties (linearity, shard sums, a hash-free checksum of what every signature's counter must
@@ -175,7 +175,7 @@ def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
 def test_c1_sars_cov2_full_output_equals_the_oracle(tmp_path, golden_dir):
     want_path = os.path.join(golden_dir, "sars_cov2.oracle.malva.verbose.vcf.gz")
     if not os.path.exists(want_path):
-        pytest.skip("tests/golden/sars_cov2.oracle.malva.verbose.vcf.gz not generated yet (tools/gen_c1_golden.py -v: hours of pure Python); "
+        pytest.skip("tests/golden/sars_cov2.oracle.malva.verbose.vcf.gz not generated yet (tests/gen_c1_golden.py -v: hours of pure Python); "
                     "test_gpu_cli.py::test_sars_cov2_panel_config_c1 holds the record count and the reference's two calls meanwhile")
     want = gzip.open(want_path, "rt").read()
     fa = os.path.join(golden_dir, "reference_sarsCov2.fasta")
