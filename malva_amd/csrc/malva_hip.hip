@@ -29,6 +29,7 @@ using namespace mg;
 
 namespace {
 
+constexpr size_t TK_META_HEAD = 8 + 8 * 32 * 4; // ticket meta block: spill count, then pass two's [8 XCDs][32 rounds] arrival counters, then the segment fills
 constexpr int BIN_SEGS = 2048; // workgroups of the binning kernel = segments per bin
 constexpr int TPB = 256;
 
@@ -101,6 +102,9 @@ struct mg_ctx {
     int probe_grid = 2048, hits_grid = 1024; // workgroups of the two list kernels (swept)
     int use_tickets = 0;     // gates beyond L2: file 8-byte tickets by gate slice instead of probing HBM at random (scan_ticket_kernel);
                              // measured slower than the direct forms at both 1e7 and 8e7 SNPs (profiles/r02_c4share_forms.txt): off, kept for A/B
+    int tkg_grid = 0;         // pass two's grid: the workgroups the device keeps resident together (found at first use)
+    int ticket_sync = 1;      // pass two: the workgroups of an XCD meet (bounded wait) before they move to the next gate slice
+    int ticket_sort = 1;      // pass one sorts tiles in LDS (scan_ticket_sort_kernel) instead of keeping a ring per slice
     int ticket_min_log2 = 26; // smallest fine gate (log2 bits) that takes the ticket form
     Scratch s_tk[2];
     unsigned long long *d_tk_meta = nullptr; // spill count, then u32 [TK_MAXP][BIN_SEGS] segment fills
@@ -579,6 +583,9 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
+    else if (!strcmp(name, "ticket_sort")) c->ticket_sort = value != 0;
+    else if (!strcmp(name, "ticket_sync")) c->ticket_sync = value != 0;
+    else if (!strcmp(name, "ticket_gate_grid")) c->tkg_grid = value > 0 ? (int)std::max<int64_t>(8, std::min<int64_t>(4096, value / 8 * 8)) : 0;
     else if (!strcmp(name, "hits_grid")) c->hits_grid = value > 0 ? (int)value : 1024;
     else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
     else if (!strcmp(name, "scan_bin_ring")) {
@@ -622,6 +629,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate && pregate_on(c) ? c->pre_k : 0;
     else if (!strcmp(name, "scan_bins")) *value = c->last_bins;
     else if (!strcmp(name, "scan_tickets")) *value = c->last_tickets;
+    else if (!strcmp(name, "ticket_gate_grid")) *value = c->tkg_grid;
     else if (!strcmp(name, "use_tickets")) *value = c->use_tickets;
     else if (!strcmp(name, "scan_spilled")) { // rows of the last chunk that took the spill list
         unsigned long long t = 0;
@@ -917,6 +925,48 @@ MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 // ---- KMC scan ----------------------------------------------------------------------------
 
 namespace {
+// ---- the ticket form's host side ---------------------------------------------------------------------------------------
+u64 ticket_slices(mg_ctx *c) // slices of half the L2-resident size (2 MiB) the fine gate splits into
+{
+    const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6);
+    return (((c->bf[MG_BF_ALT].n_gate_bits + 63) / 64) + (1ULL << word_shift) - 1) >> word_shift;
+}
+// does this index take the ticket form?  *row_bits = bits of a ticket left for the row number (rows per launch group = 2^row_bits)
+bool ticket_form(mg_ctx *c, u32 *row_bits)
+{
+    const BFState &alt = c->bf[MG_BF_ALT];
+    const u64 TP = ticket_slices(c);
+    u32 idx_bits = 1;
+    while (idx_bits < 64 && (alt.size - 1) >> idx_bits) ++idx_bits;
+    *row_bits = std::min<u32>(27, 64 - idx_bits);
+    return c->use_summary && c->use_tickets && alt.gate && c->gate_log2 >= c->ticket_min_log2 && TP >= 2 && TP <= (u64)TK_MAXP && idx_bits <= 44;
+}
+// segments, staging and meta block for launch groups of up to `cap` rows
+int ticket_layout(mg_ctx *c, u64 cap, u32 row_bits, TicketSet *out)
+{
+    TicketSet tks{};
+    const u64 TP = ticket_slices(c);
+    tks.nbins = (u32)TP;
+    tks.word_shift = (u32)(c->pregate_log2 - 1 - 6);
+    tks.row_bits = row_bits;
+    tks.nseg = (u32)std::min<u64>((cap + 4 * TPB - 1) / (4 * TPB), BIN_SEGS);
+    const u64 tile = c->ticket_sort ? TK_TILE : 4 * TPB; // rows a workgroup takes at a time
+    const u64 wg_rows = ((cap + tile - 1) / tile + tks.nseg - 1) / tks.nseg * tile;
+    tks.segcap = c->bin_cap ? c->bin_cap : ((wg_rows / TP) * 3 / 2 + 64 + 15) / 16 * 16; // 1.5x an even share, whole 128-byte lines
+    tks.ring = 16;
+    while (tks.ring < 64 && tks.ring * 2 * TP <= (u64)TK_LDS_TICKETS) tks.ring *= 2;
+    void *q[2];
+    TRY(scratch(c, c->s_tk[0], TP * tks.nseg * tks.segcap * 8, &q[0]));
+    TRY(scratch(c, c->s_tk[1], cap * 8, &q[1]));
+    tks.tickets = (u64 *)q[0];
+    tks.spill = (u64 *)q[1];
+    if (!c->d_tk_meta) HIP_TRY(c, hipMalloc(&c->d_tk_meta, TK_META_HEAD + (size_t)TK_MAXP * BIN_SEGS * 4));
+    tks.spill_count = c->d_tk_meta;
+    tks.sync = c->ticket_sync ? (u32 *)(c->d_tk_meta + 1) : nullptr;
+    tks.counts = (u32 *)((char *)c->d_tk_meta + TK_META_HEAD);
+    *out = tks;
+    return MG_OK;
+}
 template <int KC, int RC, int ROWS, int VAR>
 void launch_filter_var(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
 {
@@ -935,17 +985,36 @@ void launch_filter_rows(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *
     default: launch_filter_var<KC, RC, ROWS, 0>(c, d_hi, d_lo, d_cnt, n, open); break;
     }
 }
+// The two passes of the ticket form over one chunk of the table (SoA arrays, or compact rows when `rows12` is given).
+template <int KC, int RC>
+void launch_ticket_passes(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *rows12, u64 n, const TicketSet &layout, RowList open)
+{
+    TicketSet ts = layout;
+    ts.nseg = (u32)std::min<u64>((n + 4 * TPB - 1) / (4 * TPB), layout.nseg);
+    if (c->ticket_sort || rows12)
+        hipLaunchKernelGGL((scan_ticket_sort_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), 0, c->stream, d_hi, d_lo, rows12, n, (int)c->k, (int)c->ref_k,
+                           view(c, MG_BF_ALT), ts);
+    else
+        hipLaunchKernelGGL((scan_ticket_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), (size_t)ts.nbins * ts.ring * 8, c->stream, d_hi, d_lo, n, (int)c->k,
+                           (int)c->ref_k, view(c, MG_BF_ALT), ts);
+    if (!c->tkg_grid) { // pass two walks the slices in step: one workgroup per CU, all resident together
+        int cus = 0, dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        c->tkg_grid = std::max(8, cus / 8 * 8);
+    }
+    if (c->gate_k == 4)
+        hipLaunchKernelGGL(scan_ticket_gate_kernel<4>, dim3(c->tkg_grid), dim3(TKG_TPB), 0, c->stream, view(c, MG_BF_ALT), ts, open.cnt, c->d_hit_count);
+    else
+        hipLaunchKernelGGL(scan_ticket_gate_kernel<0>, dim3(c->tkg_grid), dim3(TKG_TPB), 0, c->stream, view(c, MG_BF_ALT), ts, open.cnt, c->d_hit_count);
+}
 template <int KC, int RC>
 void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed,
                        const BinSet *bins, const TicketSet *tickets)
 {
     if (timed) hipEventRecord(c->ev[0], c->stream);
     if (tickets) { // whole-genome index: tickets filed by gate slice, then the gate slice by slice out of L2
-        TicketSet ts = *tickets;
-        ts.nseg = (u32)std::min<u64>((n + 4 * TPB - 1) / (4 * TPB), tickets->nseg);
-        hipLaunchKernelGGL((scan_ticket_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), (size_t)ts.nbins * ts.ring * 8, c->stream, d_hi, d_lo, n, (int)c->k,
-                           (int)c->ref_k, view(c, MG_BF_ALT), ts);
-        hipLaunchKernelGGL((scan_ticket_gate_kernel<KC, RC>), dim3(2048), dim3(TPB), 0, c->stream, view(c, MG_BF_ALT), ts, RowList{nullptr, nullptr, open.cnt}, c->d_hit_count);
+        launch_ticket_passes<KC, RC>(c, d_hi, d_lo, nullptr, n, *tickets, open);
     } else if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
         BinSet bs = *bins; // the last chunk may need fewer workgroups than segments were laid out for
         bs.nseg = (u32)std::min<u64>((n + 2 * TPB - 1) / (2 * TPB), bins->nseg);
@@ -968,7 +1037,8 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
     hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
-                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt, tickets ? d_hi : (const u64 *)nullptr, tickets ? d_lo : (const u64 *)nullptr);
+                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt, tickets ? d_hi : (const u64 *)nullptr, tickets ? d_lo : (const u64 *)nullptr,
+                       (const u32 *)nullptr);
     if (timed) hipEventRecord(c->ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
@@ -989,11 +1059,9 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     // large index: tickets by gate slice (takes precedence over the row-moving partition below)
     const BFState &alt = c->bf[MG_BF_ALT];
     const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6); // slices of half the L2-resident size: 2 MiB
-    const u64 TP = (((alt.n_gate_bits + 63) / 64) + (1ULL << word_shift) - 1) >> word_shift;
-    u32 idx_bits = 1;
-    while (idx_bits < 64 && (alt.size - 1) >> idx_bits) ++idx_bits;
-    const bool tickets = c->use_summary && c->use_tickets && alt.gate && c->gate_log2 >= c->ticket_min_log2 && TP >= 2 && TP <= (u64)TK_MAXP && idx_bits <= 44;
-    const u32 row_bits = std::min<u32>(27, 64 - idx_bits);
+    u32 row_bits = 27;
+    const bool tickets = ticket_form(c, &row_bits);
+    const u64 TP = ticket_slices(c);
     const u64 chunk = tickets ? 1ULL << row_bits : 1ULL << 27; // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
     void *p[6];
@@ -1004,23 +1072,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
     BinSet bins{};
     TicketSet tks{};
-    if (tickets) {
-        tks.nbins = (u32)TP;
-        tks.word_shift = word_shift;
-        tks.row_bits = row_bits;
-        tks.nseg = (u32)std::min<u64>((cap + 4 * TPB - 1) / (4 * TPB), BIN_SEGS);
-        tks.segcap = c->bin_cap ? c->bin_cap : ((cap / TP / tks.nseg) * 3 / 2 + 64 + 15) / 16 * 16; // 1.5x an even share, whole 128-byte lines
-        tks.ring = 16;
-        while (tks.ring < 64 && tks.ring * 2 * TP <= (u64)TK_LDS_TICKETS) tks.ring *= 2;
-        void *q[2];
-        TRY(scratch(c, c->s_tk[0], TP * tks.nseg * tks.segcap * 8, &q[0]));
-        TRY(scratch(c, c->s_tk[1], cap * 8, &q[1]));
-        tks.tickets = (u64 *)q[0];
-        tks.spill = (u64 *)q[1];
-        if (!c->d_tk_meta) HIP_TRY(c, hipMalloc(&c->d_tk_meta, 8 + (size_t)TK_MAXP * BIN_SEGS * 4));
-        tks.spill_count = c->d_tk_meta;
-        tks.counts = (u32 *)(c->d_tk_meta + 1);
-    }
+    if (tickets) TRY(ticket_layout(c, cap, row_bits, &tks));
     const u64 P = !tickets && alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
     const bool partition = c->use_summary && c->use_pregate && c->use_partition && P >= 2 && P <= BIN_MAXP;
     if (partition) {
@@ -1048,7 +1100,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         const u32 *pc = (const u32 *)d_cnt + r0;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
         if (partition) HIP_TRY(c, hipMemsetAsync(c->d_bin_meta, 0, 8, c->stream));
-        if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, 8, c->stream));
+        if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, TK_META_HEAD, c->stream));
         // the reference's defaults (k35 r43, argument_parser.hpp:57-58) and config C5 (k35 r63) get fixed-length hashing
         if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
         else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
@@ -1064,16 +1116,20 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
 // ---- compact (12-byte) table rows --------------------------------------------------------------------------------
 namespace {
 template <int KC, int RC>
-void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowList hits, bool timed)
+void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowList hits, bool timed, const TicketSet *tickets)
 {
     if (timed) hipEventRecord(c->ev[0], c->stream);
-    const unsigned fgrid = (unsigned)std::min<u64>(((n + 1) / 2 + TPB - 1) / TPB, (u64)c->scan_grid);
-    hipLaunchKernelGGL((scan_filter12_kernel<KC, RC>), dim3(fgrid), dim3(TPB), 0, c->stream, (const u32 *)rows, n, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), open,
-                       c->d_hit_count, c->scan_ablate);
+    if (tickets) // whole-genome index: tickets filed by gate slice, then the gate slice by slice out of L2; the open list holds row numbers
+        launch_ticket_passes<KC, RC>(c, nullptr, nullptr, (const u32 *)rows, n, *tickets, open);
+    else {
+        const unsigned fgrid = (unsigned)std::min<u64>(((n + 1) / 2 + TPB - 1) / TPB, (u64)c->scan_grid);
+        hipLaunchKernelGGL((scan_filter12_kernel<KC, RC>), dim3(fgrid), dim3(TPB), 0, c->stream, (const u32 *)rows, n, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
+                           open, c->d_hit_count, c->scan_ablate);
+    }
     if (timed) hipEventRecord(c->ev[1], c->stream);
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
     hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits,
-                       c->d_hit_count, (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr);
+                       c->d_hit_count, (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr, tickets ? (const u32 *)rows : (const u32 *)nullptr);
     if (timed) hipEventRecord(c->ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
@@ -1117,24 +1173,29 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     if (n == 0) return MG_OK;
     if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(c, MG_ERR_ARG, "packed rows must be 16-byte aligned");
     if (!c->map.slots) TRY(map_reserve(c, 0));
-    const u64 chunk = 1ULL << 27;
+    u32 row_bits = 27;
+    const bool tickets = ticket_form(c, &row_bits);
+    const u64 chunk = tickets ? std::max<u64>(4, 1ULL << row_bits) : 1ULL << 27; // (a multiple of 4 rows: chunks start on whole quads)
     const u64 cap = n < chunk ? n : chunk;
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
     for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
     const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    TicketSet tks{};
+    if (tickets) TRY(ticket_layout(c, cap, row_bits, &tks));
     c->stats_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
     for (u64 r0 = 0; r0 < n; r0 += chunk) {
         const u64 nr = n - r0 < chunk ? n - r0 : chunk;
         const uint4 *pr = (const uint4 *)d_rows + r0 / 4 * 3;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
-        if (c->k == 35 && c->ref_k == 43) launch_rows12_chunk<35, 43>(c, pr, nr, open, hits, r0 == 0);
-        else launch_rows12_chunk<0, 0>(c, pr, nr, open, hits, r0 == 0);
+        if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, TK_META_HEAD, c->stream));
+        if (c->k == 35 && c->ref_k == 43) launch_rows12_chunk<35, 43>(c, pr, nr, open, hits, r0 == 0, tickets ? &tks : nullptr);
+        else launch_rows12_chunk<0, 0>(c, pr, nr, open, hits, r0 == 0, tickets ? &tks : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
     c->last_bins = 0;
-    c->last_tickets = 0;
+    c->last_tickets = tickets ? (int)ticket_slices(c) : 0;
     c->stats_valid = true;
     return MG_OK;
 }

@@ -550,6 +550,7 @@ struct TicketSet {
     u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift
     u32 ring;                    // staging tickets per bin (power of two); tickets leave in units of ring / 2
     u32 row_bits;                // ticket = idx << row_bits | row
+    u32 *sync;                   // [8][TK_MAXP / 8] arrivals per XCD and round of pass two (zeroed before every launch); null = no rendezvous
 };
 
 template <int KC, int RC>
@@ -652,59 +653,271 @@ __global__ void __launch_bounds__(TPB) scan_ticket_kernel(const u64 *__restrict_
     for (int b = threadIdx.x; b < P; b += TPB) ts.counts[b * ts.nseg + blockIdx.x] = sh_pos[b];
 }
 
+// Pass one, second form: a tile of TK_TILE rows is SORTED by gate slice in LDS (one returning LDS atomic per row gives
+// its rank inside its slice, a prefix sum over the slices gives the slice's place in the tile) and leaves as runs of
+// consecutive tickets, every lane of every wave storing -- instead of rings flushed slice by slice by a quarter of a
+// wave.  The rings cost a scan over up to 256 slices per 1,024 rows and 16-lane stores (measured 2.0 ms per 1.3e8 rows at
+// 128 slices: nowhere near the 24 B/row it moves).
+constexpr int TK_TILE_ROWS = 8;                  // rows per thread and tile
+constexpr int TK_TILE = TPB * TK_TILE_ROWS;      // 2,048 rows: 16 tickets per slice on average at 128 slices
+// The table is either the SoA arrays (hi, lo) or, when `rows12` is not null, the compact 12-byte rows of scan_filter12_kernel.
 template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(BFView bf, TicketSet ts,
-                                                               RowList open, unsigned long long *counters)
+__global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ rows12, u64 n,
+                                                               int k_rt, int r_rt, BFView bf, TicketSet ts)
 {
-    constexpr int CAP = 2 * TPB + 256;
-    __shared__ u64 sh_hi[CAP], sh_lo[CAP];
-    __shared__ u32 sh_cnt[CAP];
-    __shared__ u32 sh_n;
-    __shared__ unsigned long long sh_base;
-    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
-    if (threadIdx.x == 0) sh_n = 0;
-    __syncthreads();
+    __shared__ u64 sh_sorted[TK_TILE];
+    __shared__ uint16_t sh_binof[TK_TILE];
+    __shared__ u32 sh_hist[TK_MAXP], sh_off[TK_MAXP + 1], sh_pos[TK_MAXP]; // this tile's count / place in the tile / tickets already in the segment
+    __shared__ u32 sh_lut[256];
     const int P = (int)ts.nbins;
-    const u64 row_mask = (1ULL << ts.row_bits) - 1;
-    auto take = [&](const u64 *src, u64 first, u64 np) { // block-uniform arguments
-        for (u64 base = 0; base < np; base += 2 * TPB) {
-            u64 t[2], word[2];
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    ascii_lut_fill(sh_lut);
+    for (int b = threadIdx.x; b < P; b += TPB) sh_hist[b] = sh_pos[b] = 0;
+    __syncthreads();
+    typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
+    const bool vec_ok = ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
+    const u64 step = (u64)gridDim.x * TK_TILE;
+    for (u64 base = (u64)blockIdx.x * TK_TILE; base < n; base += step) {
+        u64 tk[TK_TILE_ROWS];
+        u32 binrank[TK_TILE_ROWS]; // bin << 16 | rank inside the bin (a tile holds 2,048 rows: both fit 16 bits), ~0u = no row
+#pragma unroll
+        for (int g = 0; g < TK_TILE_ROWS / 2; ++g) { // two adjacent rows per load pair, hashed as they arrive
+            const u64 i = base + (u64)g * 2 * TPB + 2 * (u64)threadIdx.x;
+            U128 m[2];
             bool live[2];
+            if (rows12) { // 24 contiguous bytes: rows i and i + 1 (i is even; the buffer is padded to whole quads of rows)
+                typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
+                u32 w[6] = {0, 0, 0, 0, 0, 0};
+                if (i < n) {
+                    const v2u32 *src = (const v2u32 *)rows12 + 3 * (i / 2);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const u64 j = base + q * TPB + threadIdx.x;
-                live[q] = j < np;
-                t[q] = live[q] ? __builtin_nontemporal_load(src + first + j) : 0;
+                    for (int q = 0; q < 3; ++q) {
+                        const v2u32 v = __builtin_nontemporal_load(src + q);
+                        w[2 * q] = v.x;
+                        w[2 * q + 1] = v.y;
+                    }
+                }
+                const u32 kmask_hi = (1u << ((2 * r - 64) & 31)) - 1; // bits of the k-mer in the third dword, the count above them (33 <= ref_k <= 44 here)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    m[j] = U128{w[3 * j] | (u64)w[3 * j + 1] << 32, (u64)(w[3 * j + 2] & kmask_hi)};
+                    live[j] = i + j < n;
+                }
+            } else if (vec_ok && i + 1 < n) {
+                const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
+                const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
+                m[0] = U128{l2.x, h2.x};
+                m[1] = U128{l2.y, h2.y};
+                live[0] = live[1] = true;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    live[j] = i + j < n;
+                    m[j].lo = live[j] ? __builtin_nontemporal_load(lo + i + j) : 0;
+                    m[j].hi = live[j] ? __builtin_nontemporal_load(hi + i + j) : 0;
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) word[q] = live[q] ? bf.gate[gate_word(bf, t[q] >> ts.row_bits)] : 0; // the slice in this XCD's L2
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const u64 gm = gate_mask(bf, t[q] >> ts.row_bits);
-                // listed by row number alone: the probe kernel, which has no stream to disturb, fetches the row and its count
-                st.push(live[q] && (word[q] & gm) == gm, U128{0, 0}, (u32)(t[q] & row_mask));
+            for (int j = 0; j < 2; ++j) {
+                const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+                const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
+                tk[2 * g + j] = (idx << ts.row_bits) | (i + j);
+                const u32 bin = (u32)(gate_word(bf, idx) >> ts.word_shift);
+                binrank[2 * g + j] = live[j] ? (bin << 16) | atomicAdd(&sh_hist[bin], 1u) : ~0u;
             }
-            st.flush_if_above(CAP - 2 * TPB, open, &counters[0]);
         }
+        __syncthreads();
+        if (threadIdx.x < 64) { // exclusive prefix sum of the slice counts (one wave, P <= 256: four slices per lane)
+            u32 v[4], run = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = threadIdx.x * 4 + q;
+                v[q] = b < P ? sh_hist[b] : 0;
+                run += v[q];
+            }
+            u32 incl = run;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += t;
+            }
+            u32 ex = incl - run;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = threadIdx.x * 4 + q;
+                if (b <= P) sh_off[b] = ex;
+                ex += v[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TK_TILE_ROWS; ++j)
+            if (binrank[j] != ~0u) {
+                const u32 at = sh_off[binrank[j] >> 16] + (binrank[j] & 0xFFFF);
+                sh_sorted[at] = tk[j];
+                sh_binof[at] = (uint16_t)(binrank[j] >> 16);
+            }
+        __syncthreads();
+        const u32 total = sh_off[P];
+        for (u32 e = threadIdx.x; e < total; e += TPB) { // runs of consecutive tickets, one per slice, into the workgroup's segments
+            const u32 b = sh_binof[e];
+            const u32 at = sh_pos[b] + (e - sh_off[b]);
+            if (at < ts.segcap) ts.tickets[((unsigned long long)b * ts.nseg + blockIdx.x) * ts.segcap + at] = sh_sorted[e];
+            else ts.spill[atomicAdd(ts.spill_count, 1ULL)] = sh_sorted[e]; // the segment is full (skewed input): rare
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < P; b += TPB) {
+            sh_pos[b] = min(sh_pos[b] + sh_hist[b], (u32)ts.segcap);
+            sh_hist[b] = 0;
+        }
+        __syncthreads();
+    }
+    for (int b = threadIdx.x; b < P; b += TPB) ts.counts[b * ts.nseg + blockIdx.x] = sh_pos[b];
+}
+
+// Pass two.  XCD x takes the slices x, x + 8, ... (workgroups b and b + 8 share an XCD under round-robin dispatch, and each
+// XCD has its own L2); with fewer than 8 slices, slice x mod P, its segments split between the XCDs that share it.  Inside
+// a slice a workgroup takes a run of consecutive segments and walks their tickets as ONE dense sequence (a prefix sum of
+// the segments' fills in LDS maps a position to its segment): TKG_U tickets per thread and step whatever the segments'
+// fills are, the next step's tickets requested before this step's gate words are waited for.  (First form: segment by
+// segment, 512 tickets at a time -- a segment holds 512 on average, so every second one took a second, nearly empty step,
+// and every step began with a chain count -> tickets -> gate word of dependent loads: 1.3 ms per 1.3e8 tickets, three
+// times what the L2 gather costs.)  Survivors are listed by row number alone: the probe kernel, which has no stream to
+// disturb, fetches the rows.  Placement only decides speed, never the result.
+constexpr int TKG_TPB = 256, TKG_U = 8, TKG_SPW = 64; // threads per workgroup; tickets per thread and step; segments of one slice per walk
+constexpr int TKG_WSTAGE = 5120;                       // staged survivors per wave (4 waves: 80 KB, so a CU holds exactly one workgroup)
+// GK: the gate's bits per entry fixed at compile time (0 = read from the view)
+template <int GK>
+__global__ void __launch_bounds__(TKG_TPB) scan_ticket_gate_kernel(BFView bf, TicketSet ts, u32 *__restrict__ open_rows, unsigned long long *counters)
+{
+    constexpr int STEP = TKG_U * TKG_TPB;
+    static_assert(TKG_WSTAGE >= 2 * 64 * TKG_U, "a wave's stage must take a whole step beyond its flush mark");
+    __shared__ u32 sh_row[TKG_TPB / 64][TKG_WSTAGE];
+    __shared__ u32 sh_start[TKG_SPW + 1];
+    const u64 row_mask = (1ULL << ts.row_bits) - 1;
+    const u32 gate_k = GK > 0 ? (u32)GK : bf.gate_k;
+    const int lane = threadIdx.x & 63;
+    u32 *const my_row = sh_row[threadIdx.x >> 6];
+    u32 wn = 0; // survivors this wave has staged (the same in every lane).  Staging and flushing are the wave's own business: no
+                // barrier inside a walk, so a wave waiting for its gate words never holds up the other fifteen
+    auto flush_if_above = [&](u32 keep) { // every lane of the wave
+        if (wn <= keep) return;
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&counters[0], (unsigned long long)wn);
+        b = __shfl(b, 0, 64);
+        for (u32 j = lane; j < wn; j += 64) open_rows[b + j] = my_row[j];
+        wn = 0;
     };
-    // Workgroups b and b + 8 share an XCD (round-robin dispatch) and each XCD has its own L2: XCD x takes slices x,
-    // x + 8, ...; with fewer than 8 slices, slice x mod P, its segments split between the XCDs that share it.
-    // Placement only decides speed, never the result.
+    // The loads of the loop below carry no predicate (a lane without a ticket reads the run's first ticket and the gate's
+    // first word): with `if (live) load` the compiler can no longer count outstanding loads and waits for ALL of them before
+    // every use, which serialised ticket and gate latency (first form: 0.98 ms per 1.3e8 tickets, 0.41 of it with both loads
+    // compiled out and 0.35-0.5 for the gate words alone -- no overlap at all).
+    struct Tk {
+        u64 t[TKG_U];
+        bool live[TKG_U];
+    };
+    auto gate_loads = [&](const Tk &k, u64 (&word)[TKG_U]) {
+#pragma unroll
+        for (int u = 0; u < TKG_U; ++u) word[u] = bf.gate[k.live[u] ? gate_word(bf, k.t[u] >> ts.row_bits) : 0]; // the slice in this XCD's L2
+    };
+    auto test_and_stage = [&](const Tk &k, const u64 (&word)[TKG_U]) { // every lane of the wave
+#pragma unroll
+        for (int u = 0; u < TKG_U; ++u) {
+            const u64 gm = gate_mask_sk(k.t[u] >> ts.row_bits, bf.gate_shift, gate_k);
+            const bool take = k.live[u] && (word[u] & gm) == gm;
+            const u64 mask = __ballot(take);
+            if (take) my_row[wn + __popcll(mask & ((1ULL << lane) - 1))] = (u32)(k.t[u] & row_mask);
+            wn += (u32)__popcll(mask);
+        }
+        flush_if_above(TKG_WSTAGE - 64 * TKG_U);
+    };
+    // `nsegs` <= TKG_SPW consecutive segments starting at ticket `first`, fills at cnts[0..nsegs): block-uniform arguments
+    auto walk = [&](const u64 *first, const u32 *cnts, u32 nsegs) {
+        if (threadIdx.x < 64) { // inclusive prefix sum of the fills, one wave
+            u32 incl = threadIdx.x < nsegs ? cnts[threadIdx.x] : 0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 v = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += v;
+            }
+            sh_start[threadIdx.x + 1] = incl;
+            if (threadIdx.x == 0) sh_start[0] = 0;
+        }
+        __syncthreads();
+        const u32 total = sh_start[nsegs];
+        u32 seg[TKG_U], lo_[TKG_U], hi_[TKG_U]; // per position of the step: its segment and that segment's range in the sequence
+#pragma unroll
+        for (int u = 0; u < TKG_U; ++u) seg[u] = 0, lo_[u] = 0, hi_[u] = sh_start[1];
+        auto fetch = [&](u32 base, Tk &k) { // bases must come in increasing order (the cursors only move forward)
+#pragma unroll
+            for (int u = 0; u < TKG_U; ++u) {
+                const u32 q = base + u * TKG_TPB + threadIdx.x;
+                k.live[u] = q < total;
+                if (k.live[u])
+                    while (q >= hi_[u]) { // q < total = sh_start[nsegs]: ends inside the table
+                        ++seg[u];
+                        lo_[u] = hi_[u];
+                        hi_[u] = sh_start[seg[u] + 1];
+                    }
+                k.t[u] = __builtin_nontemporal_load(first + (k.live[u] ? (u64)seg[u] * ts.segcap + (q - lo_[u]) : 0));
+            }
+        };
+        // tickets are requested two steps ahead: per step the wave issues this step's gate loads, then the tickets of step
+        // + 2, and waits for the gate words only (loads return in order, so the tickets of step + 1 are home by then too)
+        Tk a, b, c;
+        fetch(0, a);
+        fetch(STEP, b);
+        for (u32 base = 0; base < total; base += STEP) {
+            u64 word[TKG_U];
+            gate_loads(a, word);
+            asm volatile("" ::: "memory");
+            fetch(base + 2 * STEP, c);
+            asm volatile("" ::: "memory");
+            test_and_stage(a, word);
+            a = b;
+            b = c;
+        }
+        __syncthreads(); // sh_start is rewritten by the next walk
+    };
     const u32 xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3; // the grid is a multiple of 8
-    if (P >= 8) {
-        for (int p = (int)xcd; p < P; p += 8)
-            for (u32 w = local; w < ts.nseg; w += nlocal) take(ts.tickets, ((u64)p * ts.nseg + w) * ts.segcap, ts.counts[p * ts.nseg + w]);
-    } else {
-        const int p = (int)(xcd % (u32)P);
-        const u32 share = xcd / (u32)P, nshare = (8 - (u32)p + (u32)P - 1) / (u32)P; // XCDs p, p + P, ... hold this slice
-        for (u32 w = local * nshare + share; w < ts.nseg; w += nlocal * nshare) take(ts.tickets, ((u64)p * ts.nseg + w) * ts.segcap, ts.counts[p * ts.nseg + w]);
+    const int P = (int)ts.nbins;
+    const u32 nshare = P >= 8 ? 1 : (8 - xcd % (u32)P + (u32)P - 1) / (u32)P; // XCDs p, p + P, ... hold slice p when P < 8
+    const u32 me = P >= 8 ? local : local * nshare + xcd / (u32)P, nme = nlocal * nshare;
+    const u32 spw = (ts.nseg + nme - 1) / nme, s0 = me * spw;
+    const u32 s1 = s0 < ts.nseg ? (s0 + spw < ts.nseg ? s0 + spw : ts.nseg) : s0;
+    for (int p = P >= 8 ? (int)xcd : (int)(xcd % (u32)P); p < P; p += 8) {
+        for (u32 s = s0; s < s1; s += TKG_SPW)
+            walk(ts.tickets + ((u64)p * ts.nseg + s) * ts.segcap, ts.counts + (u64)p * ts.nseg + s, s1 - s < (u32)TKG_SPW ? s1 - s : (u32)TKG_SPW);
+        // Rendezvous of the XCD's workgroups before the next slice.  Left to themselves they drift apart by a slice or more,
+        // two or three slices then compete for the 4 MiB L2 and 42 % of the gate loads miss it (TCC_MISS, round 2; a grid
+        // larger than what is resident at once is worse still: its late workgroups start at the first slice again).  The
+        // rendezvous only decides speed: the wait is BOUNDED, and whoever gives up simply goes on.
+        if (ts.sync && p + 8 < P) {
+            if (threadIdx.x == 0) {
+                u32 *const arrived = ts.sync + xcd * (TK_MAXP / 8) + (u32)(p >> 3);
+                atomicAdd(arrived, 1u);
+                for (int spin = 0; spin < 256 && __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nlocal; ++spin)
+                    __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+        }
     }
-    {
+    { // the spill list: one dense run, an even share per workgroup
         const u64 ns = *ts.spill_count, chunk = (ns + gridDim.x - 1) / gridDim.x;
-        const u64 lo_ = min(ns, chunk * blockIdx.x), hi_ = min(ns, lo_ + chunk);
-        take(ts.spill, lo_, hi_ - lo_);
+        const u64 b0 = ns < chunk * blockIdx.x ? ns : chunk * blockIdx.x, b1 = ns < b0 + chunk ? ns : b0 + chunk;
+        for (u64 base = b0; base < b1; base += STEP) {
+            Tk k;
+            u64 word[TKG_U];
+#pragma unroll
+            for (int u = 0; u < TKG_U; ++u) {
+                const u64 q = base + u * TKG_TPB + threadIdx.x;
+                k.live[u] = q < b1;
+                k.t[u] = k.live[u] ? __builtin_nontemporal_load(ts.spill + q) : 0;
+            }
+            gate_loads(k, word);
+            test_and_stage(k, word);
+        }
     }
-    st.flush_if_above(0, open, &counters[0]);
+    flush_if_above(0);
 }
 
 // (Probe and hit pass fused in one kernel -- no second list, no re-hash -- was measured: 0.276 ms against 0.100 +
@@ -712,7 +925,7 @@ __global__ void __launch_bounds__(TPB) scan_ticket_gate_kernel(BFView bf, Ticket
 template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFView bf, MapView map, RowList open, RowList hits,
                                                          unsigned long long *counters, const u32 *__restrict__ cnt_table,
-                                                         const u64 *__restrict__ row_hi, const u64 *__restrict__ row_lo)
+                                                         const u64 *__restrict__ row_hi, const u64 *__restrict__ row_lo, const u32 *__restrict__ rows12)
 {
     constexpr int CAP = TPB + 256;
     __shared__ u64 sh_hi[CAP], sh_lo[CAP];
@@ -735,7 +948,13 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         u32 count = 0;
         if (j < n_open) {
             count = open.cnt[j];
-            if (row_hi) { // ticket form: the list holds row numbers only; the row's three words are requested together
+            if (rows12) { // ticket form over compact rows: the list holds row numbers, a row is 12 contiguous bytes (one line, now and then two)
+                const u32 *w = rows12 + 3 * (u64)count;
+                const u32 w0 = __builtin_nontemporal_load(w), w1 = __builtin_nontemporal_load(w + 1), w2 = __builtin_nontemporal_load(w + 2);
+                const u32 kbits_hi = (u32)(2 * r - 64) & 31; // (33 <= ref_k <= 44 here)
+                m = U128{w0 | (u64)w1 << 32, (u64)(w2 & ((1u << kbits_hi) - 1))};
+                count = w2 >> kbits_hi;
+            } else if (row_hi) { // ticket form: the list holds row numbers only; the row's three words are requested together
                 m = U128{__builtin_nontemporal_load(row_lo + count), __builtin_nontemporal_load(row_hi + count)};
                 count = __builtin_nontemporal_load(cnt_table + count);
             } else {

@@ -212,3 +212,32 @@ def test_scan_compact_rows_equals_oracle(k, ref_k, n_rows, bits):
     with Context(35, 63, 1 << 20) as ctx:                              # 126-bit k-mers leave no room for a count
         with pytest.raises(MalvaError):
             ctx.kmc_scan_rows_device(1 << 20, 4)
+
+
+@pytest.mark.parametrize("k,ref_k,n_rows,bits,gate_log2,bin_cap", [(35, 43, 150003, 1 << 33, 14, 0), (35, 43, 120001, 1 << 17, 11, 0), (31, 41, 60002, (1 << 18) + 77, 12, 0),
+                                                                  (35, 43, 150003, 1 << 33, 14, 16), (33, 44, 4, 1 << 20, 12, 0), (35, 43, 2049, 1 << 20, 12, 0)])
+def test_scan_compact_rows_ticket_form(k, ref_k, n_rows, bits, gate_log2, bin_cap):
+    """the ticket form over 12-byte rows (what a whole-genome index takes when the table is resident in its compact form):
+    pass one reads the packed rows, the open list holds row numbers, the probe kernel fetches the 12 bytes of each.
+    Forced on small gates as in test_scan_ticket_form; counters equal the oracle's."""
+    import torch
+    panel = synth.snp_panel(3000, 90 + k)
+    hi, lo, cnt = synth.kmer_table(panel, n_rows, k, ref_k, 91)
+    cnt[:] = 1 + (cnt * 37) % ((1 << (96 - 2 * ref_k)) - 1)
+    with Context(k, ref_k, bits) as ctx:
+        for name, value in [("pregate_log2", 10), ("gate_log2", gate_log2), ("use_tickets", 1), ("ticket_min_log2", 11), ("scan_bin_cap", bin_cap)]:
+            ctx.set_option(name, value)
+        obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
+        ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        dev = torch.device("cuda", 0)
+        d_hi, d_lo = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (hi, lo))
+        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+        d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.kmc_pack_rows_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows, d_rows.data_ptr())
+        ctx.kmc_scan_rows_device(d_rows.data_ptr(), n_rows)
+        ctx.synchronize()
+        assert ctx.get_option("scan_tickets") >= 2
+        assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
+        assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
+        assert map_values_by_key(ctx) == dict(omap.items())

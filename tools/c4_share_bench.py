@@ -23,6 +23,7 @@ ap.add_argument("--rows", type=float, default=3.75e8)
 ap.add_argument("--b", type=int, default=16)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--forms", default="tickets,legacy")
+ap.add_argument("--layout", default="soa", choices=["soa", "compact"], help="table rows as SoA arrays (20 B) or packed 12-byte rows")
 args = ap.parse_args()
 K, R = 35, 43
 n_vars, n_rows = int(args.variants), int(args.rows)
@@ -31,7 +32,7 @@ panel = synth.snp_panel(n_vars, 4242, spacing=40)
 plant = min(n_vars, n_rows // 5 * 2 // 15)          # 7.5 windows per planted variant on average -> 20 % of the rows
 tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
 print("[c4] panel + table: %.0f s, %d site rows (%.1f %%)" % (time.time() - t0, tab.n_site, 100.0 * tab.n_site / n_rows), file=sys.stderr)
-forms = {"tickets": [("use_tickets", 1)], "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
+forms = {"tickets": [("use_tickets", 1)], "tickets_nosync": [("use_tickets", 1), ("ticket_sync", 0)], "tickets_nogate": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 256)], "tickets_synth": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 512)], "tickets_none": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 768)], "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
          # smaller fine gates (more false positives, but inside the 256 MiB Infinity Cache): gate_log2 is fixed before the inserts
          "gate30": [("use_pregate", 0), ("gate_log2", 30)], "gate29": [("use_pregate", 0), ("gate_log2", 29)],
          "gate30k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 30)], "gate29k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 29)],
@@ -44,17 +45,25 @@ for form in args.forms.split(","):
         build_device_index(ctx, panel, K)
         build_s = time.time() - t0
         ms = []
+        d_rows = None
+        if args.layout == "compact":
+            d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.kmc_pack_rows_device(*tab.ptrs(), d_rows.data_ptr())
         for _ in range(args.reps + 1):
             ctx.counters_reset()
             ctx.synchronize()
             t0 = time.perf_counter()
-            ctx.kmc_scan_device(*tab.ptrs())
+            if d_rows is not None:
+                ctx.kmc_scan_rows_device(d_rows.data_ptr(), n_rows)
+            else:
+                ctx.kmc_scan_device(*tab.ptrs())
             ctx.synchronize()
             ms.append(1e3 * (time.perf_counter() - t0))
         f, p, h, n_open, n_hit = ctx.scan_stats()
         first = min(n_rows, 1 << 27)
-        print(json.dumps({"form": form, "variants": n_vars, "rows": n_rows, "b": args.b, "gate_log2": ctx.get_option("gate_log2"),
-                          "pregate_k": ctx.get_option("pregate_k"), "scan_tickets": ctx.get_option("scan_tickets"), "scan_bins": ctx.get_option("scan_bins"),
+        print(json.dumps({"form": form, "layout": args.layout, "variants": n_vars, "rows": n_rows, "b": args.b, "gate_log2": ctx.get_option("gate_log2"),
+                          "pregate_k": ctx.get_option("pregate_k"), "scan_tickets": ctx.get_option("scan_tickets"), "gate_grid": ctx.get_option("ticket_gate_grid"), "scan_bins": ctx.get_option("scan_bins"),
                           "spilled": ctx.get_option("scan_spilled"), "scan_ms_whole_table": round(min(ms[1:]), 3),
                           "first_chunk_rows": first, "first_chunk_ms": {"filter": round(f, 3), "probe": round(p, 3), "hits": round(h, 3)},
                           "filter_frac_of_8TBs": round(44 * first / (f * 1e-3) / 8e12, 3),
