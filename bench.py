@@ -389,7 +389,9 @@ def main():
                        "summary_bitmaps": not args.no_summary,
                        "exchange": ("none" if world == 1 else "%s over %d counters%s" % (
                            exchange, n_bf + n_map, ", 16-bit packed when exact (%d of %d steps)" % (sum(packed_steps), len(packed_steps)) if packed_steps else ""))},
-            "roofline": {"kernel": ("scan_bin_kernel<%s,4> + scan_bin_gate_kernel<%s> (partitioned second level, %d slices)" % (spec, spec, ctx.get_option("scan_bins"))
+            "roofline": {"kernel": ("scan_ticket_sort_kernel<%s> + scan_ticket_gate_kernel (ticket form, %d gate slices; the two passes summed)" % (spec, ctx.get_option("scan_tickets"))
+                                    if ctx.get_option("scan_tickets") else
+                                    "scan_bin_kernel<%s,4> + scan_bin_gate_kernel<%s> (partitioned second level, %d slices)" % (spec, spec, ctx.get_option("scan_bins"))
                                     if ctx.get_option("scan_bins") else ("scan_filter12_kernel<%s>" if compact else "scan_filter_kernel<%s,2>") % spec), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/%s (rocprofv3 PMC)" % tname if traffic else None,
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,

@@ -100,12 +100,12 @@ struct mg_ctx {
     int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
     int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
     int probe_grid = 2048, hits_grid = 1024; // workgroups of the two list kernels (swept)
-    int use_tickets = 0;     // gates beyond L2: file 8-byte tickets by gate slice instead of probing HBM at random (scan_ticket_kernel);
-                             // measured slower than the direct forms at both 1e7 and 8e7 SNPs (profiles/r02_c4share_forms.txt): off, kept for A/B
-    int tkg_grid = 0;         // pass two's grid: the workgroups the device keeps resident together (found at first use)
-    int ticket_sync = 1;      // pass two: the workgroups of an XCD meet (bounded wait) before they move to the next gate slice
-    int ticket_sort = 1;      // pass one sorts tiles in LDS (scan_ticket_sort_kernel) instead of keeping a ring per slice
-    int ticket_min_log2 = 26; // smallest fine gate (log2 bits) that takes the ticket form
+    int use_tickets = 1;      // gates of 2^ticket_min_log2 bits and more: 8-byte tickets filed by 2 MiB gate slice, the slices then walked out of L2
+                              // (scan_ticket_sort_kernel + scan_ticket_gate_kernel) instead of one random HBM sector per table row
+    int tkg_grid = 0;         // pass two's grid: one workgroup per CU (found at first use)
+    int ticket_sync = 0;      // pass two: the workgroups of an XCD meet (bounded wait) before they move to the next gate slice; measured: no gain
+    int ticket_min_log2 = 28; // smallest fine gate (log2 bits) that takes the ticket form: 32 MiB.  Measured on a C4 share (3.75e8 rows, compact rows):
+                              // 16 MiB gate 3.6 ms two-level direct / 4.8 tickets; 32 MiB 7.7 / 6.2; 256 MiB 9.3 / 7.3 (profiles/r02_c4share_forms.txt)
     Scratch s_tk[2];
     unsigned long long *d_tk_meta = nullptr; // spill count, then u32 [TK_MAXP][BIN_SEGS] segment fills
     int bin_ring = 0, bin_rows = 4; // A/B: staging ring per bin (0 = as large as LDS allows), rows per thread of the binning kernel
@@ -583,7 +583,6 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
-    else if (!strcmp(name, "ticket_sort")) c->ticket_sort = value != 0;
     else if (!strcmp(name, "ticket_sync")) c->ticket_sync = value != 0;
     else if (!strcmp(name, "ticket_gate_grid")) c->tkg_grid = value > 0 ? (int)std::max<int64_t>(8, std::min<int64_t>(4096, value / 8 * 8)) : 0;
     else if (!strcmp(name, "hits_grid")) c->hits_grid = value > 0 ? (int)value : 1024;
@@ -950,11 +949,8 @@ int ticket_layout(mg_ctx *c, u64 cap, u32 row_bits, TicketSet *out)
     tks.word_shift = (u32)(c->pregate_log2 - 1 - 6);
     tks.row_bits = row_bits;
     tks.nseg = (u32)std::min<u64>((cap + 4 * TPB - 1) / (4 * TPB), BIN_SEGS);
-    const u64 tile = c->ticket_sort ? TK_TILE : 4 * TPB; // rows a workgroup takes at a time
-    const u64 wg_rows = ((cap + tile - 1) / tile + tks.nseg - 1) / tks.nseg * tile;
+    const u64 wg_rows = ((cap + TK_TILE - 1) / TK_TILE + tks.nseg - 1) / tks.nseg * TK_TILE; // a workgroup takes whole tiles
     tks.segcap = c->bin_cap ? c->bin_cap : ((wg_rows / TP) * 3 / 2 + 64 + 15) / 16 * 16; // 1.5x an even share, whole 128-byte lines
-    tks.ring = 16;
-    while (tks.ring < 64 && tks.ring * 2 * TP <= (u64)TK_LDS_TICKETS) tks.ring *= 2;
     void *q[2];
     TRY(scratch(c, c->s_tk[0], TP * tks.nseg * tks.segcap * 8, &q[0]));
     TRY(scratch(c, c->s_tk[1], cap * 8, &q[1]));
@@ -991,12 +987,8 @@ void launch_ticket_passes(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32
 {
     TicketSet ts = layout;
     ts.nseg = (u32)std::min<u64>((n + 4 * TPB - 1) / (4 * TPB), layout.nseg);
-    if (c->ticket_sort || rows12)
-        hipLaunchKernelGGL((scan_ticket_sort_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), 0, c->stream, d_hi, d_lo, rows12, n, (int)c->k, (int)c->ref_k,
-                           view(c, MG_BF_ALT), ts);
-    else
-        hipLaunchKernelGGL((scan_ticket_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), (size_t)ts.nbins * ts.ring * 8, c->stream, d_hi, d_lo, n, (int)c->k,
-                           (int)c->ref_k, view(c, MG_BF_ALT), ts);
+    hipLaunchKernelGGL((scan_ticket_sort_kernel<KC, RC>), dim3(ts.nseg), dim3(TPB), 0, c->stream, d_hi, d_lo, rows12, n, (int)c->k, (int)c->ref_k,
+                       view(c, MG_BF_ALT), ts);
     if (!c->tkg_grid) { // pass two walks the slices in step: one workgroup per CU, all resident together
         int cus = 0, dev = 0;
         hipGetDevice(&dev);

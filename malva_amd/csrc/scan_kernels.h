@@ -540,7 +540,6 @@ __global__ void __launch_bounds__(TPB) scan_bin_gate_kernel(int k_rt, int r_rt, 
 // Traffic per row: 16 (stream) + 8 (ticket out) + 8 (ticket in) = 32 B sequential and one L2 probe, against
 // 20 B + one random HBM line (4-5x an L2 read).
 constexpr int TK_MAXP = 256;       // slices: fine gates up to 512 MiB
-constexpr int TK_LDS_TICKETS = 4096; // staging tickets per workgroup over all slices (32 KB)
 struct TicketSet {
     u64 *tickets;               // [nbins][nseg] segments of `segcap` tickets
     u32 *counts;                // [nbins][nseg]
@@ -548,116 +547,15 @@ struct TicketSet {
     unsigned long long *spill_count;
     u64 segcap;
     u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift
-    u32 ring;                    // staging tickets per bin (power of two); tickets leave in units of ring / 2
     u32 row_bits;                // ticket = idx << row_bits | row
     u32 *sync;                   // [8][TK_MAXP / 8] arrivals per XCD and round of pass two (zeroed before every launch); null = no rendezvous
 };
 
-template <int KC, int RC>
-__global__ void __launch_bounds__(TPB) scan_ticket_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, u64 n, int k_rt, int r_rt, BFView bf,
-                                                          TicketSet ts)
-{
-    constexpr int ROWS = 4;
-    extern __shared__ u64 sh_tk[]; // nbins * ring tickets
-    __shared__ u32 sh_n[TK_MAXP], sh_head[TK_MAXP], sh_pos[TK_MAXP]; // staged so far / flushed so far / tickets in the segment
-    __shared__ u32 sh_lut[256];
-    const int P = (int)ts.nbins;
-    const u32 ring = ts.ring, unit = ring / 2;
-    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
-    const int off = (r - k) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    ascii_lut_fill(sh_lut);
-    for (int b = threadIdx.x; b < P; b += TPB) sh_n[b] = sh_head[b] = sh_pos[b] = 0;
-    __syncthreads();
-    // every thread of the workgroup calls this, between barriers; `all`: also the last partial unit of every bin
-    auto flush_bins = [&](bool all) {
-        for (int b = wave; b < P; b += TPB / 64) {
-            const u32 head = sh_head[b];
-            const u32 staged = min(sh_n[b], head + ring); // lanes that found the ring full bumped the counter past it
-            const u32 c = all ? staged - head : (staged - head) / unit * unit;
-            if (lane == 0) sh_n[b] = staged;
-            if (c == 0) continue;
-            const u32 pos = sh_pos[b];
-            u64 *dst = ts.tickets;
-            unsigned long long at = ((unsigned long long)b * ts.nseg + blockIdx.x) * ts.segcap + pos;
-            const bool fits = pos + c <= ts.segcap;
-            if (!fits) { // the segment is full: this flush goes to the spill list
-                if (lane == 0) at = atomicAdd(ts.spill_count, (unsigned long long)c);
-                at = __shfl(at, 0, 64);
-                dst = ts.spill;
-            }
-            for (u32 o = lane; o < c; o += 64) dst[at + o] = sh_tk[b * ring + ((head + o) & (ring - 1))];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                sh_head[b] = head + c;
-                if (fits) sh_pos[b] = pos + c;
-            }
-        }
-    };
-    typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
-    const bool vec_ok = ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
-    const u64 step = (u64)gridDim.x * TPB * ROWS;
-    for (u64 base = (u64)blockIdx.x * TPB * ROWS; base < n; base += step) {
-        U128 m[ROWS];
-        u64 tk[ROWS];
-        u32 bin[ROWS];
-        bool pending[ROWS];
-        // A: rows base + {2t, 2t+1} and base + 2 TPB + {2t, 2t+1}: two 16-byte loads per array and thread (counts are not read here)
-#pragma unroll
-        for (int g = 0; g < ROWS / 2; ++g) {
-            const u64 i = base + (u64)g * 2 * TPB + 2 * (u64)threadIdx.x;
-            if (vec_ok && i + 1 < n) {
-                const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
-                const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
-                m[2 * g] = U128{l2.x, h2.x};
-                m[2 * g + 1] = U128{l2.y, h2.y};
-                pending[2 * g] = pending[2 * g + 1] = true;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    pending[2 * g + j] = i + j < n;
-                    m[2 * g + j].lo = pending[2 * g + j] ? __builtin_nontemporal_load(lo + i + j) : 0;
-                    m[2 * g + j].hi = pending[2 * g + j] ? __builtin_nontemporal_load(hi + i + j) : 0;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { // B: canonical centre k-mer, XXH3, slot -> ticket
-            const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
-            const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
-            const u64 row = base + (u64)(j / 2) * 2 * TPB + 2 * (u64)threadIdx.x + (j & 1);
-            tk[j] = (idx << ts.row_bits) | row;
-            bin[j] = (u32)(gate_word(bf, idx) >> ts.word_shift);
-        }
-        // C: tickets into their bin's ring; a full ring defers the lane until the flush that follows
-        bool again;
-        do {
-            bool mine = false;
-#pragma unroll
-            for (int j = 0; j < ROWS; ++j)
-                if (pending[j]) {
-                    const u32 slot = atomicAdd(&sh_n[bin[j]], 1u);
-                    if (slot - sh_head[bin[j]] < ring) {
-                        sh_tk[bin[j] * ring + (slot & (ring - 1))] = tk[j];
-                        pending[j] = false;
-                    } else
-                        mine = true;
-                }
-            again = __syncthreads_or(mine);
-            flush_bins(false);
-            __syncthreads();
-        } while (again);
-    }
-    flush_bins(true);
-    __syncthreads();
-    for (int b = threadIdx.x; b < P; b += TPB) ts.counts[b * ts.nseg + blockIdx.x] = sh_pos[b];
-}
-
-// Pass one, second form: a tile of TK_TILE rows is SORTED by gate slice in LDS (one returning LDS atomic per row gives
-// its rank inside its slice, a prefix sum over the slices gives the slice's place in the tile) and leaves as runs of
-// consecutive tickets, every lane of every wave storing -- instead of rings flushed slice by slice by a quarter of a
-// wave.  The rings cost a scan over up to 256 slices per 1,024 rows and 16-lane stores (measured 2.0 ms per 1.3e8 rows at
-// 128 slices: nowhere near the 24 B/row it moves).
+// Pass one: a tile of TK_TILE rows is SORTED by gate slice in LDS (one returning LDS atomic per row gives its rank inside
+// its slice, a prefix sum over the slices gives the slice's place in the tile) and leaves as runs of consecutive tickets
+// into segments the workgroup owns (no global atomics), every lane of every wave storing.  1.0 ms per 1.3e8 rows: the
+// hashing's VALU time, as in the filter kernel.  (First form: an LDS ring per slice, flushed slice by slice by a quarter
+// of a wave: a scan over up to 256 slices per 1,024 rows and 16-lane stores, 2.0 ms.)
 constexpr int TK_TILE_ROWS = 8;                  // rows per thread and tile
 constexpr int TK_TILE = TPB * TK_TILE_ROWS;      // 2,048 rows: 16 tickets per slice on average at 128 slices
 // The table is either the SoA arrays (hi, lo) or, when `rows12` is not null, the compact 12-byte rows of scan_filter12_kernel.
@@ -785,7 +683,7 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
 // times what the L2 gather costs.)  Survivors are listed by row number alone: the probe kernel, which has no stream to
 // disturb, fetches the rows.  Placement only decides speed, never the result.
 constexpr int TKG_TPB = 256, TKG_U = 8, TKG_SPW = 64; // threads per workgroup; tickets per thread and step; segments of one slice per walk
-constexpr int TKG_WSTAGE = 5120;                       // staged survivors per wave (4 waves: 80 KB, so a CU holds exactly one workgroup)
+constexpr int TKG_WSTAGE = 4096;                       // staged survivors per wave (4 waves: 64 KB)
 // GK: the gate's bits per entry fixed at compile time (0 = read from the view)
 template <int GK>
 __global__ void __launch_bounds__(TKG_TPB) scan_ticket_gate_kernel(BFView bf, TicketSet ts, u32 *__restrict__ open_rows, unsigned long long *counters)

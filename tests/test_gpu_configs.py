@@ -144,31 +144,48 @@ def test_c3_full_size_1e8_rows_1e6_snps_b4():
         assert (g1 + g2 > 0).sum() > 1000
 
 
-@pytest.mark.parametrize("n_vars,expect", [(10_000_000, "two-level"), (10_000_000, "tickets"), (80_000_000, "saturated")])
+@pytest.mark.parametrize("n_vars,expect", [(10_000_000, "tickets"), (10_000_000, "two-level"), (80_000_000, "tickets-compact"), (80_000_000, "saturated")])
 def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
-    """one GPU's eighth of config C4 (3e9 k-mers / 8) against the replicated index; 38-40 nt spacing as SURVEY 8(d)"""
+    """one GPU's eighth of config C4 (3e9 k-mers / 8) against the replicated index; 38-40 nt spacing as SURVEY 8(d).
+    `tickets` is what the library picks by itself for gates of 32 MiB and more; the forms it replaced stay as options."""
     n_rows, bits, plant = 375_000_000, 16 << 33, 1_000_000
     panel = synth.snp_panel(n_vars, 4242, spacing=40)
     tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
     with Context(K, R, bits) as ctx:
-        if expect == "tickets":
-            ctx.set_option("use_tickets", 1)
+        if not expect.startswith("tickets"):
+            ctx.set_option("use_tickets", 0)
         build_device_index(ctx, panel, K)
         counters, n_bf, n_map = counters_tensor(ctx)
         assert n_map == n_vars
-        _scan(ctx, tab)
+        d_rows = None
+        if expect == "tickets-compact":  # the table resident as 12-byte rows: what bench.py --strong scans at this size
+            d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.kmc_pack_rows_device(*tab.ptrs(), d_rows.data_ptr())
+
+        def scan(a=0, b=None):
+            if d_rows is None:
+                return _scan(ctx, tab, a, b)
+            b = n_rows if b is None else b
+            assert a % 4 == 0                                                             # packed rows start on whole quads
+            torch.cuda.synchronize()
+            ctx.kmc_scan_rows_device(d_rows[3 * a:].data_ptr(), b - a)
+            ctx.synchronize()
+        scan()
         whole = _snap(counters)
         if expect == "two-level":        # 32 MiB fine gate -> 4 MiB coarse gate in front, survivors partitioned by fine-gate slice
             assert ctx.get_option("pregate_k") >= 1 and ctx.get_option("gate_log2") == 28 and ctx.get_option("scan_bins") == 16
-        elif expect == "tickets":        # the A/B form: one 8-byte ticket per row filed under its 2 MiB gate slice
-            assert ctx.get_option("scan_tickets") == 16 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_spilled") == 0
+        elif expect == "tickets":        # one 8-byte ticket per row filed under its 2 MiB gate slice
+            assert ctx.get_option("gate_log2") == 28 and ctx.get_option("scan_tickets") == 16 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_spilled") == 0
+        elif expect == "tickets-compact":
+            assert ctx.get_option("gate_log2") == 31 and ctx.get_option("scan_tickets") == 128 and ctx.get_option("scan_spilled") == 0
         else:                            # 1.6e8 entries saturate a 4 MiB coarse gate: decided at finalize, scans go straight to the 256 MiB gate
-            assert ctx.get_option("pregate_k") == 0 and ctx.get_option("gate_log2") == 31 and ctx.get_option("scan_bins") == 0
+            assert ctx.get_option("pregate_k") == 0 and ctx.get_option("gate_log2") == 31 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_tickets") == 0
         _check_expected(ctx, panel, tab, whole, n_bf, n_check=plant)
-        _scan(ctx, tab)
+        scan()
         assert torch.equal(counters, whole * 2)                                           # linearity
-        ctx.counters_reset(); _scan(ctx, tab, 0, 150_000_000); first = _snap(counters)
-        ctx.counters_reset(); _scan(ctx, tab, 150_000_000, n_rows)
+        ctx.counters_reset(); scan(0, 150_000_000); first = _snap(counters)
+        ctx.counters_reset(); scan(150_000_000, n_rows)
         assert torch.equal(first + counters, whole)                                       # shard sum (uneven shards, chunk seams inside both)
 
 
