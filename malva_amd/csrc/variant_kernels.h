@@ -267,6 +267,12 @@ struct BkChains {
 };
 
 // get_combs_on_the_right (step +1) / _left (step -1); indices are batch-global variant indices inside [b0, b1)
+// VB::are_near (var_block.hpp:417-423) in the reference's arithmetic.  It writes  int + ... + ceil((float)k / 2) >= int
+// under `using namespace std`: ceil is the float overload, so the int sum is CONVERTED TO FLOAT, the addition rounds to
+// float and the right side is compared as a float.  Exact below 2^24; beyond (most of a human chromosome) positions are
+// rounded to multiples of 2..16 and the answer differs from the exact one now and then, in both directions.
+__device__ __forceinline__ bool near_f32(int lhs_sum, int k, int rhs_pos) { return (float)lhs_sum + ceilf((float)k / 2) >= (float)rhs_pos; }
+
 __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
 {
     const int k = B.k;
@@ -276,7 +282,7 @@ __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, 
     };
     auto nr = [&](int x, int y, int extra) {
         const int l = step > 0 ? x : y, r = step > 0 ? y : x;
-        return B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra + (k + 1) / 2 >= B.pos[r];
+        return near_f32(B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra, k, B.pos[r]);
     };
     out->n = 0;
     bool halt = false;
@@ -289,8 +295,10 @@ __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, 
         if (sorted) {
             int max_sum = 0;
             for (int c = 0; c < out->n; ++c) max_sum = max(max_sum, out->sum[c]);
-            if (step > 0 ? B.pos[j] > B.pos[i] + (int)B.ref_size[i] - (int)B.min_size[i] - 1 + max_sum + (k + 1) / 2
-                         : B.pos[j] + max_gain - 1 + max_sum + (k + 1) / 2 < B.pos[i])
+            // (the same float test as `nr`, on the largest left side any chain can still present: it is monotone in both
+            // arguments, so beyond the first position it rejects it rejects everything)
+            if (step > 0 ? !near_f32(B.pos[i] + (int)B.ref_size[i] - (int)B.min_size[i] - 1 + max_sum, k, B.pos[j])
+                         : !near_f32(B.pos[j] + max_gain - 1 + max_sum, k, B.pos[i]))
                 break;
         }
         if (!B.present[j]) continue;

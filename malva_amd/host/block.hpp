@@ -6,6 +6,7 @@
 // blocks that hold one short-allele variant bypass it (mg_call_isolated).
 #pragma once
 #include <climits>
+#include <cmath>
 #include <exception>
 #include <set>
 #include <thread>
@@ -38,11 +39,13 @@ class Block {
 
     // var_block.hpp:408-412
     static bool overlapping(const Variant &a, const Variant &b) { return a.ref_pos <= b.ref_pos && b.ref_pos < a.ref_pos + a.ref_size; }
-    // var_block.hpp:417-423: v1.pos + v1.ref_size - v1.min_size - 1 + extra + ceil(k/2) >= v2.pos
-    bool near(const Variant &a, const Variant &b, int extra = 0) const
-    {
-        return a.ref_pos + a.ref_size - a.min_size - 1 + extra + (k + 1) / 2 >= b.ref_pos;
-    }
+    // var_block.hpp:417-423: v1.pos + v1.ref_size - v1.min_size - 1 + extra + ceil((float)k / 2) >= v2.pos -- in the
+    // reference's arithmetic: under `using namespace std` that ceil is the float overload, so the int sum is converted
+    // to FLOAT, the addition rounds to float and v2.pos is compared as a float.  Exact below 2^24; beyond (most of a
+    // human chromosome) positions are rounded to multiples of 2..16 and the answer differs from the exact one now and
+    // then, in both directions.  Monotone in both arguments (what the walk's early stop relies on).
+    static bool near_f32(int lhs_sum, int k, int rhs_pos) { return (float)lhs_sum + std::ceil((float)k / 2) >= (float)rhs_pos; }
+    bool near(const Variant &a, const Variant &b, int extra = 0) const { return near_f32(a.ref_pos + a.ref_size - a.min_size - 1 + extra, k, b.ref_pos); }
     bool near_to_last(const Variant &v) const { return near(vars.back(), v); } // var_block.hpp:77-80
 
     // One variant, every allele shorter than k: the only chain is the variant itself and each allele
@@ -73,8 +76,8 @@ class Block {
             if (px && px->sorted) {
                 int max_sum = 0;
                 for (int s_ : sums) max_sum = std::max(max_sum, s_);
-                if (step > 0 ? cur.ref_pos > mid.ref_pos + mid.ref_size - mid.min_size - 1 + max_sum + (k + 1) / 2
-                             : cur.ref_pos + px->max_gain - 1 + max_sum + (k + 1) / 2 < mid.ref_pos)
+                if (step > 0 ? !near_f32(mid.ref_pos + mid.ref_size - mid.min_size - 1 + max_sum, k, cur.ref_pos)
+                             : !near_f32(cur.ref_pos + px->max_gain - 1 + max_sum, k, mid.ref_pos))
                     break;
             }
             if (!cur.is_present) continue;

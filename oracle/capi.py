@@ -23,6 +23,7 @@ def lib():
         sig = {
             "mo_xxh3_64": (u64, [vp, sz]),
             "mo_canonical": (None, [cp, C.c_int, vp]),
+            "mo_are_near": (C.c_int, [C.c_int] * 6),
             "mo_bf_new": (vp, [u64]),
             "mo_bf_free": (None, [vp]),
             "mo_bf_hash": (u64, [cp]),
@@ -79,6 +80,11 @@ def canonical(kmer: bytes) -> bytes:
     buf = C.create_string_buffer(len(kmer) + 1)
     lib().mo_canonical(kmer, len(kmer), buf)
     return buf.raw[: len(kmer)]
+
+
+def are_near(v1_ref_pos: int, v1_ref_size: int, v1_min_size: int, sum_to_add: int, k: int, v2_ref_pos: int) -> bool:
+    """VB::are_near in the reference's float arithmetic (var_block.hpp:417-423)"""
+    return bool(lib().mo_are_near(v1_ref_pos, v1_ref_size, v1_min_size, sum_to_add, k, v2_ref_pos))
 
 
 def rows_from_kmers(kmers, stride=None):

@@ -470,6 +470,23 @@ MO_API void mo_kmc_scan_packed(mo_bf *context_bf, mo_bf *bf, mo_kmap *ref_bf, co
  * SURVEY 8(d)(ii), next to the single-threaded one that mirrors the reference.  Both counter updates are wrapping
  * sums (Appendix A.2), so they commute; the threads share the read-only bits / rank / keys and add atomically.
  * Results are identical to mo_kmc_scan_packed (tests/test_oracle_pins.py). */
+/* ------------------------------------------------------------------------- */
+/* VB::are_near, var_block.hpp:417-423.                                       */
+/* The reference writes                                                       */
+/*   v1.ref_pos + v1.ref_size - v1.min_size - 1 + sum_to_add                  */
+/*       + ceil((float)k / 2) >= v2.ref_pos                                   */
+/* with `using namespace std`: ceil(float) is the float overload, so the int   */
+/* sum on its left is converted to FLOAT, the addition rounds to float, and    */
+/* v2.ref_pos is converted to float for the comparison.  Below 2^24 that is    */
+/* integer arithmetic; above (most of every human chromosome) positions are    */
+/* rounded to multiples of 2, 4, 8, 16 and the answer can differ from the      */
+/* exact one in both directions.  Written with the same operand types, so the  */
+/* C compiler applies the same conversions (ceilf = C++'s std::ceil(float)).   */
+MO_API int mo_are_near(int v1_ref_pos, int v1_ref_size, int v1_min_size, int sum_to_add, int k, int v2_ref_pos)
+{
+    return v1_ref_pos + v1_ref_size - v1_min_size - 1 + sum_to_add + ceilf((float)k / 2) >= v2_ref_pos;
+}
+
 #include <pthread.h>
 typedef struct {
     mo_bf *context_bf, *bf;

@@ -21,6 +21,11 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 
+def _F32(x) -> float:
+    """x rounded to IEEE binary32 (round to nearest even), as a C cast to float rounds an int or a double"""
+    return struct.unpack("f", struct.pack("f", float(x)))[0]
+
+
 def f32(x: float) -> float:
     """round a Python float to IEEE binary32 and back (the reference stores `float`)."""
     return struct.unpack("<f", struct.pack("<f", x))[0]
@@ -261,9 +266,13 @@ class VB:
     def are_overlapping(v1: Variant, v2: Variant) -> bool:
         return v1.ref_pos <= v2.ref_pos < v1.ref_pos + v1.ref_size
 
-    # var_block.hpp:417-423 (ceil((float)k/2) is exact for any sane k)
+    # var_block.hpp:417-423.  `int + ... + ceil((float)k / 2) >= int` under `using namespace std`: ceil is the FLOAT
+    # overload, so the int sum is converted to float, the addition rounds to float and v2.ref_pos is compared as a
+    # float.  Exact below 2^24; beyond that positions are rounded to multiples of 2, 4, 8, 16 (most of a human
+    # chromosome) and the answer differs from the exact one now and then, in both directions.
     def are_near(self, v1: Variant, v2: Variant, extra: int = 0) -> bool:
-        return v1.ref_pos + v1.ref_size - v1.min_size - 1 + extra + math.ceil(self.k / 2) >= v2.ref_pos
+        lhs = _F32(_F32(v1.ref_pos + v1.ref_size - v1.min_size - 1 + extra) + _F32(math.ceil(self.k / 2)))
+        return bool(lhs >= _F32(v2.ref_pos))
 
     def is_near_to_last(self, v: Variant) -> bool:  # var_block.hpp:77-80
         return self.are_near(self.variants[-1], v)

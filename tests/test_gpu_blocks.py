@@ -114,6 +114,64 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
     ctx.close()
 
 
+@pytest.mark.parametrize("haploid", [False, True])
+def test_positions_beyond_2_to_the_25_float_near(tmp_path, haploid):
+    """Chain walks on the device at positions where the reference's `are_near` runs in float (var_block.hpp:417-423: the
+    int sum is promoted by ceil((float)k / 2)): 35 Mb contig, clusters beyond 2^25 with gaps around the threshold.  The
+    blocks are cut by the oracle (float too); inside them the device must find the oracle's chains -- an integer
+    walk finds others (tests/test_host_enumerator_cpu.py shows 781 blocks against 666 on the same case)."""
+    k, ref_k, bits = 35, 43, 1 << 24
+    prefix = str(tmp_path / "far")
+    seq, records, pairs = vcf_synth.make_far_case(prefix, 12, haploid=haploid)
+    assert pairs > 30
+    opt = pipeline.Options(haploid=haploid, k=k, ref_k=ref_k, bf_size=bits)
+    refs = {"1": seq}
+    blocks, vks = [], []
+    for vb, reference, _ in pipeline._blocks(VCFReader(prefix + ".vcf", "-"), opt, refs, False):
+        if vb is None:
+            break
+        blocks.append((vb, "1"))
+        vks.append(vb.extract_kmers(reference, haploid))
+    assert sum(len(vb.variants) > 1 for vb, _ in blocks) > 200
+    # an index straight from the signatures (no reference scan needed here) with made-up weights
+    obf, omap = ocapi.BF(bits), ocapi.KMAP()
+    for km in vks:
+        for per in km.values():
+            for a, sigs in per.items():
+                for sig in sigs:
+                    for s_ in sig:
+                        (omap if a == 0 else obf).add_key(s_.encode())
+    obf.switch_mode()
+    for km in vks:
+        for per in km.values():
+            for a, sigs in per.items():
+                for sig in sigs:
+                    for s_ in sig:
+                        w = 1 + ocapi.xxh3_64(s_.encode()) % 97
+                        if a == 0:
+                            omap.increment(s_.encode(), w)
+                        else:
+                            obf.increment(s_.encode(), w)
+    want = []
+    for (vb, _), km in zip(blocks, vks):
+        ks, is_ref, so, ao = flatten_vk(km, [len(v.alts) + 1 for v in vb.variants])
+        w = ocapi.lookup_weights(obf, omap, ocapi.rows_from_kmers(ks)[0], np.array(is_ref, np.uint8)) if ks else np.zeros(0, np.int32)
+        want.append(ocapi.set_coverages(w, so, ao))
+    want = np.concatenate(want)
+    with Context(k, ref_k, bits) as ctx:
+        ctx.bf_import_sparse(BF_ALT, 1, bits, obf.set_positions(), obf.counts())
+        ctx.bf_import_sparse(BF_CTX, 1, bits, np.zeros(0, np.uint64), np.zeros(0, np.uint16))
+        items = list(omap.items())
+        ctx.map_import([k_ for k_, _ in items], np.array([v for _, v in items], dtype=np.int32))
+        ctx.reference_upload(seq.encode())
+        args = pack_blocks(blocks, {"1": 0}, {"1": len(seq)})
+        cov, ovf = ctx.cover_blocks(**args, haploid=haploid)
+    ok = np.repeat(ovf == 0, np.diff(np.array(args["var_allele_off"])))
+    assert ok.mean() > 0.95
+    assert np.array_equal(cov[ok], want[ok])
+    assert (want[ok] > 0).sum() > 1000
+
+
 @pytest.mark.parametrize("seed,haploid,k,ref_k,dense", [(61, False, 35, 43, False), (62, True, 35, 43, False), (63, False, 31, 41, False),
                                                         (64, False, 35, 63, False), (65, False, 35, 43, True), (66, True, 35, 43, True)])
 def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k, dense):

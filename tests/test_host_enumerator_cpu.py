@@ -69,6 +69,21 @@ def test_clustered_variants(tmp_path, seed, haploid, k, strip):
         assert "," in want.split("SIG", 1)[1]            # ... and so does the sliding (allele >= k) signature
 
 
+@pytest.mark.parametrize("haploid", [False, True])
+def test_positions_beyond_2_to_the_25_float_near(tmp_path, haploid):
+    """Beyond 2^24 the reference's `are_near` no longer computes in integers (float promotion, var_block.hpp:417-423):
+    block cuts and chain walks of the C++ host enumerator must follow it -- the case holds dozens of neighbour pairs on
+    which the float answer and the exact one differ, in both directions."""
+    prefix = str(tmp_path / "far")
+    _, records, pairs = vcf_synth.make_far_case(prefix, 11, haploid=haploid)
+    assert pairs > 30
+    opt = pipeline.Options(haploid=haploid)
+    for for_index in (True, False):
+        want = oracle_dump(prefix + ".fa", prefix + ".vcf", opt, for_index)
+        assert cli_dump(prefix + ".fa", prefix + ".vcf", opt, for_index) == want
+    assert want.count("BLOCK") > 400
+
+
 def _write_case(tmp_path, gt_rows, samples, fmt="GT", seed=7, spacing=9):
     import numpy as np
     rng = np.random.default_rng(seed)

@@ -106,3 +106,56 @@ def donor_table(contigs, records, ref_k, seed, path):
         for km, c in sorted(counts.items()):
             if c >= 2:
                 fh.write("%s\t%d\n" % (km.decode(), min(c, 255)))
+
+
+def make_far_case(path_prefix, seed, k=35, base=1 << 25, span=1_500_000, n_clusters=400, n_samples=4, haploid=False):
+    """One contig longer than 2^25 bases with clusters of SNPs and short indels BEYOND position 2^25, where the
+    reference's `are_near` (float arithmetic, var_block.hpp:417-423) stops agreeing with integer arithmetic: gaps
+    between neighbours are drawn around the k/2 threshold.  Returns (contig sequence, records, pairs) with `pairs` =
+    the number of adjacent record pairs on which the float test and the exact one disagree."""
+    import struct
+    rng = np.random.default_rng(seed)
+    length = base + span
+    g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length)
+    seq = bytes(g).decode()
+    half = (k + 1) // 2
+    records = []
+    pos = base + 1000
+    for _ in range(n_clusters):
+        pos += int(rng.integers(200, (span - 4000) // n_clusters))
+        p = pos
+        for _ in range(int(rng.integers(2, 5))):
+            kind = rng.integers(0, 10)
+            ref_len = 1 if kind < 7 else int(rng.integers(2, 7))
+            ref = seq[p:p + ref_len]
+            alen = 1 if rng.random() < 0.7 else int(rng.integers(1, 7))
+            alt = "".join(rng.choice(list("ACGT"), size=alen))
+            if alt == ref:
+                alt = ("A" if ref[0] != "A" else "C") + alt[1:]
+            records.append(("1", p, ref, [alt]))
+            min_size = min(ref_len, len(alt))
+            p += ref_len - min_size - 1 + half + int(rng.integers(-5, 6))      # the next one lands around this one's reach
+            p = max(p, records[-1][1] + ref_len)                                # (never overlapping: keeps the chains simple)
+    f32 = lambda x: struct.unpack("f", struct.pack("f", float(x)))[0]
+    pairs = 0
+    for (_, p1, r1, a1), (_, p2, _, _) in zip(records, records[1:]):
+        lhs = p1 + len(r1) - min(len(r1), len(a1[0])) - 1
+        pairs += (f32(f32(lhs) + f32(half)) >= f32(p2)) != (lhs + half >= p2)
+    samples = ["S%d" % i for i in range(n_samples)]
+    with open(path_prefix + ".fa", "w") as fh:
+        fh.write(">1\n")
+        for i in range(0, length, 1 << 20):
+            fh.write(seq[i:i + (1 << 20)] + "\n")
+    with open(path_prefix + ".vcf", "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"af\">\n"
+                 "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##contig=<ID=1,length=%d>\n" % length)
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n")
+        for name, p, ref, alts in records:
+            if haploid:
+                gts = [str(int(rng.integers(0, 2))) for _ in samples]
+            else:
+                gts = ["%d%s%d" % (rng.integers(0, 2), "|" if rng.random() < 0.8 else "/", rng.integers(0, 2)) for _ in samples]
+            if not any("1" in g_ for g_ in gts):
+                gts[0] = "1" if haploid else "1|0"
+            fh.write("%s\t%d\t.\t%s\t%s\t.\t.\tAF=%.3f\tGT\t%s\n" % (name, p + 1, ref, ",".join(alts), 0.1 + 0.5 * rng.random(), "\t".join(gts)))
+    return seq, records, pairs
