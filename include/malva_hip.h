@@ -291,7 +291,7 @@ int mg_debug_packed_index(mg_ctx *ctx, int which, const uint64_t *hi, const uint
                           uint64_t *idx_out);
 /* timing of the first chunk of the most recent mg_kmc_scan* in milliseconds (HIP
  * events on the context's stream): ms_out[0] filter kernel, [1] probe kernel,
- * [2] hit kernel; rows_out[0] = rows that passed the gate (last chunk),
+ * [2] hit kernel (with the ticket form [0] is its two passes together); rows_out[0] = rows that passed the gate (last chunk),
  * rows_out[1] = rows whose bf bit was set (whole call) */
 int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *rows_out);
 /* 0 disables the cache-resident summary bitmaps (A/B switch; results identical) */
