@@ -211,14 +211,20 @@ def main():
             # exchange is mg_counters_allreduce on the library's stream.  If the library cannot bring RCCL up on
             # this node the run still measures (torch's RCCL, same collective) and the JSON line says so.
             from malva_amd import capi
-            try:
-                uid = [capi.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init(rank, world, uid[0])
-                ok = torch.ones(1, dtype=torch.int32, device=dev)
-            except Exception as e:          # noqa: BLE001 -- reported, never silent
-                log(0, "rank %d: native exchange unavailable (%s)" % (rank, e))
-                ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            uid = [None]
+            if rank == 0:                   # (a failure here must not leave the other ranks waiting in the broadcast)
+                try:
+                    uid = [capi.comm_unique_id()]
+                except Exception as e:      # noqa: BLE001 -- reported, never silent
+                    log(0, "rank 0: native exchange unavailable (%s)" % e)
+            dist.broadcast_object_list(uid, src=0)
+            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            if uid[0] is not None:
+                try:
+                    ctx.comm_init(rank, world, uid[0])
+                    ok = torch.ones(1, dtype=torch.int32, device=dev)
+                except Exception as e:      # noqa: BLE001
+                    print("[bench] rank %d: native exchange unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 exchange = "mg_counters_allreduce: ncclAllReduce(sum,uint32) inside libmalva_hip.so, in place"
