@@ -195,6 +195,16 @@ int mg_lookup_cover(mg_ctx *ctx, const char *rows, size_t stride, size_t n_rows,
                     const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
                     uint32_t *cov_out);
 
+/* Block cutting of the record loops (main.cpp:341, 547: `!vb.is_near_to_last(v) || last_seq_name != v.seq_name`, with
+ * VB::is_near_to_last = are_near(last variant, v), var_block.hpp:77-80, 417-423 -- in the reference's float arithmetic) for
+ * a batch of n_vars KEPT records in file order, on the device.  contig_id[i] identifies record i's sequence; give
+ * contig_id[0] the id of `last_seq_name` as it stands when record 0 arrives (the name of the file's first record, kept or
+ * not, for the first batch; the previous kept record's name afterwards) and put the previous batch's last record in front
+ * as record 0 to continue a block across batches.  blk_var_off_out (n_vars + 1 entries) receives the first record of
+ * every block and n_vars behind the last; these are the blk_var_off of mg_cover_blocks / mg_index_blocks. */
+int mg_cut_blocks(mg_ctx *ctx, size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size,
+                  const uint32_t *contig_id, uint32_t *blk_var_off_out, size_t *n_blocks_out);
+
 /* VB::extract_kmers (var_block.hpp:95-219, chains :436-677, haplotype picks :709-786) fused with
  * set_coverages (main.cpp:151-184) for blocks of any shape, enumerated ON THE DEVICE.  Variants are flat
  * across blocks (blk_var_off); pos is the 0-based position in the block's contig, which starts at

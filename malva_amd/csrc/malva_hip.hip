@@ -1870,6 +1870,37 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     return MG_OK;
 }
 
+// block cutting for a batch of kept records in file order (main.cpp:341, 547; var_block.hpp:77-80), on the device
+MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint32_t *contig_id,
+                            uint32_t *blk_var_off_out, size_t *n_blocks_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    *n_blocks_out = 0;
+    if (n_vars == 0) return MG_OK;
+    if (!pos || !ref_size || !min_size || !contig_id || !blk_var_off_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (n_vars >= 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "mg_cut_blocks takes fewer than 2^32 records per batch");
+    void *d_pos, *d_rs, *d_ms, *d_cid, *d_cut, *d_off;
+    TRY(upload(c, c->s_misc[0], pos, 4 * n_vars, &d_pos));
+    TRY(upload(c, c->s_misc[1], ref_size, 4 * n_vars, &d_rs));
+    TRY(upload(c, c->s_misc[2], min_size, 4 * n_vars, &d_ms));
+    TRY(upload(c, c->s_misc[3], contig_id, 4 * n_vars, &d_cid));
+    TRY(scratch(c, c->s_irr, n_vars, &d_cut));
+    TRY(scratch(c, c->s_out, 4 * (n_vars + 1), &d_off));
+    unsigned long long *d_nb = c->d_hit_count + 3; // a free word outside any scan
+    hipLaunchKernelGGL(cut_flags_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (u64)n_vars, (const int *)d_pos, (const u32 *)d_rs, (const u32 *)d_ms,
+                       (const u32 *)d_cid, (int)c->k, (u8 *)d_cut);
+    hipLaunchKernelGGL(cut_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, (u64)n_vars, (const u8 *)d_cut, (u32 *)d_off, d_nb);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long nb = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nb, d_nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(blk_var_off_out, d_off, 4 * (nb + 1), hipMemcpyDeviceToHost));
+    *n_blocks_out = (size_t)nb;
+    return MG_OK;
+}
+
 // index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for a batch of blocks, on the device
 MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
                               const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,

@@ -273,6 +273,52 @@ struct BkChains {
 // rounded to multiples of 2..16 and the answer differs from the exact one now and then, in both directions.
 __device__ __forceinline__ bool near_f32(int lhs_sum, int k, int rhs_pos) { return (float)lhs_sum + ceilf((float)k / 2) >= (float)rhs_pos; }
 
+// ---- block cutting on the device (main.cpp:341, 547 with var_block.hpp:77-80) -------------------------------------------
+// The record loops close a block when the next kept record is not near the block's last one (VB::is_near_to_last: only the
+// LAST variant counts, sum_to_add = 0) or sits on another sequence than `last_seq_name`.  `last_seq_name` is the name of
+// the file's first record until the first flush and the previous kept record's name from then on (it is refreshed at every
+// flush that sees a new name, and a new name always flushes), so with contig[0] = that first name the test is local:
+//   cut[i] = contig[i] != contig[i-1]  ||  !are_near(record i-1, record i)          (cut[0] = 1)
+// and the blocks are the runs between cuts.  One thread per record.
+__global__ void __launch_bounds__(TPB) cut_flags_kernel(u64 n, const int *__restrict__ pos, const u32 *__restrict__ ref_size, const u32 *__restrict__ min_size,
+                                                        const u32 *__restrict__ contig, int k, u8 *__restrict__ cut)
+{
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    cut[i] = i == 0 || contig[i] != contig[i - 1] || !near_f32(pos[i - 1] + (int)ref_size[i - 1] - (int)min_size[i - 1] - 1, k, pos[i]);
+}
+// blk_var_off[b] = index of the first record of block b, blk_var_off[n_blocks] = n; one workgroup walks the flags in tiles
+// (a batch is a few hundred thousand records at most: the walk is a few microseconds per 10^5)
+__global__ void __launch_bounds__(1024) cut_offsets_kernel(u64 n, const u8 *__restrict__ cut, u32 *__restrict__ blk_var_off, unsigned long long *n_blocks_out)
+{
+    __shared__ u32 sh_wave[16];
+    __shared__ u32 sh_run;
+    if (threadIdx.x == 0) sh_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u64 base = 0; base < n; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const bool f = i < n && cut[i];
+        const u64 mask = __ballot(f);
+        if (lane == 0) sh_wave[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        u32 before = sh_run;
+        for (int w = 0; w < wave; ++w) before += sh_wave[w];
+        if (f) blk_var_off[before + __popcll(mask & ((1ULL << lane) - 1))] = (u32)i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 t = 0;
+            for (int w = 0; w < 16; ++w) t += sh_wave[w];
+            sh_run += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        blk_var_off[sh_run] = (u32)n;
+        *n_blocks_out = sh_run;
+    }
+}
+
 __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
 {
     const int k = B.k;

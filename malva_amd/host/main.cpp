@@ -152,6 +152,7 @@ void pelapsed(const std::string &s, bool rollback = false)
 
 struct Device {
     mg_ctx *ctx = nullptr;
+    std::mutex mu; // calls on one context are serialised by the caller (include/malva_hip.h): held by whoever drives the context from a second thread
     ~Device() { mg_destroy(ctx); }
     void check(int rc, const char *what)
     {
@@ -194,13 +195,90 @@ std::string index_path(const Options &o, const char *suffix)
 // The record loop shared by index_main (main.cpp:309-370) and call_main (:522-579).  on_block(block, reference
 // of `last_seq_name`) is called for every closed block.  Keeps the reference's control flow, including that
 // last_seq_name is refreshed only when a block is flushed.
-template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const Reference &refs, bool for_index, std::vector<std::string> *used, F on_block)
+// `cutter` (optional): the device that makes the cuts (mg_cut_blocks) -- the kept records are then collected a batch at a
+// time and the loop below is replayed over the device's block offsets; without it (dump-kmers, MALVA_GENO_HOST_CUT=1) the
+// cuts are made record by record on the host.  Same blocks either way (tests/test_gpu_cli.py runs both).
+template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const Reference &refs, bool for_index, std::vector<std::string> *used, F on_block,
+                                         Device *cutter = nullptr)
 {
     static const std::string empty;
     auto ref_of = [&](const std::string &name) -> const std::string & {
         auto it = refs.seqs.find(name);
         return it == refs.seqs.end() ? empty : it->second;
     };
+    if (cutter && !getenv("MALVA_GENO_HOST_CUT")) {
+        // records per cut batch; MALVA_GENO_CUT_BATCH exists so tests can put a batch seam inside every block
+        const size_t batch_max = getenv("MALVA_GENO_CUT_BATCH") ? (size_t)std::max(1L, atol(getenv("MALVA_GENO_CUT_BATCH"))) : 100000;
+        Block vb((int)o.k);          // the open block: the records since the last cut
+        std::string block_name;      // `last_seq_name` of the reference loop: the name the open block will be flushed under
+        uint32_t last_cid = 0;       // contig id the open block's last record presents to the next one
+        std::map<std::string, uint32_t> ids;
+        auto id_of = [&](const std::string &name) { return ids.emplace(name, (uint32_t)ids.size()).first->second; };
+        std::vector<Variant> kept;
+        std::vector<int32_t> pos;
+        std::vector<uint32_t> ref_size, min_size, cid, off;
+        size_t i = 0, cells = 0;
+        bool more = true, seen_kept = false;
+        Variant v;
+        while (more) {
+            kept.clear();
+            cells = 0;
+            while (kept.size() < batch_max && cells < (64u << 20) && (more = vcf.next(v, o.freq_key, o.uniform))) {
+                ++i;
+                if (i % 5000 == 0) pelapsed("Processed " + std::to_string(i) + " variants", true);
+                if (block_name.empty()) { // the file's first record names the first block, kept or not (main.cpp:319-323)
+                    block_name = v.seq_name;
+                    if (used) used->push_back(block_name);
+                }
+                if (for_index ? (!v.has_alts || !v.is_present) : !v.has_alts) continue;
+                cells += v.genotypes.size();
+                kept.push_back(std::move(v));
+            }
+            if (kept.empty()) continue;
+            const bool carry = !vb.empty();
+            const size_t n = kept.size() + (carry ? 1 : 0);
+            pos.resize(n); ref_size.resize(n); min_size.resize(n); cid.resize(n); off.resize(n + 1);
+            if (carry) {
+                const Variant &c = vb.vars.back();
+                pos[0] = c.ref_pos; ref_size[0] = (uint32_t)c.ref_size; min_size[0] = (uint32_t)c.min_size; cid[0] = last_cid;
+            }
+            for (size_t j = 0; j < kept.size(); ++j) {
+                const Variant &r = kept[j];
+                const size_t q = j + (carry ? 1 : 0);
+                pos[q] = r.ref_pos; ref_size[q] = (uint32_t)r.ref_size; min_size[q] = (uint32_t)r.min_size;
+                // the very first kept record is added to an empty block unseen; what the NEXT record compares its name with
+                // is `last_seq_name`, still the file's first name then
+                cid[q] = seen_kept ? id_of(r.seq_name) : id_of(block_name);
+                seen_kept = true;
+            }
+            size_t nb = 0;
+            {
+                std::lock_guard<std::mutex> lk(cutter->mu);
+                cutter->check(mg_cut_blocks(cutter->ctx, n, pos.data(), ref_size.data(), min_size.data(), cid.data(), off.data(), &nb), "mg_cut_blocks");
+            }
+            last_cid = cid[n - 1];
+            size_t b = 0; // off[b] = next block start at or after the current element
+            for (size_t q = carry ? 1 : 0; q < n; ++q) {
+                while (b < nb && off[b] < q) ++b;
+                const bool cut = b < nb && off[b] == q;
+                Variant &r = kept[q - (carry ? 1 : 0)];
+                if (cut && !vb.empty()) {
+                    on_block(vb, block_name, ref_of(block_name));
+                    vb.clear();
+                    if (block_name != r.seq_name) {
+                        block_name = r.seq_name;
+                        if (used) used->push_back(block_name);
+                    }
+                }
+                vb.add(std::move(r));
+            }
+        }
+        if (!vb.empty()) {
+            on_block(vb, block_name, ref_of(block_name));
+            vb.clear();
+        }
+        return i;
+    }
     Block vb((int)o.k);
     std::string last_seq_name;
     Variant v;
@@ -457,7 +535,7 @@ int index_main(const Options &o)
         waiting.push_back(std::move(vb));
         vb = Block((int)o.k);
         if (waiting.size() >= 4096 || waiting_cells >= (200u << 20)) enumerate_waiting(); // bound the panel genotypes held in memory
-    });
+    }, &dev);
     enumerate_waiting();
     flush(true);
     if (n_general_blocks)
@@ -853,6 +931,7 @@ int call_main(const Options &o)
         std::vector<Rec> &recs = job.recs;
         Batch &iso = job.iso, &gen = job.gen;
         Device &dev = devs[job.device];
+        std::unique_lock<std::mutex> device_lock(dev.mu); // (the parsing thread cuts blocks on device 0 meanwhile)
         if (iso.n()) {
             const size_t n = iso.n(), na = iso.var_allele_off.back();
             iso.cov.resize(na); iso.g1.resize(n); iso.g2.resize(n); iso.gq.resize(n); iso.status.resize(n);
@@ -932,6 +1011,7 @@ int call_main(const Options &o)
                                   o.verbose ? gen.var_gt_off.data() : nullptr),
                       "mg_genotype"); // vb.genotype + the GT/GQ part of output_variants, main.cpp:558-559
         }
+        device_lock.unlock(); // the records' text needs no device
         std::string out;
         char num[64];
         for (const Rec &r : recs) { // output_variants, var_block.hpp:337-396
@@ -1064,7 +1144,7 @@ int call_main(const Options &o)
         }
         if (gen.genotype_cells >= (200u << 20)) run_and_print(); // bound the panel genotypes held in memory
         if (recs.size() >= batch_records) run_and_print();
-    });
+    }, &devs[0]);
     run_and_print();
     drain(0);
     std::cout.flush();

@@ -172,6 +172,36 @@ def test_positions_beyond_2_to_the_25_float_near(tmp_path, haploid):
     assert (want[ok] > 0).sum() > 1000
 
 
+@pytest.mark.parametrize("k", [35, 21, 64])
+def test_blocks_cut_on_the_device(k):
+    """mg_cut_blocks: the cut test of the record loops (main.cpp:341, 547 -- not near the block's last record, or another
+    sequence) for a batch of records, against the oracle's are_near (float arithmetic) record by record: positions below
+    and far above 2^24, gaps around the threshold, contig changes, a batch of one, an empty batch."""
+    rng = np.random.default_rng(k)
+    n = 200_000
+    gaps = rng.integers(1, 2 * k, size=n)
+    pos = np.cumsum(gaps).astype(np.int64)
+    pos[n // 2:] += (1 << 27) - pos[n // 2]                      # second half starts at 2^27: float spacing 8..16
+    pos[n // 4:n // 2] += (1 << 24) - 5000 - pos[n // 4]         # second quarter straddles 2^24
+    pos = np.maximum.accumulate(pos)
+    ref_size = rng.integers(1, 12, size=n).astype(np.uint32)
+    min_size = np.minimum(ref_size, rng.integers(1, 12, size=n)).astype(np.uint32)
+    contig = np.sort(rng.integers(0, 5, size=n)).astype(np.uint32)
+    want = [0]
+    for i in range(1, n):
+        if contig[i] != contig[i - 1] or not ocapi.are_near(int(pos[i - 1]), int(ref_size[i - 1]), int(min_size[i - 1]), 0, k, int(pos[i])):
+            want.append(i)
+    want.append(n)
+    with Context(k, k, 1 << 20) as ctx:
+        got = ctx.cut_blocks(pos, ref_size, min_size, contig)
+        assert np.array_equal(got, np.array(want, dtype=np.uint32))
+        assert 0.05 < (len(want) - 1) / n < 0.95
+        assert np.array_equal(ctx.cut_blocks(pos[:1], ref_size[:1], min_size[:1], contig[:1]), np.array([0, 1], dtype=np.uint32))
+        assert len(ctx.cut_blocks(pos[:0], ref_size[:0], min_size[:0], contig[:0])) == 0
+        # 1,025 records: one more than the offsets kernel's tile
+        assert np.array_equal(ctx.cut_blocks(pos[:1025], ref_size[:1025], min_size[:1025], contig[:1025]), np.array([w for w in want if w < 1025] + [1025], dtype=np.uint32))
+
+
 @pytest.mark.parametrize("seed,haploid,k,ref_k,dense", [(61, False, 35, 43, False), (62, True, 35, 43, False), (63, False, 31, 41, False),
                                                         (64, False, 35, 63, False), (65, False, 35, 43, True), (66, True, 35, 43, True)])
 def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k, dense):

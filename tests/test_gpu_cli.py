@@ -132,6 +132,36 @@ def test_c5_like_panel_many_batches(tmp_path):
         assert got.count("\n") > 1500
 
 
+@pytest.mark.parametrize("haploid", [False, True])
+def test_blocks_cut_on_the_device_or_on_the_host(tmp_path, haploid):
+    """`index` and `call` cut their blocks on the device (mg_cut_blocks over batches of kept records); with batches of 7
+    records nearly every block straddles a batch seam, with MALVA_GENO_HOST_CUT=1 the cuts are made record by record on
+    the host as in round 1: byte-identical output, equal to the oracle's.  The panel's first record is a symbolic-only
+    one on another sequence than the records behind it: the reference then flushes the first block under THAT name
+    (main.cpp:319-323, 341-356), and so must both cutters."""
+    prefix = str(tmp_path / "cut")
+    contigs, records = vcf_synth.make_case(prefix, 77, haploid=haploid, k=35, n_clusters=160, vcf_strip_chr=True)
+    lines = open(prefix + ".vcf").read().split("\n")
+    first = next(i for i, l in enumerate(lines) if l and not l.startswith("#"))
+    n_samples = len(lines[first].split("\t")) - 9
+    gt0 = "0" if haploid else "0|0"
+    lines.insert(first, "\t".join(["2", "50", ".", contigs["chr2"][49], "<DEL>", ".", ".", "AF=0.1", "GT"] + [gt0] * n_samples))
+    open(prefix + ".vcf", "w").write("\n".join(lines))
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, 43, 78, table + ".txt")
+    opt = pipeline.Options(haploid=haploid, verbose=True, bf_size=1 << 33, strip_chr=True)
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+    want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+    args = ["-b", "1", "-p", "-v"] + (["-1"] if haploid else []) + [prefix + ".fa", prefix + ".vcf", table]
+    outs = []
+    for env in ({}, {"MALVA_GENO_CUT_BATCH": "7"}, {"MALVA_GENO_HOST_CUT": "1"}):
+        run_cli(["index"] + args, env=dict(os.environ, **env))
+        outs.append(run_cli(["call"] + args, env=dict(os.environ, **env)))
+    assert outs[0] == want and outs[1] == want and outs[2] == want
+    assert want.count("\n") > 300
+
+
 def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
     """a run of 18 SNPs at consecutive positions with UNPHASED genotypes gives chains of up to 18 unphased members: 2^18
     haplotype mixes per sample, beyond the device kernel's 2^14 -- those blocks must come back flagged and be redone by the
