@@ -682,8 +682,8 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
 // and every step began with a chain count -> tickets -> gate word of dependent loads: 1.3 ms per 1.3e8 tickets, three
 // times what the L2 gather costs.)  Survivors are listed by row number alone: the probe kernel, which has no stream to
 // disturb, fetches the rows.  Placement only decides speed, never the result.
-constexpr int TKG_TPB = 256, TKG_U = 8, TKG_SPW = 64; // threads per workgroup; tickets per thread and step; segments of one slice per walk
-constexpr int TKG_WSTAGE = 4096;                       // staged survivors per wave (4 waves: 64 KB)
+constexpr int TKG_TPB = 512, TKG_U = 8, TKG_SPW = 64; // threads per workgroup; tickets per thread and step; segments of one slice per walk
+constexpr int TKG_WSTAGE = 2048;                       // staged survivors per wave (8 waves: 64 KB)
 // GK: the gate's bits per entry fixed at compile time (0 = read from the view)
 template <int GK>
 __global__ void __launch_bounds__(TKG_TPB) scan_ticket_gate_kernel(BFView bf, TicketSet ts, u32 *__restrict__ open_rows, unsigned long long *counters)
