@@ -563,16 +563,21 @@ template <int KC, int RC>
 __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ rows12, u64 n,
                                                                int k_rt, int r_rt, BFView bf, TicketSet ts)
 {
+    // Three barriers per tile: the slice counts alternate between two arrays (the one of tile t + 1 is cleared while tile t
+    // is sorted), every wave keeps its own copy of the prefix sums, and a ticket's slice is recomputed from the ticket
+    // when it leaves (first form: five barriers and a 4 KB slice-of-position array).
     __shared__ u64 sh_sorted[TK_TILE];
-    __shared__ uint16_t sh_binof[TK_TILE];
-    __shared__ u32 sh_hist[TK_MAXP], sh_off[TK_MAXP + 1], sh_pos[TK_MAXP]; // this tile's count / place in the tile / tickets already in the segment
+    __shared__ u32 sh_hist[2][TK_MAXP], sh_off[TPB / 64][TK_MAXP + 1], sh_pos[TK_MAXP]; // a tile's counts / places in the tile (per wave) / tickets already in the segment
     __shared__ u32 sh_lut[256];
     const int P = (int)ts.nbins;
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63;
+    u32 *const my_off = sh_off[threadIdx.x >> 6];
     ascii_lut_fill(sh_lut);
-    for (int b = threadIdx.x; b < P; b += TPB) sh_hist[b] = sh_pos[b] = 0;
+    for (int b = threadIdx.x; b < P; b += TPB) sh_hist[0][b] = sh_hist[1][b] = sh_pos[b] = 0;
     __syncthreads();
+    u32 parity = 0;
     typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
     const bool vec_ok = ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
     const u64 step = (u64)gridDim.x * TK_TILE;
@@ -622,54 +627,49 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
                 const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
                 tk[2 * g + j] = (idx << ts.row_bits) | (i + j);
                 const u32 bin = (u32)(gate_word(bf, idx) >> ts.word_shift);
-                binrank[2 * g + j] = live[j] ? (bin << 16) | atomicAdd(&sh_hist[bin], 1u) : ~0u;
+                binrank[2 * g + j] = live[j] ? (bin << 16) | atomicAdd(&sh_hist[parity][bin], 1u) : ~0u;
             }
         }
-        __syncthreads();
-        if (threadIdx.x < 64) { // exclusive prefix sum of the slice counts (one wave, P <= 256: four slices per lane)
+        __syncthreads(); // 1: the tile's slice counts are complete (and the previous tile is done with everything)
+        { // every wave: exclusive prefix sum of the slice counts into its own copy (P <= 256: four slices per lane)
             u32 v[4], run = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int b = threadIdx.x * 4 + q;
-                v[q] = b < P ? sh_hist[b] : 0;
+                const int b = lane * 4 + q;
+                v[q] = b < P ? sh_hist[parity][b] : 0;
                 run += v[q];
             }
             u32 incl = run;
             for (int o = 1; o < 64; o <<= 1) {
                 const u32 t = __shfl_up(incl, o, 64);
-                if ((int)threadIdx.x >= o) incl += t;
+                if (lane >= o) incl += t;
             }
             u32 ex = incl - run;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int b = threadIdx.x * 4 + q;
-                if (b <= P) sh_off[b] = ex;
+                const int b = lane * 4 + q;
+                if (b <= P) my_off[b] = ex;
                 ex += v[q];
             }
         }
-        __syncthreads();
+        for (int b = threadIdx.x; b < P; b += TPB) sh_hist[parity ^ 1][b] = 0; // the next tile's counts (last read before barrier 1)
 #pragma unroll
         for (int j = 0; j < TK_TILE_ROWS; ++j)
-            if (binrank[j] != ~0u) {
-                const u32 at = sh_off[binrank[j] >> 16] + (binrank[j] & 0xFFFF);
-                sh_sorted[at] = tk[j];
-                sh_binof[at] = (uint16_t)(binrank[j] >> 16);
-            }
-        __syncthreads();
-        const u32 total = sh_off[P];
+            if (binrank[j] != ~0u) sh_sorted[my_off[binrank[j] >> 16] + (binrank[j] & 0xFFFF)] = tk[j];
+        __syncthreads(); // 2: the tile is sorted
+        const u32 total = my_off[P];
         for (u32 e = threadIdx.x; e < total; e += TPB) { // runs of consecutive tickets, one per slice, into the workgroup's segments
-            const u32 b = sh_binof[e];
-            const u32 at = sh_pos[b] + (e - sh_off[b]);
-            if (at < ts.segcap) ts.tickets[((unsigned long long)b * ts.nseg + blockIdx.x) * ts.segcap + at] = sh_sorted[e];
-            else ts.spill[atomicAdd(ts.spill_count, 1ULL)] = sh_sorted[e]; // the segment is full (skewed input): rare
+            const u64 t = sh_sorted[e];
+            const u32 b = (u32)(gate_word(bf, t >> ts.row_bits) >> ts.word_shift);
+            const u32 at = sh_pos[b] + (e - my_off[b]);
+            if (at < ts.segcap) ts.tickets[((unsigned long long)b * ts.nseg + blockIdx.x) * ts.segcap + at] = t;
+            else ts.spill[atomicAdd(ts.spill_count, 1ULL)] = t; // the segment is full (skewed input): rare
         }
-        __syncthreads();
-        for (int b = threadIdx.x; b < P; b += TPB) {
-            sh_pos[b] = min(sh_pos[b] + sh_hist[b], (u32)ts.segcap);
-            sh_hist[b] = 0;
-        }
-        __syncthreads();
+        __syncthreads(); // 3: everybody has read the segments' fills
+        for (int b = threadIdx.x; b < P; b += TPB) sh_pos[b] = min(sh_pos[b] + sh_hist[parity][b], (u32)ts.segcap);
+        parity ^= 1; // (the fills are next read behind barrier 2 of the next tile; these counts are cleared behind its barrier 1)
     }
+    __syncthreads();
     for (int b = threadIdx.x; b < P; b += TPB) ts.counts[b * ts.nseg + blockIdx.x] = sh_pos[b];
 }
 
