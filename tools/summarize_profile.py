@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key in ("scan_filter12_kernel", "scan_ticket_gate_kernel", "scan_ticket_kernel", "kmc_decode_kernel", "pack_rows12_kernel", "scan_filter_kernel", "scan_probe_kernel", "scan_hits_kernel", "scan_bin_gate_kernel", "scan_bin_kernel", "iso_cover_kernel<false>",
+    for key in ("scan_filter12_kernel", "scan_ticket_gate_kernel", "scan_ticket_sort_kernel", "cut_flags_kernel", "cut_offsets_kernel", "kmc_decode_kernel", "pack_rows12_kernel", "scan_filter_kernel", "scan_probe_kernel", "scan_hits_kernel", "scan_bin_gate_kernel", "scan_bin_kernel", "iso_cover_kernel<false>",
                 "iso_cover_kernel<true>", "iso_genotype_kernel", "ref_scan_kernel", "rows_kernel", "map_insert_kernel", "genotype_kernel",
                 "cover_kernel", "blk_pop_kernel", "summary_kernel"):
         if key in name:
