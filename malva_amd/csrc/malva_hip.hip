@@ -103,6 +103,7 @@ struct mg_ctx {
     int use_tickets = 1;      // gates of 2^ticket_min_log2 bits and more: 8-byte tickets filed by 2 MiB gate slice, the slices then walked out of L2
                               // (scan_ticket_sort_kernel + scan_ticket_gate_kernel) instead of one random HBM sector per table row
     int tkg_grid = 0;         // pass two's grid: one workgroup per CU (found at first use)
+    int chunk_log2 = 27;      // rows per launch group (tests shrink it to put many chunks into a small table)
     int ticket_sync = 0;      // pass two: the workgroups of an XCD meet (bounded wait) before they move to the next gate slice; measured: no gain
     int ticket_min_log2 = 28; // smallest fine gate (log2 bits) that takes the ticket form: 32 MiB.  Measured on a C4 share (3.75e8 rows, compact rows):
                               // 16 MiB gate 3.6 ms two-level direct / 4.8 tickets; 32 MiB 7.7 / 6.2; 256 MiB 9.3 / 7.3 (profiles/r02_c4share_forms.txt)
@@ -584,6 +585,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
     else if (!strcmp(name, "ticket_sync")) c->ticket_sync = value != 0;
+    else if (!strcmp(name, "scan_chunk_log2")) c->chunk_log2 = (int)std::min<int64_t>(27, std::max<int64_t>(10, value));
     else if (!strcmp(name, "ticket_gate_grid")) c->tkg_grid = value > 0 ? (int)std::max<int64_t>(8, std::min<int64_t>(4096, value / 8 * 8)) : 0;
     else if (!strcmp(name, "hits_grid")) c->hits_grid = value > 0 ? (int)value : 1024;
     else if (!strcmp(name, "scan_bin_cap")) c->bin_cap = value > 0 ? (u64)value : 0;
@@ -1054,7 +1056,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     u32 row_bits = 27;
     const bool tickets = ticket_form(c, &row_bits);
     const u64 TP = ticket_slices(c);
-    const u64 chunk = tickets ? 1ULL << row_bits : 1ULL << 27; // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
+    const u64 chunk = 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2); // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
@@ -1167,7 +1169,7 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     if (!c->map.slots) TRY(map_reserve(c, 0));
     u32 row_bits = 27;
     const bool tickets = ticket_form(c, &row_bits);
-    const u64 chunk = tickets ? std::max<u64>(4, 1ULL << row_bits) : 1ULL << 27; // (a multiple of 4 rows: chunks start on whole quads)
+    const u64 chunk = std::max<u64>(4, 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2)); // (a multiple of 4 rows: chunks start on whole quads)
     const u64 cap = n < chunk ? n : chunk;
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
