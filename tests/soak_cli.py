@@ -20,8 +20,13 @@ for seed in range(first, first + n):
     k, ref_k = [(35, 43), (31, 41), (35, 63), (25, 33)][(seed >> 3) & 3]
     with tempfile.TemporaryDirectory() as d:
         prefix = os.path.join(d, "c")
-        contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=30 if dense else 80, dense=dense,
-                                               n_samples=3 + seed % 6, vcf_strip_chr=True)
+        far = seed % 8 == 7           # one case in eight: a 35 Mb contig, clusters beyond position 2^25 (are_near in float)
+        if far:
+            seq, records, _ = vcf_synth.make_far_case(prefix, seed, k=k, n_clusters=150, n_samples=3 + seed % 4, haploid=haploid)
+            contigs = {"1": seq}
+        else:
+            contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=30 if dense else 80, dense=dense,
+                                                   n_samples=3 + seed % 6, vcf_strip_chr=True)
         table = os.path.join(d, "t")
         vcf_synth.donor_table(contigs, records, ref_k, seed, table + ".txt")
         opt = pipeline.Options(haploid=haploid, verbose=verbose, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
@@ -30,14 +35,15 @@ for seed in range(first, first + n):
         want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
         args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p"] + (["-1"] if haploid else []) + (["-v"] if verbose else [])
         args += [prefix + ".fa", prefix + ".vcf", table]
-        r = subprocess.run([BIN, "index"] + args, capture_output=True, text=True)
+        env = dict(os.environ, MALVA_GENO_CUT_BATCH=str(1 + seed % 13)) if seed % 3 == 0 else dict(os.environ)   # block-cut batch seams everywhere
+        r = subprocess.run([BIN, "index"] + args, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-500:]
-        r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True)
+        r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-500:]
         ok = r.stdout == want
         nonref = sum(1 for l in want.split("\n") if l and not l.startswith("#") and not l.split("\t")[-1].startswith(("0:", "0/0:")))
-        print("seed %d haploid=%d dense=%d verbose=%d k=%d r=%d records=%d nonref=%d %s %s" % (
-            seed, haploid, dense, verbose, k, ref_k, want.count("\n"), nonref, "OK" if ok else "MISMATCH",
+        print("seed %d far=%d haploid=%d dense=%d verbose=%d k=%d r=%d records=%d nonref=%d %s %s" % (
+            seed, far, haploid, dense, verbose, k, ref_k, want.count("\n"), nonref, "OK" if ok else "MISMATCH",
             "(host blocks)" if "enumerated on the host" in r.stderr else ""), flush=True)
         if not ok:
             bad += 1
