@@ -648,9 +648,10 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int b = lane * 4 + q;
-                if (b <= P) my_off[b] = ex;
+                if (b < P) my_off[b] = ex;
                 ex += v[q];
             }
+            if (lane == 63) my_off[P] = incl; // the tile's ticket count (P may be 256: no lane's b reaches it)
         }
         for (int b = threadIdx.x; b < P; b += TPB) sh_hist[parity ^ 1][b] = 0; // the next tile's counts (last read before barrier 1)
 #pragma unroll

@@ -75,6 +75,7 @@ def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
 @pytest.mark.parametrize("k,ref_k,bits,gate_log2,slices,bin_cap", [(35, 43, 1 << 33, 14, 32, 0), (35, 43, 1 << 17, 14, 32, 0), (35, 63, 1 << 20, 13, 16, 0),
                                                                   (31, 41, (1 << 18) + 77, 14, 32, 0), (35, 43, 1 << 33, 12, 8, 0),
                                                                   (35, 43, 1 << 33, 11, 4, 0),      # fewer slices than XCDs: slices shared
+                                                                  (35, 43, 1 << 33, 17, 256, 0),    # the most slices the form takes (a 512 MiB gate at full size)
                                                                   (35, 43, 1 << 33, 14, 32, 16), (35, 43, 1 << 17, 13, 16, 16)])
 def test_scan_ticket_form(k, ref_k, bits, gate_log2, slices, bin_cap):
     """whole-genome-sized indexes file an 8-byte ticket per table row under the slice of the fine gate it will probe and
