@@ -960,6 +960,7 @@ int ticket_layout(mg_ctx *c, u64 cap, u32 row_bits, TicketSet *out)
     tks.spill = (u64 *)q[1];
     if (!c->d_tk_meta) HIP_TRY(c, hipMalloc(&c->d_tk_meta, TK_META_HEAD + (size_t)TK_MAXP * BIN_SEGS * 4));
     tks.spill_count = c->d_tk_meta;
+    tks.ablate = (u32)c->scan_ablate >> 8; // (timing-only diagnostics of pass one: scan_ablate 256, 512)
     tks.sync = c->ticket_sync ? (u32 *)(c->d_tk_meta + 1) : nullptr;
     tks.counts = (u32 *)((char *)c->d_tk_meta + TK_META_HEAD);
     *out = tks;

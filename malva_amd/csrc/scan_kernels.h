@@ -548,6 +548,7 @@ struct TicketSet {
     u64 segcap;
     u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift
     u32 row_bits;                // ticket = idx << row_bits | row
+    u32 ablate;                  // timing-only diagnostic of pass one (results are wrong when non-zero): 1 = tickets not stored, 2 = tile not sorted either
     u32 *sync;                   // [8][TK_MAXP / 8] arrivals per XCD and round of pass two (zeroed before every launch); null = no rendezvous
 };
 
@@ -656,9 +657,10 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
         for (int b = threadIdx.x; b < P; b += TPB) sh_hist[parity ^ 1][b] = 0; // the next tile's counts (last read before barrier 1)
 #pragma unroll
         for (int j = 0; j < TK_TILE_ROWS; ++j)
-            if (binrank[j] != ~0u) sh_sorted[my_off[binrank[j] >> 16] + (binrank[j] & 0xFFFF)] = tk[j];
+            if (binrank[j] != ~0u && !(ts.ablate & 2)) sh_sorted[my_off[binrank[j] >> 16] + (binrank[j] & 0xFFFF)] = tk[j];
+            else if (ts.ablate & 2) asm volatile("" ::"v"((u32)tk[j]), "v"((u32)(tk[j] >> 32)));
         __syncthreads(); // 2: the tile is sorted
-        const u32 total = my_off[P];
+        const u32 total = (ts.ablate & 3) ? 0 : my_off[P];
         for (u32 e = threadIdx.x; e < total; e += TPB) { // runs of consecutive tickets, one per slice, into the workgroup's segments
             const u64 t = sh_sorted[e];
             const u32 b = (u32)(gate_word(bf, t >> ts.row_bits) >> ts.word_shift);

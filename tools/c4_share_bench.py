@@ -32,7 +32,10 @@ panel = synth.snp_panel(n_vars, 4242, spacing=40)
 plant = min(n_vars, n_rows // 5 * 2 // 15)          # 7.5 windows per planted variant on average -> 20 % of the rows
 tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
 print("[c4] panel + table: %.0f s, %d site rows (%.1f %%)" % (time.time() - t0, tab.n_site, 100.0 * tab.n_site / n_rows), file=sys.stderr)
-forms = {"tickets": [("use_tickets", 1)], "tickets_nosync": [("use_tickets", 1), ("ticket_sync", 0)], "tickets_g512": [("use_tickets", 1), ("ticket_sync", 0), ("ticket_gate_grid", 512)], "tickets_g512s": [("use_tickets", 1), ("ticket_gate_grid", 512)], "tickets_nogate": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 256)], "tickets_synth": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 512)], "tickets_none": [("use_tickets", 1), ("ticket_sync", 0), ("scan_ablate", 768)], "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
+forms = {"tickets": [("use_tickets", 1)], "tickets_sync": [("use_tickets", 1), ("ticket_sync", 1)],
+         # timing only (wrong results): pass one without its ticket stores / without sorting the tile either
+         "tickets_nostore": [("use_tickets", 1), ("scan_ablate", 256)], "tickets_nosort": [("use_tickets", 1), ("scan_ablate", 512)],
+         "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
          # smaller fine gates (more false positives, but inside the 256 MiB Infinity Cache): gate_log2 is fixed before the inserts
          "gate30": [("use_pregate", 0), ("gate_log2", 30)], "gate29": [("use_pregate", 0), ("gate_log2", 29)],
          "gate30k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 30)], "gate29k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 29)],
