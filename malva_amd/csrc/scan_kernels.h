@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
             else ts.spill[atomicAdd(ts.spill_count, 1ULL)] = t; // the segment is full (skewed input): rare
         }
         __syncthreads(); // 3: everybody has read the segments' fills
-        for (int b = threadIdx.x; b < P; b += TPB) sh_pos[b] = min(sh_pos[b] + sh_hist[parity][b], (u32)ts.segcap);
+        for (int b = threadIdx.x; b < P && !(ts.ablate & 3); b += TPB) sh_pos[b] = min(sh_pos[b] + sh_hist[parity][b], (u32)ts.segcap);
         parity ^= 1; // (the fills are next read behind barrier 2 of the next tile; these counts are cleared behind its barrier 1)
     }
     __syncthreads();
