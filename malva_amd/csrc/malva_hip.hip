@@ -29,7 +29,7 @@ using namespace mg;
 
 namespace {
 
-constexpr size_t TK_META_HEAD = 8 + 8 * 32 * 4; // ticket meta block: spill count, then pass two's [8 XCDs][32 rounds] arrival counters, then the segment fills
+constexpr size_t TK_META_HEAD = 8; // ticket meta block: spill count, then the segment fills
 constexpr int BIN_SEGS = 2048; // workgroups of the binning kernel = segments per bin
 constexpr int TPB = 256;
 
@@ -104,7 +104,6 @@ struct mg_ctx {
                               // (scan_ticket_sort_kernel + scan_ticket_gate_kernel) instead of one random HBM sector per table row
     int tkg_grid = 0;         // pass two's grid: one workgroup per CU (found at first use)
     int chunk_log2 = 27;      // rows per launch group (tests shrink it to put many chunks into a small table)
-    int ticket_sync = 0;      // pass two: the workgroups of an XCD meet (bounded wait) before they move to the next gate slice; measured: no gain
     int ticket_min_log2 = 28; // smallest fine gate (log2 bits) that takes the ticket form: 32 MiB.  Measured on a C4 share (3.75e8 rows, compact rows):
                               // 16 MiB gate 3.6 ms two-level direct / 4.8 tickets; 32 MiB 7.7 / 6.2; 256 MiB 9.3 / 7.3 (profiles/r02_c4share_forms.txt)
     Scratch s_tk[2];
@@ -584,7 +583,6 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
-    else if (!strcmp(name, "ticket_sync")) c->ticket_sync = value != 0;
     else if (!strcmp(name, "scan_chunk_log2")) c->chunk_log2 = (int)std::min<int64_t>(27, std::max<int64_t>(10, value));
     else if (!strcmp(name, "ticket_gate_grid")) c->tkg_grid = value > 0 ? (int)std::max<int64_t>(8, std::min<int64_t>(4096, value / 8 * 8)) : 0;
     else if (!strcmp(name, "hits_grid")) c->hits_grid = value > 0 ? (int)value : 1024;
@@ -961,7 +959,6 @@ int ticket_layout(mg_ctx *c, u64 cap, u32 row_bits, TicketSet *out)
     if (!c->d_tk_meta) HIP_TRY(c, hipMalloc(&c->d_tk_meta, TK_META_HEAD + (size_t)TK_MAXP * BIN_SEGS * 4));
     tks.spill_count = c->d_tk_meta;
     tks.ablate = (u32)c->scan_ablate >> 8; // (timing-only diagnostics of pass one: scan_ablate 256, 512)
-    tks.sync = c->ticket_sync ? (u32 *)(c->d_tk_meta + 1) : nullptr;
     tks.counts = (u32 *)((char *)c->d_tk_meta + TK_META_HEAD);
     *out = tks;
     return MG_OK;

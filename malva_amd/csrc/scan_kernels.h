@@ -549,7 +549,6 @@ struct TicketSet {
     u32 nbins, nseg, word_shift; // bin = fine-gate word index >> word_shift
     u32 row_bits;                // ticket = idx << row_bits | row
     u32 ablate;                  // timing-only diagnostic of pass one (results are wrong when non-zero): 1 = tickets not stored, 2 = tile not sorted either
-    u32 *sync;                   // [8][TK_MAXP / 8] arrivals per XCD and round of pass two (zeroed before every launch); null = no rendezvous
 };
 
 // Pass one: a tile of TK_TILE rows is SORTED by gate slice in LDS (one returning LDS atomic per row gives its rank inside
@@ -683,8 +682,13 @@ __global__ void __launch_bounds__(TPB) scan_ticket_sort_kernel(const u64 *__rest
 // fills are, the next step's tickets requested before this step's gate words are waited for.  (First form: segment by
 // segment, 512 tickets at a time -- a segment holds 512 on average, so every second one took a second, nearly empty step,
 // and every step began with a chain count -> tickets -> gate word of dependent loads: 1.3 ms per 1.3e8 tickets, three
-// times what the L2 gather costs.)  Survivors are listed by row number alone: the probe kernel, which has no stream to
-// disturb, fetches the rows.  Placement only decides speed, never the result.
+// times what the L2 gather costs.)  ONE workgroup per CU, all resident together: a grid larger than what is resident starts
+// its late workgroups at the first slice again while the early ones are on the last, two or three slices then fight over
+// the 4 MiB L2 and 42 % of the gate loads miss it (TCC_MISS, first form).  The barrier at the end of a walk is what keeps
+// a workgroup's waves on the same slice (a flat walk over all slices without it: 15 % slower); a rendezvous of the XCD's
+// workgroups between slices (bounded wait) was built and measured too: no gain at this shape, a loss with more
+// workgroups.  Survivors are listed by row number alone: the probe kernel, which has no stream to disturb, fetches the
+// rows.  Placement only decides speed, never the result.
 constexpr int TKG_TPB = 512, TKG_U = 8, TKG_SPW = 64; // threads per workgroup; tickets per thread and step; segments of one slice per walk
 constexpr int TKG_WSTAGE = 2048;                       // staged survivors per wave (8 waves: 64 KB)
 // GK: the gate's bits per entry fixed at compile time (0 = read from the view)
@@ -788,19 +792,6 @@ __global__ void __launch_bounds__(TKG_TPB) scan_ticket_gate_kernel(BFView bf, Ti
     for (int p = P >= 8 ? (int)xcd : (int)(xcd % (u32)P); p < P; p += 8) {
         for (u32 s = s0; s < s1; s += TKG_SPW)
             walk(ts.tickets + ((u64)p * ts.nseg + s) * ts.segcap, ts.counts + (u64)p * ts.nseg + s, s1 - s < (u32)TKG_SPW ? s1 - s : (u32)TKG_SPW);
-        // Rendezvous of the XCD's workgroups before the next slice.  Left to themselves they drift apart by a slice or more,
-        // two or three slices then compete for the 4 MiB L2 and 42 % of the gate loads miss it (TCC_MISS, round 2; a grid
-        // larger than what is resident at once is worse still: its late workgroups start at the first slice again).  The
-        // rendezvous only decides speed: the wait is BOUNDED, and whoever gives up simply goes on.
-        if (ts.sync && p + 8 < P) {
-            if (threadIdx.x == 0) {
-                u32 *const arrived = ts.sync + xcd * (TK_MAXP / 8) + (u32)(p >> 3);
-                atomicAdd(arrived, 1u);
-                for (int spin = 0; spin < 256 && __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nlocal; ++spin)
-                    __builtin_amdgcn_s_sleep(4);
-            }
-            __syncthreads();
-        }
     }
     { // the spill list: one dense run, an even share per workgroup
         const u64 ns = *ts.spill_count, chunk = (ns + gridDim.x - 1) / gridDim.x;

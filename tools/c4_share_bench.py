@@ -32,7 +32,7 @@ panel = synth.snp_panel(n_vars, 4242, spacing=40)
 plant = min(n_vars, n_rows // 5 * 2 // 15)          # 7.5 windows per planted variant on average -> 20 % of the rows
 tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
 print("[c4] panel + table: %.0f s, %d site rows (%.1f %%)" % (time.time() - t0, tab.n_site, 100.0 * tab.n_site / n_rows), file=sys.stderr)
-forms = {"tickets": [("use_tickets", 1)], "tickets_sync": [("use_tickets", 1), ("ticket_sync", 1)],
+forms = {"tickets": [("use_tickets", 1)],
          # timing only (wrong results): pass one without its ticket stores / without sorting the tile either
          "tickets_nostore": [("use_tickets", 1), ("scan_ablate", 256)], "tickets_nosort": [("use_tickets", 1), ("scan_ablate", 512)],
          "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
