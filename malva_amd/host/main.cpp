@@ -217,7 +217,7 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
         std::vector<Variant> kept;
         std::vector<int32_t> pos;
         std::vector<uint32_t> ref_size, min_size, cid, off;
-        size_t i = 0, cells = 0;
+        size_t i = 0, cells = 0, n_cut_blocks = 0, n_batches = 0;
         bool more = true, seen_kept = false;
         Variant v;
         while (more) {
@@ -257,6 +257,7 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
                 cutter->check(mg_cut_blocks(cutter->ctx, n, pos.data(), ref_size.data(), min_size.data(), cid.data(), off.data(), &nb), "mg_cut_blocks");
             }
             last_cid = cid[n - 1];
+            ++n_batches;
             size_t b = 0; // off[b] = next block start at or after the current element
             for (size_t q = carry ? 1 : 0; q < n; ++q) {
                 while (b < nb && off[b] < q) ++b;
@@ -264,6 +265,7 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
                 Variant &r = kept[q - (carry ? 1 : 0)];
                 if (cut && !vb.empty()) {
                     on_block(vb, block_name, ref_of(block_name));
+                    ++n_cut_blocks;
                     vb.clear();
                     if (block_name != r.seq_name) {
                         block_name = r.seq_name;
@@ -275,8 +277,10 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
         }
         if (!vb.empty()) {
             on_block(vb, block_name, ref_of(block_name));
+            ++n_cut_blocks;
             vb.clear();
         }
+        std::cerr << "[malva-geno] " << n_cut_blocks << " block(s) cut on the device in " << n_batches << " batch(es)" << std::endl;
         return i;
     }
     Block vb((int)o.k);

@@ -160,6 +160,12 @@ def test_blocks_cut_on_the_device_or_on_the_host(tmp_path, haploid):
         outs.append(run_cli(["call"] + args, env=dict(os.environ, **env)))
     assert outs[0] == want and outs[1] == want and outs[2] == want
     assert want.count("\n") > 300
+    r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, MALVA_GENO_CUT_BATCH="7"))
+    assert r.returncode == 0 and " block(s) cut on the device in " in r.stderr and r.stdout == want
+    n_batches = int(r.stderr.split(" block(s) cut on the device in ")[1].split()[0])
+    assert n_batches > 40                                       # batches of 7 kept records
+    r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, MALVA_GENO_HOST_CUT="1"))
+    assert r.returncode == 0 and "cut on the device" not in r.stderr
 
 
 def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
