@@ -240,6 +240,18 @@ int mg_index_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, 
 #define MG_GT_SINGLE 2   /* one allele only: (best_geno,1)                        */
 #define MG_GT_NOCOV 3    /* all coverages 0: (best_geno,0)                        */
 
+/* Index-time counterpart of mg_call_isolated for blocks of ONE variant whose alleles are all shorter than k: VB::extract_kmers
+ * with comb = {v} (var_block.hpp:95-219) + add_kmers_to_bf (main.cpp:122-144) on the device -- allele 0's signature k-mer goes
+ * into the exact map (KMAP::add_key), the signature of every other allele some panel haplotype carries (present_mask) sets its
+ * bit of `bf` (BF::add_key).  pos, offsets, pool, present_mask and flags as for mg_call_isolated (flags bit0: is_present and
+ * not within k of a contig end, var_block.hpp:104; flanks inside the contig).  overflow_out[v] = 1: nothing of that variant
+ * was inserted (a base outside ACGT in its window or alleles, more than 64 alleles, k outside 17..64) -- enumerate it on the
+ * host and insert with mg_map_insert / mg_bf_insert.  Before mg_bf_finalize; after mg_reference_upload.  Variant v's REF key
+ * takes insertion row (rows so far) + v; the index FILE fixes the counter layout for every GPU of a call. */
+int mg_index_isolated(mg_ctx *ctx, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off, const uint32_t *allele_off,
+                      const char *allele_pool, size_t pool_len, const uint64_t *present_mask, const uint8_t *flags,
+                      uint8_t *overflow_out);
+
 /* VB::genotype (var_block.hpp:224-330) + the normalise / first-strict-max / GQ
  * part of VB::output_variants (:366-394).  Variant v owns allele slots
  * [var_allele_off[v], var_allele_off[v+1]).  gt2 = -1 in haploid mode.

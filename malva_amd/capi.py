@@ -104,6 +104,7 @@ def lib():
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
         "mg_cut_blocks": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "mg_index_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp],
         "mg_index_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp],
         "mg_reference_upload": [vp, vp, sz],
         "mg_call_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, fl, it, it, vp, vp, vp, vp, vp, vp, vp],
@@ -138,7 +139,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
-            "mg_counters_allreduce_all", "mg_cut_blocks",
+            "mg_counters_allreduce_all", "mg_cut_blocks", "mg_index_isolated",
             "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_set_option", "mg_get_option"]
@@ -485,6 +486,15 @@ class Context:
         self._ck(self._L.mg_cover_blocks(self.h, len(bb), _p(bb), _p(bl), _p(bo), n, _p(pos), _p(rs), _p(ms), _p(pr), _p(vo), _p(ao),
                                          _p(pool), pool.size, _p(canon), _p(gt), n_samples, int(haploid), _p(cov), _p(ovf)))
         return cov, ovf
+
+    def index_isolated(self, pos, var_allele_off, allele_off, pool, present_mask, flags):
+        """-> overflow flags; lone short variants indexed on the device (extract_kmers + add_kmers_to_bf)"""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)
+        pos, vo, ao, pool, pm, fl = a(pos, np.uint64), a(var_allele_off, np.uint32), a(allele_off, np.uint32), a(pool, np.uint8), a(present_mask, np.uint64), a(flags, np.uint8)
+        n = len(pos)
+        ovf = np.zeros(n, dtype=np.uint8)
+        self._ck(self._L.mg_index_isolated(self.h, n, _p(pos), _p(vo), _p(ao), _p(pool), pool.size, _p(pm), _p(fl), _p(ovf)))
+        return ovf
 
     def cut_blocks(self, pos, ref_size, min_size, contig_id):
         """-> blk_var_off (n_blocks + 1 entries) of the kept records, cut as the reference's record loops cut them"""

@@ -1942,6 +1942,46 @@ MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     return MG_OK;
 }
 
+// index time: blocks of one variant whose alleles are all shorter than k (nearly every block of a SNP panel), on the device
+MG_EXPORT int mg_index_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off, const uint32_t *allele_off,
+                                const char *allele_pool, size_t pool_len, const uint64_t *present_mask, const uint8_t *flags, uint8_t *overflow_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!pos || !var_allele_off || !allele_off || !allele_pool || !present_mask || !flags || !overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
+    if (c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_index_isolated after mg_bf_finalize");
+    if (c->map.rows_total + n_vars >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "exact map: more than 2^32-1 insertion rows");
+    const size_t na = var_allele_off[n_vars];
+    for (size_t v = 0; v < n_vars; ++v) // every window the kernel will read lies inside the uploaded reference (as mg_call_isolated checks)
+        if (flags[v] & 1) {
+            const u32 a0 = var_allele_off[v];
+            const u64 rs = allele_off[a0 + 1] - allele_off[a0];
+            if (pos[v] < c->k / 2 || pos[v] + rs + (c->k + 1) / 2 > c->ref_len)
+                return fail(c, MG_ERR_ARG, "variant %zu flagged eligible but its flanks leave the uploaded reference", v);
+        }
+    if (allele_off[na] > pool_len) return fail(c, MG_ERR_ARG, "allele offsets exceed the pool");
+    TRY(map_reserve(c, n_vars)); // may grow and re-hash the table: before the kernel, never under it
+    void *d_pos, *d_vo, *d_ao, *d_pool, *d_pm, *d_fl, *d_ovf;
+    TRY(upload(c, c->s_rows, pos, 8 * n_vars, &d_pos));
+    TRY(upload(c, c->s_aux, var_allele_off, 4 * (n_vars + 1), &d_vo));
+    TRY(upload(c, c->s_misc[0], allele_off, 4 * (na + 1), &d_ao));
+    TRY(upload(c, c->s_misc[1], allele_pool, pool_len, &d_pool));
+    TRY(upload(c, c->s_misc[3], present_mask, 8 * n_vars, &d_pm));
+    TRY(upload(c, c->s_misc[4], flags, n_vars, &d_fl));
+    TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
+    c->gate_dirty = true;
+    hipLaunchKernelGGL(iso_index_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars, (const u64 *)d_pos, (const u32 *)d_vo,
+                       (const u32 *)d_ao, (const u8 *)d_pool, (const u64 *)d_pm, (const u8 *)d_fl, (int)c->k, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total,
+                       (u8 *)d_ovf);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->map.rows_total += n_vars;
+    return MG_OK;
+}
+
 MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 {
     const DeviceGuard on_device(c);

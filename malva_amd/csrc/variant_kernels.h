@@ -223,6 +223,87 @@ __global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32
     genotype_one(cov + a0, freq + a0, (int)A, p, gt1 + v, gt2 + v, gq + v, status + v, probs ? probs + var_gt_off[v] : nullptr);
 }
 
+// ---- isolated variants at INDEX time ------------------------------------------------------------------------------------
+// VB::extract_kmers for a block of one variant whose alleles are all shorter than k (var_block.hpp:95-219 with comb = {v})
+// + add_kmers_to_bf (main.cpp:122-144): the signature k-mer of allele 0 goes into the exact map (KMAP::add_key), that of
+// every other allele some panel haplotype carries sets its bit of `bf` (BF::add_key).  One thread per variant; the
+// signatures are assembled exactly as iso_cover_kernel's fast path assembles them.  A variant with a base outside ACGT
+// in its window or alleles, more than 64 alleles, or k outside 17..64 is only flagged (nothing of it is inserted): the
+// host enumerates it (extract_lone) and inserts through the batch calls.  Variant v's REF key takes insertion row row0 + v.
+__global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off, const u32 *allele_off,
+                                                        const u8 *pool, const u64 *present_mask, const u8 *flags, int k, BFView bf, MapView map, u32 row0,
+                                                        u8 *overflow)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    overflow[v] = 0;
+    if (!(flags[v] & 1)) return; // not present, or within k of a contig end: no k-mers (var_block.hpp:104)
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    const u64 pm = present_mask[v];
+    if (pm == 0) return;
+    const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
+    const u8 *site = reference + pos[v];
+    const int lmax = k / 2, rmax = (k + 1) / 2;
+    if (k < 17 || k > MG_MAX_PACKED_K || A > 64 || k != (int)map.klen) {
+        overflow[v] = 1;
+        return;
+    }
+    u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
+    {
+        const SpanWords ls = span_load(site - lmax, lmax), rs = span_load(site + ref_size, rmax);
+        span_pack(ls, lmax, &lf, &lbad);
+        span_pack(rs, rmax, &rf, &rbad);
+    }
+    // the canonical signature of allele a (L-form), or false when something in it is not ACGT / it does not fit the lone-variant form
+    auto signature = [&](u32 a, U128 *key) -> bool {
+        const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
+        const int mp = k / 2 - alen / 2, ms = (k + 1) / 2 - (alen - alen / 2);
+        if (mp < 0 || ms < 0) return false; // an allele of k bases or more: not this kernel's case
+        if ((lbad >> (lmax - mp)) != 0 || (ms != 0 && (rbad & ((1ULL << ms) - 1)) != 0)) return false;
+        const u8 *al = pool + allele_off[a0 + a];
+        U128 L{0, 0};
+        bool fast = true;
+        for (int i = 0; i < alen; ++i) {
+            bool ok;
+            const u64 code = acgt_code(al[i], &ok);
+            fast &= ok;
+            if (i < 32) L.lo |= code << (2 * i);
+            else L.hi |= code << (2 * (i - 32));
+        }
+        if (!fast) return false;
+        L = shl128(L, 2 * mp);
+        if (mp) L.lo |= lf >> (2 * (lmax - mp)); // last mp bases of the left flank
+        if (ms) {
+            const U128 r = shl128(U128{ms >= 32 ? rf : rf & ((1ULL << (2 * ms)) - 1), 0}, 2 * (mp + alen));
+            L.lo |= r.lo;
+            L.hi |= r.hi;
+        }
+        const U128 mk = mask128(2 * k);
+        const U128 mform = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - k)); // M-form of the k-mer
+        const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};                               // L-form of its reverse complement
+        *key = lt128(L, rc) ? L : rc;
+        return true;
+    };
+    U128 key;
+    for (u32 a = 0; a < A; ++a) // first: can every carried allele be done here?
+        if (((pm >> a) & 1) && !signature(a, &key)) {
+            overflow[v] = 1;
+            return;
+        }
+    for (u32 a = 0; a < A; ++a) {
+        if (!((pm >> a) & 1)) continue;
+        signature(a, &key);
+        const u64 h = xxh3_packed(key, k);
+        if (a == 0)
+            map_insert_key(map, bf, key, h, row0 + (u32)v, row0);
+        else {
+            const u64 idx = mod_size(h, bf.mod);
+            atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
+            gate_set(bf, idx);
+        }
+    }
+}
+
 // ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
 // VB::extract_kmers (var_block.hpp:95-219) with get_combs_on_the_right/left (:436-624), combine_combs (:630-677),
 // get_ref_subs (:682-702) and build_alleles_combs / combine_haplotypes (:709-786), fused with set_coverages

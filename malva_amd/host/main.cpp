@@ -526,10 +526,69 @@ int index_main(const Options &o)
         waiting_base.clear();
         waiting_cells = 0;
     };
-    const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
-        if (vb.is_lone_short()) { // nearly every block of a SNP panel: one k-mer per carried allele, no containers
-            vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
+    // Blocks of one variant whose alleles are all shorter than k -- nearly every block of a SNP panel -- are indexed ON THE
+    // DEVICE too, a batch at a time (mg_index_isolated: signature assembly from the uploaded reference, exact-map insert /
+    // filter bit); the host keeps the few the device hands back (a base outside ACGT in the window) and those whose
+    // right flank a contig end clips (the reference then makes a shorter k-mer, var_block.hpp:187).
+    struct LoneBatch {
+        std::vector<uint64_t> pos, present;
+        std::vector<uint32_t> var_allele_off{0}, allele_off{0};
+        std::vector<char> pool;
+        std::vector<uint8_t> flags;
+        std::vector<Block> blocks; // kept for the variants handed back
+        std::vector<const std::string *> refs;
+        size_t cells = 0;
+        size_t n() const { return pos.size(); }
+    } lone;
+    size_t n_lone_device = 0, n_lone_host = 0;
+    auto index_lone = [&]() {
+        if (!lone.n()) return;
+        std::vector<uint8_t> overflow(lone.n(), 1);
+        dev.check(mg_index_isolated(dev.ctx, lone.n(), lone.pos.data(), lone.var_allele_off.data(), lone.allele_off.data(), lone.pool.data(), lone.pool.size(),
+                                    lone.present.data(), lone.flags.data(), overflow.data()),
+                  "mg_index_isolated");
+        for (size_t v = 0; v < lone.n(); ++v) {
+            if (!overflow[v]) {
+                ++n_lone_device;
+                continue;
+            }
+            ++n_lone_host;
+            lone.blocks[v].extract_lone(*lone.refs[v], o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
             flush(false);
+        }
+        lone = LoneBatch();
+    };
+    const size_t n = for_each_block(vcf, o, refs, true, &used, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
+        if (vb.is_lone_short()) {
+            const Variant &v = vb.vars[0];
+            const bool on_device = !host_only && contig_base.count(seq_name) && v.n_alleles() <= 64 &&
+                                   (long)v.ref_pos + v.ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
+            if (!on_device) { // one k-mer per carried allele, no containers
+                vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
+                flush(false);
+                return;
+            }
+            const bool eligible = v.is_present && v.ref_pos >= (int)o.k && v.ref_pos <= (int)reference.size() - (int)o.k; // var_block.hpp:104
+            uint64_t mask = 0;
+            if (eligible)
+                for (size_t g = 0; g < v.genotypes.size(); ++g) { // build_alleles_combs on a chain of one
+                    mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
+                    if (!o.haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
+                }
+            lone.pos.push_back(contig_base.at(seq_name) + (uint64_t)std::max(v.ref_pos, 0));
+            lone.present.push_back(mask);
+            lone.flags.push_back(eligible ? 1 : 0);
+            for (uint32_t a = 0; a < (uint32_t)v.n_alleles(); ++a) {
+                const std::string &al = v.allele((int)a);
+                lone.pool.insert(lone.pool.end(), al.begin(), al.end());
+                lone.allele_off.push_back((uint32_t)lone.pool.size());
+            }
+            lone.var_allele_off.push_back(lone.var_allele_off.back() + (uint32_t)v.n_alleles());
+            lone.cells += v.genotypes.size();
+            lone.refs.push_back(&reference);
+            lone.blocks.push_back(std::move(vb));
+            vb = Block((int)o.k);
+            if (lone.n() >= 200000 || lone.cells >= (200u << 20)) index_lone();
             return;
         }
         auto cb = contig_base.find(seq_name);
@@ -541,7 +600,11 @@ int index_main(const Options &o)
         if (waiting.size() >= 4096 || waiting_cells >= (200u << 20)) enumerate_waiting(); // bound the panel genotypes held in memory
     }, &dev);
     enumerate_waiting();
+    index_lone();
     flush(true);
+    if (n_lone_device + n_lone_host)
+        std::cerr << "[malva-geno] " << n_lone_device + n_lone_host << " lone variant(s): " << n_lone_device << " indexed on the device, " << n_lone_host
+                  << " on the host" << std::endl;
     if (n_general_blocks)
         std::cerr << "[malva-geno] " << n_general_blocks << " general block(s): " << n_general_blocks - n_host_blocks << " enumerated on the device, " << n_host_blocks
                   << " on the host" << std::endl;

@@ -172,6 +172,45 @@ def test_positions_beyond_2_to_the_25_float_near(tmp_path, haploid):
     assert (want[ok] > 0).sum() > 1000
 
 
+@pytest.mark.parametrize("k,ref_k,n_bad", [(35, 43, 0), (35, 43, 40), (21, 29, 7), (64, 64, 0), (15, 23, 0)])
+def test_lone_variants_indexed_on_the_device(k, ref_k, n_bad):
+    """mg_index_isolated: extract_kmers + add_kmers_to_bf (var_block.hpp:95-219 with comb = {v}; main.cpp:122-144) for blocks of
+    one short variant, against the oracle's add_key calls over the same signatures: same `bf` bits, same exact-map keys.
+    Variants with an N in their window (n_bad of them) and every variant when k < 17 come back flagged and untouched."""
+    from malva_amd import synth
+    bits = 1 << 24
+    panel = synth.snp_panel(4000, 300 + k)
+    genome = panel.genome.copy()
+    rng = np.random.default_rng(k)
+    bad = rng.choice(panel.n, size=n_bad, replace=False) if n_bad else np.zeros(0, dtype=np.int64)
+    for v in bad:
+        genome[int(panel.pos[v]) - 3] = ord("N")
+    sig, valid = synth.snp_signature_rows(synth.Panel(genome=genome, pos=panel.pos, var_allele_off=panel.var_allele_off, allele_off=panel.allele_off,
+                                                      pool=panel.pool, freq=panel.freq, present_mask=panel.present_mask, flags=panel.flags,
+                                                      donor_gt=panel.donor_gt), k)
+    with Context(k, ref_k, bits) as ctx:
+        ctx.reference_upload(genome)
+        ovf = ctx.index_isolated(panel.pos.astype(np.uint64), panel.var_allele_off, panel.allele_off, panel.pool, panel.present_mask, panel.flags)
+        want_ovf = np.zeros(panel.n, dtype=np.uint8)
+        want_ovf[bad] = 1
+        if k < 17:
+            want_ovf[:] = 1
+        assert np.array_equal(ovf, want_ovf)
+        obf, omap = ocapi.BF(bits), ocapi.KMAP()
+        rows = np.zeros((sig.shape[0], 72), dtype=np.uint8)
+        rows[:, :k] = sig
+        keep = np.repeat(want_ovf == 0, 2)                       # signature rows come in (REF, ALT) pairs per variant
+        is_ref = np.zeros(rows.shape[0], dtype=np.uint8)
+        is_ref[0::2] = 1
+        ocapi.add_kmers(obf, omap, rows[keep], is_ref[keep])
+        ctx.bf_finalize(BF_ALT)
+        obf.switch_mode()
+        assert np.array_equal(ctx.bf_export(BF_ALT)[2], obf.words())
+        keys, vals = ctx.map_export()
+        assert sorted(keys) == sorted(k_ for k_, _ in omap.items()) and not vals.any()
+        assert (want_ovf == 0).sum() == 0 or len(keys) > 0
+
+
 @pytest.mark.parametrize("k", [35, 21, 64])
 def test_blocks_cut_on_the_device(k):
     """mg_cut_blocks: the cut test of the record loops (main.cpp:341, 547 -- not near the block's last record, or another

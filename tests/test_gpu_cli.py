@@ -166,6 +166,12 @@ def test_blocks_cut_on_the_device_or_on_the_host(tmp_path, haploid):
     assert n_batches > 40                                       # batches of 7 kept records
     r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, MALVA_GENO_HOST_CUT="1"))
     assert r.returncode == 0 and "cut on the device" not in r.stderr
+    # ... and `index` enumerates on the device too: lone short variants through mg_index_isolated, the rest through mg_index_blocks
+    r = subprocess.run([BIN, "index"] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0
+    lone = r.stderr.split(" lone variant(s): ")[1].split()
+    assert int(lone[0]) > 20 and int(lone[5]) <= 3                # "<n> indexed on the device, <m> on the host" (N / IUPAC windows only)
+    assert " general block(s): " in r.stderr
 
 
 def test_device_capacity_overflow_falls_back_to_host_enumerator(tmp_path):
