@@ -52,10 +52,14 @@ ref:
 	else echo "reference not present: keeping prebuilt oracle/_ref (if any)"; fi
 
 # the microbenchmark behind DESIGN.md's bound for the filter kernel (run it on an MI355X)
-microbench: bin/l2_gather_bench
+microbench: bin/l2_gather_bench bin/ticket_gate_bench
 bin/l2_gather_bench: tools/l2_gather_bench.hip
 	@mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+# the bare access pattern of the ticket form's pass two
+bin/ticket_gate_bench: tools/ticket_gate_bench.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 
 clean:
 	rm -rf malva_amd/lib bin oracle/libmalva_oracle.so oracle/_ref
