@@ -403,7 +403,8 @@ def main():
                          "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                          "units_per_launch": rows_per_launch, "avg_launch_ms": filt_ms},
             # the whole H10 loop (filter + probe + hit kernels, summed): the fraction SURVEY 8(d)'s 44 B/k-mer budget is about
-            "roofline_scan": {"kernels": "scan_filter + scan_probe + scan_hits", "bound": "hbm", "achieved": achieved_scan, "peak": HBM_PEAK_GBS,
+            "roofline_scan": {"kernels": ("scan_ticket_sort + scan_ticket_gate + scan_probe + scan_hits" if ctx.get_option("scan_tickets") else
+                                          "scan_filter + scan_probe + scan_hits"), "bound": "hbm", "achieved": achieved_scan, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved_scan / HBM_PEAK_GBS, "ms": scan_ms_sum, "bytes_per_unit": SCAN_BYTES_PER_KMER,
                               "units_per_launch": rows_per_launch},
             "kernels_ms": {"scan_filter": filt_ms, "scan_probe": probe_ms, "scan_hits": hits_ms, "call_isolated": geno_ms_avg,

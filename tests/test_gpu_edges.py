@@ -185,3 +185,25 @@ def test_calls_from_another_host_thread():
     assert "error" not in got, got.get("error")
     assert np.array_equal(got["counts"], obf.counts()) and got["map"] == dict(omap.items())
     ctx.close()
+
+
+def test_index_isolated_and_cut_blocks_refuse_what_they_cannot_do():
+    """error behaviour of the round-2 entry points: wrong state, missing reference, flanks outside the reference, empty batches"""
+    panel = synth.snp_panel(50, 77)
+    args = (panel.pos.astype(np.uint64), panel.var_allele_off, panel.allele_off, panel.pool, panel.present_mask, panel.flags)
+    with Context(35, 43, 1 << 20) as ctx:
+        with pytest.raises(MalvaError):                                   # no reference uploaded yet
+            ctx.index_isolated(*args)
+        ctx.reference_upload(panel.genome)
+        assert ctx.index_isolated(*(a[:0] if i != 1 else a[:1] for i, a in enumerate(args))).size == 0    # empty batch: no-op
+        far = args[0].copy()
+        far[3] = len(panel.genome) - 5                                    # flagged eligible, right flank leaves the reference
+        with pytest.raises(MalvaError):
+            ctx.index_isolated(far, *args[1:])
+        assert not ctx.index_isolated(*args).any() and ctx.map_size() == 50
+        ctx.bf_finalize(BF_ALT)
+        with pytest.raises(MalvaError):                                   # `bf` is in read mode now
+            ctx.index_isolated(*args)
+        assert len(ctx.cut_blocks([], [], [], [])) == 0
+        assert list(ctx.cut_blocks([10, 20, 100], [1, 1, 1], [1, 1, 1], [0, 0, 0])) == [0, 2, 3]     # 10 + 18 >= 20 near; 20 + 18 < 100
+        assert list(ctx.cut_blocks([10, 20, 21], [1, 1, 1], [1, 1, 1], [0, 1, 1])) == [0, 1, 3]       # another sequence cuts
