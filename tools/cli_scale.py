@@ -88,7 +88,7 @@ def main():
         if r.returncode:
             print(r.stderr[-2000:])
             raise SystemExit("malva-geno %s failed" % sub)
-        phases = [l for l in r.stderr.split("\n") if "Execution Time" in l and "000 variants]" not in l]
+        phases = [l for l in r.stderr.split("\n") if ("Execution Time" in l and "000 variants]" not in l) or "on the device" in l or "on the host" in l]
         print("== malva-geno %s: %.2f s wall = %.3g variants/s\n   %s" % (sub, dt, n / dt, "\n   ".join(phases)), flush=True)
     nrec = sum(1 for l in open(os.path.join(args.dir, "out.vcf")) if not l.startswith("#"))
     print("records written by call: %d" % nrec)
@@ -116,7 +116,7 @@ def c5(args):
             if r.returncode:
                 print(r.stderr[-2000:])
                 raise SystemExit("malva-geno %s failed" % sub)
-            notes = [l for l in r.stderr.split("\n") if "on the host" in l]
+            notes = [l for l in r.stderr.split("\n") if "on the host" in l or "on the device" in l]
             print("== malva-geno %s: %.2f s wall = %.3g records/s %s" % (sub, dt, n / dt, " ".join(notes)), flush=True)
 
 
