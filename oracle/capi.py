@@ -59,6 +59,11 @@ def lib():
             "mo_select_gt": (C.c_int, [vp, C.c_int, vp, vp]),
             "mo_call_isolated": (None, [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float,
                                         C.c_int, C.c_int, vp, vp, vp, vp]),
+            "mo_allele_canon": (None, [sz, vp, vp, vp, vp]),
+            "mo_cut_blocks": (sz, [sz, vp, vp, vp, vp, C.c_int, vp, vp]),
+            "mo_cover_blocks": (C.c_int64, [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, C.c_int, C.c_int, vp, vp]),
+            "mo_index_blocks": (C.c_int64, [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, C.c_int, C.c_int, vp]),
+            "mo_genotype_panel": (None, [vp, vp, vp, sz, C.c_float, C.c_int, C.c_int, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -295,3 +300,75 @@ def call_isolated(bf: BF, ref_bf: KMAP, reference: bytes, pos, allele_off, var_a
                            _p(pool), _p(freq), _p(present_mask), _p(is_present), k, C.c_float(error_rate), max_cov,
                            int(haploid), _p(cov), _p(g1), _p(g2), _p(gq))
     return cov, g1, g2, gq
+
+
+# ---- variant blocks over a flat panel (the arrays mg_cover_blocks / mg_index_blocks take) ---------------------------
+
+def _arr(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def allele_canon(var_allele_off, allele_off, pool):
+    """first allele of the variant with the same text, per allele slot (Variant::get_allele_index, variant.hpp:228-240)"""
+    vo, ao, pool = _arr(var_allele_off, np.uint32), _arr(allele_off, np.uint32), _arr(pool, np.uint8)
+    canon = np.zeros(int(vo[-1]), dtype=np.uint8)
+    lib().mo_allele_canon(len(vo) - 1, _p(vo), _p(ao), _p(pool), _p(canon))
+    return canon
+
+
+def cut_blocks(pos, ref_size, min_size, contig_id, k):
+    """the record loops' block cut (main.cpp:341, 547) -> (blk_var_off [n_blocks + 1], blk_contig [n_blocks])"""
+    pos, rs, ms, cid = _arr(pos, np.int32), _arr(ref_size, np.uint32), _arr(min_size, np.uint32), _arr(contig_id, np.uint32)
+    n = len(pos)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    bc = np.zeros(max(n, 1), dtype=np.uint32)
+    nb = lib().mo_cut_blocks(n, _p(pos), _p(rs), _p(ms), _p(cid), k, _p(off), _p(bc))
+    return off[:nb + 1].copy(), bc[:nb].copy()
+
+
+def _block_args(reference, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, canon, gt,
+                n_samples):
+    ref = np.frombuffer(reference, dtype=np.uint8) if isinstance(reference, (bytes, bytearray)) else _arr(reference, np.uint8)
+    a = dict(ref=ref, bb=_arr(blk_ref_base, np.uint64), bl=_arr(blk_ref_len, np.uint32), bo=_arr(blk_var_off, np.uint32), pos=_arr(pos, np.int32),
+             rs=_arr(ref_size, np.uint32), ms=_arr(min_size, np.uint32), pr=_arr(present, np.uint8), vo=_arr(var_allele_off, np.uint32),
+             ao=_arr(allele_off, np.uint32), pool=_arr(pool, np.uint8), canon=_arr(canon, np.uint8), gt=_arr(gt, np.uint16).reshape(-1))
+    assert a["gt"].size >= len(a["pos"]) * n_samples
+    return a
+
+
+def cover_blocks(bf: BF, ref_bf: KMAP, reference, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off,
+                 allele_off, pool, canon, gt, n_samples, haploid, k, stats=None):
+    """extract_kmers + set_coverages (main.cpp:556-557) for a batch of blocks -> coverage per allele slot"""
+    a = _block_args(reference, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, canon, gt,
+                    n_samples)
+    cov = np.zeros(int(a["vo"][-1]), dtype=np.uint32)
+    st = np.zeros(2, dtype=np.uint64)
+    rc = lib().mo_cover_blocks(bf.h, ref_bf.h, _p(a["ref"]), len(a["bb"]), _p(a["bb"]), _p(a["bl"]), _p(a["bo"]), _p(a["pos"]), _p(a["rs"]), _p(a["ms"]),
+                               _p(a["pr"]), _p(a["vo"]), _p(a["ao"]), _p(a["pool"]), _p(a["canon"]), _p(a["gt"]), n_samples, int(haploid), k, _p(cov), _p(st))
+    if rc != 0:
+        raise IndexError("std::out_of_range in block %d (the reference throws here)" % (-rc - 1))
+    if stats is not None:
+        stats["kmers"], stats["signatures"] = int(st[0]), int(st[1])
+    return cov
+
+
+def index_blocks(bf: BF, ref_bf: KMAP, reference, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off,
+                 allele_off, pool, canon, gt, n_samples, haploid, k):
+    """extract_kmers + add_kmers_to_bf (main.cpp:349-350) for a batch of blocks; returns the k-mers added"""
+    a = _block_args(reference, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, canon, gt,
+                    n_samples)
+    st = np.zeros(2, dtype=np.uint64)
+    rc = lib().mo_index_blocks(bf.h, ref_bf.h, _p(a["ref"]), len(a["bb"]), _p(a["bb"]), _p(a["bl"]), _p(a["bo"]), _p(a["pos"]), _p(a["rs"]), _p(a["ms"]),
+                               _p(a["pr"]), _p(a["vo"]), _p(a["ao"]), _p(a["pool"]), _p(a["canon"]), _p(a["gt"]), n_samples, int(haploid), k, _p(st))
+    if rc != 0:
+        raise IndexError("std::out_of_range in block %d (the reference throws here)" % (-rc - 1))
+    return int(st[0])
+
+
+def genotype_panel(cov, freq, var_allele_off, error_rate, max_cov, haploid):
+    """VB::genotype + normalise / first-strict-max / GQ for every variant -> (gt1, gt2, gq); gt2 = -1 in haploid mode"""
+    cov, freq, vo = _arr(cov, np.uint32), _arr(freq, np.float32), _arr(var_allele_off, np.uint32)
+    n = len(vo) - 1
+    g1, g2, gq = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lib().mo_genotype_panel(_p(cov), _p(freq), _p(vo), n, C.c_float(error_rate), max_cov, int(haploid), _p(g1), _p(g2), _p(gq))
+    return g1, g2, gq

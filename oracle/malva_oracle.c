@@ -777,3 +777,525 @@ MO_API void mo_bf_load_words(mo_bf *b, const uint64_t *words)
 {
     memcpy(b->words, words, b->nwords * 8);
 }
+
+/* ========================================================================= */
+/* Variant blocks over a FLAT panel (the arrays mg_cover_blocks / mg_index_blocks
+ * take), so that the block path can be checked -- and timed -- at sizes the
+ * Python model (oracle/model.py, which this section is tested against) cannot
+ * reach.  Restates, function by function:
+ *   block cut               main.cpp:341, 547 + VB::is_near_to_last var_block.hpp:77-80
+ *   are_overlapping/near    var_block.hpp:408-423
+ *   get_combs_on_the_right  var_block.hpp:436-525
+ *   get_combs_on_the_left   var_block.hpp:534-624
+ *   combine_combs           var_block.hpp:630-677
+ *   get_ref_subs            var_block.hpp:682-702
+ *   combine_haplotypes      var_block.hpp:709-728
+ *   build_alleles_combs     var_block.hpp:734-786
+ *   extract_kmers           var_block.hpp:95-219
+ *   set_coverages           main.cpp:151-184     (mo_cover_blocks)
+ *   add_kmers_to_bf         main.cpp:122-144     (mo_index_blocks)
+ * Containers are restated as growable int arrays; the unordered_set of allele
+ * vectors as a hash set over vectors of "first allele with the same text"
+ * indices (string_view equality is by content, variant.hpp:228-240 resolves the
+ * mid allele the same way).                                                  */
+/* ========================================================================= */
+
+typedef struct {
+    const char *reference;       /* the block's contig */
+    int64_t ref_len;
+    const int32_t *pos;          /* Variant::ref_pos, 0-based */
+    const uint32_t *ref_size, *min_size;
+    const uint8_t *present;      /* Variant::is_present */
+    const uint32_t *var_allele_off, *allele_off;
+    const char *pool;
+    const uint8_t *canon;        /* [slot] first allele index of the variant with the same text */
+    const uint16_t *gt;          /* [v * n_samples + s] = a1 | a2 << 7 | phased << 14 */
+    uint32_t n_samples;
+    int haploid, k;
+} mo_blk;
+
+typedef struct { int *p; int n, cap; } mo_ivec;
+static void iv_push(mo_ivec *v, int x)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 8; v->p = (int *)realloc(v->p, (size_t)v->cap * sizeof(int)); }
+    v->p[v->n++] = x;
+}
+static mo_ivec iv_copy(const mo_ivec *s)
+{
+    mo_ivec d = {NULL, 0, 0};
+    int i;
+    for (i = 0; i < s->n; i++) iv_push(&d, s->p[i]);
+    return d;
+}
+typedef struct { mo_ivec *c; int *sum; int n, cap; } mo_chains;
+static void ch_push(mo_chains *cs, mo_ivec c, int sum)
+{
+    if (cs->n == cs->cap) {
+        cs->cap = cs->cap ? cs->cap * 2 : 4;
+        cs->c = (mo_ivec *)realloc(cs->c, (size_t)cs->cap * sizeof(mo_ivec));
+        cs->sum = (int *)realloc(cs->sum, (size_t)cs->cap * sizeof(int));
+    }
+    cs->c[cs->n] = c; cs->sum[cs->n] = sum; cs->n++;
+}
+static void ch_free(mo_chains *cs)
+{
+    int i;
+    for (i = 0; i < cs->n; i++) free(cs->c[i].p);
+    free(cs->c); free(cs->sum);
+    cs->c = NULL; cs->sum = NULL; cs->n = cs->cap = 0;
+}
+
+/* var_block.hpp:408-412 */
+static int blk_overlapping(const mo_blk *B, int v1, int v2)
+{
+    return B->pos[v1] <= B->pos[v2] && B->pos[v2] < B->pos[v1] + (int)B->ref_size[v1];
+}
+/* var_block.hpp:417-423 (float arithmetic: mo_are_near) */
+static int blk_near(const mo_blk *B, int v1, int v2, int sum_to_add)
+{
+    return mo_are_near(B->pos[v1], (int)B->ref_size[v1], (int)B->min_size[v1], sum_to_add, B->k, B->pos[v2]);
+}
+
+/* get_combs_on_the_right (step = +1, var_block.hpp:436-525) and _left (step = -1, :534-624): mirror images; the
+ * argument order of are_overlapping / are_near is always (left variant, right variant) on the genome. */
+static void blk_walk(const mo_blk *B, int b0, int b1, int i, int step, mo_chains *combs)
+{
+    int halt = 0, j, c;
+    for (j = i + step; j >= b0 && j < b1 && !halt; j += step) {
+        const int gain = (int)B->ref_size[j] - (int)B->min_size[j];
+        if (!B->present[j]) continue;
+        if (step > 0 ? blk_overlapping(B, i, j) : blk_overlapping(B, j, i)) continue;
+        if (combs->n == 0) { /* first var to be added */
+            if (step > 0 ? blk_near(B, i, j, 0) : blk_near(B, j, i, 0)) {
+                mo_ivec nc = {NULL, 0, 0};
+                iv_push(&nc, j);
+                ch_push(combs, nc, gain);
+            }
+            continue;
+        }
+        {
+            int added = 0;
+            const int n0 = combs->n;
+            for (c = 0; c < n0; c++) {
+                const int last = combs->c[c].p[combs->c[c].n - 1];
+                if (!(step > 0 ? blk_overlapping(B, last, j) : blk_overlapping(B, j, last))) {
+                    added = 1;
+                    if (step > 0 ? blk_near(B, i, j, combs->sum[c]) : blk_near(B, j, i, combs->sum[c])) {
+                        iv_push(&combs->c[c], j);
+                        combs->sum[c] += gain;
+                    }
+                }
+            }
+            if (!added) { /* shorten the combinations and try to add the var */
+                mo_chains fresh = {NULL, NULL, 0, 0};
+                for (c = 0; c < n0; c++) {
+                    mo_ivec nc = iv_copy(&combs->c[c]);
+                    int ns = combs->sum[c];
+                    /* (the reference reads back() of an emptied vector here: restated as "stop when empty", like oracle/model.py) */
+                    while (nc.n > 0 && (step > 0 ? blk_overlapping(B, nc.p[nc.n - 1], j) : blk_overlapping(B, j, nc.p[nc.n - 1]))) {
+                        const int m = nc.p[nc.n - 1];
+                        ns -= (int)B->ref_size[m] - (int)B->min_size[m];
+                        nc.n--;
+                    }
+                    iv_push(&nc, j);
+                    if (step > 0 ? blk_near(B, i, j, ns) : blk_near(B, j, i, ns)) {
+                        added = 1;
+                        ch_push(&fresh, nc, ns + gain);
+                    } else
+                        free(nc.p);
+                }
+                for (c = 0; c < fresh.n; c++) ch_push(combs, fresh.c[c], fresh.sum[c]);
+                free(fresh.c); free(fresh.sum);
+                if (!added) halt = 1;
+            }
+        }
+    }
+}
+
+/* a set of byte vectors of one length (the unordered_set<vector<string_view>> of build_alleles_combs) */
+typedef struct { uint8_t *pool; int64_t *slot; size_t n, cap, pcap; int width; } mo_pickset;
+static void ps_init(mo_pickset *s, int width)
+{
+    size_t i;
+    s->width = width; s->n = 0; s->cap = 64; s->pcap = 64;
+    s->pool = (uint8_t *)malloc(s->pcap * (size_t)width);
+    s->slot = (int64_t *)malloc(s->cap * 8);
+    for (i = 0; i < s->cap; i++) s->slot[i] = -1;
+}
+static void ps_free(mo_pickset *s) { free(s->pool); free(s->slot); }
+static uint64_t ps_hash(const uint8_t *p, int w)
+{
+    uint64_t h = 0xcbf29ce484222325ULL; int i;
+    for (i = 0; i < w; i++) { h ^= p[i]; h *= 0x100000001b3ULL; }
+    return h ^ (h >> 31);
+}
+static void ps_insert(mo_pickset *s, const uint8_t *p)
+{
+    const size_t w = (size_t)s->width;
+    size_t i;
+    if ((s->n + 1) * 2 > s->cap) {
+        size_t ncap = s->cap * 2, e;
+        free(s->slot);
+        s->slot = (int64_t *)malloc(ncap * 8);
+        for (i = 0; i < ncap; i++) s->slot[i] = -1;
+        for (e = 0; e < s->n; e++) {
+            i = ps_hash(s->pool + e * w, s->width) & (ncap - 1);
+            while (s->slot[i] >= 0) i = (i + 1) & (ncap - 1);
+            s->slot[i] = (int64_t)e;
+        }
+        s->cap = ncap;
+    }
+    i = ps_hash(p, s->width) & (s->cap - 1);
+    while (s->slot[i] >= 0) {
+        if (memcmp(s->pool + (size_t)s->slot[i] * w, p, w) == 0) return;
+        i = (i + 1) & (s->cap - 1);
+    }
+    if (s->n == s->pcap) { s->pcap *= 2; s->pool = (uint8_t *)realloc(s->pool, s->pcap * w); }
+    memcpy(s->pool + s->n * w, p, w);
+    s->slot[i] = (int64_t)s->n++;
+}
+
+/* what extract_kmers hands on: one signature (list of k-mers) of allele `allele` of variant v */
+typedef int (*mo_sig_fn)(void *ud, int v, int allele, const char *kmers, size_t n_kmers, size_t stride);
+
+/* std::string(s, pos, n): clips at the end; pos beyond the size throws (-> -1); a negative n converts to a huge size_t (-> to the end) */
+static int64_t std_substr(const char *s, int64_t size, int64_t pos, int64_t n, char *out)
+{
+    int64_t m;
+    if (pos < 0 || pos > size) return -1;
+    m = n < 0 ? size - pos : (pos + n > size ? size - pos : n);
+    memcpy(out, s + pos, (size_t)m);
+    return m;
+}
+
+/* extract_kmers for the variants [b0, b1) of one block, var_block.hpp:95-219.  Returns 0, or -1 where the reference throws
+ * std::out_of_range (a window that starts before the contig or a cut longer than the string). */
+static int blk_extract(const mo_blk *B, int b0, int b1, mo_sig_fn emit, void *ud)
+{
+    const int k = B->k;
+    int vi, rc = 0;
+    size_t bufcap = 4096;
+    char *kmer = (char *)malloc(bufcap), *sig = NULL;
+    size_t sigcap = 0;
+    for (vi = b0; vi < b1 && rc == 0; vi++) {
+        mo_chains right = {NULL, NULL, 0, 0}, left = {NULL, NULL, 0, 0}, combs = {NULL, NULL, 0, 0};
+        int c;
+        if (!B->present[vi] || B->pos[vi] < k || (int64_t)B->pos[vi] > B->ref_len - k) continue; /* var_block.hpp:104 */
+        blk_walk(B, b0, b1, vi, +1, &right);
+        blk_walk(B, b0, b1, vi, -1, &left);
+        /* combine_combs, var_block.hpp:630-677 */
+        if (left.n == 0 && right.n == 0) {
+            mo_ivec cb = {NULL, 0, 0};
+            iv_push(&cb, vi);
+            ch_push(&combs, cb, 0);
+        } else if (left.n == 0) {
+            for (c = 0; c < right.n; c++) {
+                mo_ivec cb = {NULL, 0, 0};
+                int q;
+                iv_push(&cb, vi);
+                for (q = 0; q < right.c[c].n; q++) iv_push(&cb, right.c[c].p[q]);
+                ch_push(&combs, cb, 0);
+            }
+        } else {
+            int l;
+            for (l = 0; l < left.n; l++) {
+                mo_ivec lc = {NULL, 0, 0};
+                int q;
+                for (q = left.c[l].n - 1; q >= 0; q--) iv_push(&lc, left.c[l].p[q]); /* reverse */
+                iv_push(&lc, vi);
+                if (right.n == 0)
+                    ch_push(&combs, lc, 0);
+                else {
+                    for (c = 0; c < right.n; c++) {
+                        mo_ivec cb = iv_copy(&lc);
+                        for (q = 0; q < right.c[c].n; q++) iv_push(&cb, right.c[c].p[q]);
+                        ch_push(&combs, cb, 0);
+                    }
+                    free(lc.p);
+                }
+            }
+        }
+        for (c = 0; c < combs.n && rc == 0; c++) {
+            const int *comb = combs.c[c].p;
+            const int m = combs.c[c].n;
+            mo_pickset aacs;
+            uint8_t *hap1 = (uint8_t *)malloc((size_t)m), *hap2 = (uint8_t *)malloc((size_t)m), *row = (uint8_t *)malloc((size_t)m);
+            uint32_t gt_i;
+            size_t e;
+            int j;
+            /* build_alleles_combs, var_block.hpp:734-786: for each individual having this variant */
+            ps_init(&aacs, m);
+            for (gt_i = 0; gt_i < B->n_samples; gt_i++) {
+                int phased = 1;
+                for (j = 0; j < m; j++) {
+                    const uint16_t g = B->gt[(size_t)comb[j] * B->n_samples + gt_i];
+                    const uint32_t a0 = B->var_allele_off[comb[j]];
+                    phased &= (g >> 14) & 1;
+                    hap1[j] = B->canon[a0 + (g & 127)];
+                    hap2[j] = B->canon[a0 + ((g >> 7) & 127)];
+                }
+                if (B->haploid)
+                    ps_insert(&aacs, hap1);
+                else if (phased) {
+                    ps_insert(&aacs, hap1);
+                    ps_insert(&aacs, hap2);
+                } else { /* combine_haplotypes, var_block.hpp:709-728: 2N rows, N = 2^(n-1) */
+                    const int64_t N = (int64_t)1 << (m - 1);
+                    int64_t col;
+                    if (m > 30) { rc = -2; break; } /* 2^31 rows per sample: beyond anything the tests build */
+                    for (col = 0; col < 2 * N; col++) {
+                        int level;
+                        for (level = 0; level < m; level++) {
+                            const int64_t rep = (int64_t)1 << (m - 1 - level);
+                            const int64_t q = col < N ? (col / rep) % 2 : ((col - N) / rep + 1) % 2;
+                            row[level] = q ? hap2[level] : hap1[level];
+                        }
+                        ps_insert(&aacs, row);
+                    }
+                }
+            }
+            for (e = 0; e < aacs.n && rc == 0; e++) {
+                const uint8_t *aac = aacs.pool + e * (size_t)m;
+                int mid_allele = -1;
+                size_t n_kmers = 0;
+                const size_t stride = (size_t)k + 1;
+                if (m == 1) {
+                    const uint32_t s0 = B->var_allele_off[comb[0]] + aac[0];
+                    const uint32_t al = B->allele_off[s0 + 1] - B->allele_off[s0];
+                    if (al >= (uint32_t)k) { /* var_block.hpp:130-144: every k-mer of the allele */
+                        uint32_t p;
+                        mid_allele = aac[0];
+                        n_kmers = al - (uint32_t)k + 1;
+                        if (n_kmers * stride > sigcap) { sigcap = n_kmers * stride; sig = (char *)realloc(sig, sigcap); }
+                        for (p = 0; p < n_kmers; p++) {
+                            memcpy(sig + p * stride, B->pool + B->allele_off[s0] + p, (size_t)k);
+                            sig[p * stride + (size_t)k] = 0;
+                        }
+                    }
+                }
+                if (mid_allele < 0) { /* var_block.hpp:146-199 */
+                    int64_t len = 0, mid_pos = 0, mid_len = 0, last_end = -1;
+                    int64_t first_part, second_part, mp, ms;
+                    for (j = 0; j < m; j++) {
+                        const uint32_t s0 = B->var_allele_off[comb[j]] + aac[j];
+                        const int64_t al = (int64_t)(B->allele_off[s0 + 1] - B->allele_off[s0]);
+                        int64_t rs_pos = 0, rs_n = 0, got = 0;
+                        const int has_rs = j + 1 < m; /* get_ref_subs, var_block.hpp:682-702: the reference between member j and j + 1 */
+                        (void)last_end;
+                        if (has_rs) {
+                            rs_pos = (int64_t)B->pos[comb[j]] + (int64_t)B->ref_size[comb[j]];
+                            rs_n = (int64_t)B->pos[comb[j + 1]] - rs_pos;
+                        }
+                        while ((size_t)(len + al + (has_rs ? (rs_n < 0 ? B->ref_len : rs_n) : 0) + 2 * k + 16) > bufcap) { bufcap *= 2; kmer = (char *)realloc(kmer, bufcap); }
+                        if (comb[j] == vi) { mid_pos = len; mid_len = al; mid_allele = aac[j]; }
+                        memcpy(kmer + len, B->pool + B->allele_off[s0], (size_t)al);
+                        len += al;
+                        if (has_rs) {
+                            got = std_substr(B->reference, B->ref_len, rs_pos, rs_n, kmer + len);
+                            if (got < 0) { rc = -1; break; }
+                            len += got;
+                        }
+                    }
+                    if (rc) break;
+                    first_part = mid_pos + mid_len / 2;
+                    second_part = len - first_part;
+                    mp = k / 2 - first_part;
+                    ms = (int64_t)(ceilf((float)k / 2) - (float)second_part);
+                    if (mp >= 0) { /* extending on the left */
+                        char pre[k + 1];
+                        const int64_t got = std_substr(B->reference, B->ref_len, (int64_t)B->pos[comb[0]] - mp, mp, pre);
+                        if (got < 0) { rc = -1; break; }
+                        memmove(kmer + got, kmer, (size_t)len);
+                        memcpy(kmer, pre, (size_t)got);
+                        len += got;
+                    } else {
+                        if (-mp >= len) len = 0; /* erase(0, n) clips n to the size: nothing throws, the string is emptied */
+                        else {
+                            memmove(kmer, kmer - mp, (size_t)(len + mp));
+                            len += mp;
+                        }
+                    }
+                    if (ms >= 0) { /* extending on the right */
+                        const int last = comb[m - 1];
+                        const int64_t got = std_substr(B->reference, B->ref_len, (int64_t)B->pos[last] + (int64_t)B->ref_size[last], ms, kmer + len);
+                        if (got < 0) { rc = -1; break; }
+                        len += got;
+                    } else {
+                        if (-ms > len) { rc = -1; break; } /* erase(size - n, n) with n > size: out_of_range */
+                        len += ms;
+                    }
+                    n_kmers = 1;
+                    if ((size_t)len + 1 > sigcap) { sigcap = (size_t)len + 1 + stride; sig = (char *)realloc(sig, sigcap); }
+                    memcpy(sig, kmer, (size_t)len);
+                    sig[len] = 0;
+                }
+                rc = emit(ud, vi, (int)B->canon[B->var_allele_off[vi] + (uint32_t)mid_allele], sig, n_kmers, stride);
+            }
+            ps_free(&aacs);
+            free(hap1); free(hap2); free(row);
+        }
+        ch_free(&right); ch_free(&left); ch_free(&combs);
+    }
+    free(kmer); free(sig);
+    return rc;
+}
+
+/* `canon` of a flat panel: first allele of the variant with the same text (Variant::get_allele_index, variant.hpp:228-240) */
+MO_API void mo_allele_canon(size_t n_vars, const uint32_t *var_allele_off, const uint32_t *allele_off, const char *pool, uint8_t *canon)
+{
+    size_t v;
+    for (v = 0; v < n_vars; v++) {
+        const uint32_t a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+        uint32_t a, b;
+        for (a = 0; a < A; a++) {
+            const uint32_t la = allele_off[a0 + a + 1] - allele_off[a0 + a];
+            canon[a0 + a] = (uint8_t)a;
+            for (b = 0; b < a; b++) {
+                const uint32_t lb = allele_off[a0 + b + 1] - allele_off[a0 + b];
+                if (la == lb && memcmp(pool + allele_off[a0 + a], pool + allele_off[a0 + b], la) == 0) { canon[a0 + a] = (uint8_t)b; break; }
+            }
+        }
+    }
+}
+
+/* The record loop's block cut (main.cpp:341, 547) over the kept records of a file, in order.  contig_id[0] is the id of
+ * `last_seq_name` as it stands when record 0 arrives (main.cpp:333-334, 533-534).  Writes the first record of every block
+ * and n behind the last, and per block the id of the sequence it is evaluated against (`last_seq_name` at the flush,
+ * main.cpp:556).  Returns the number of blocks. */
+MO_API size_t mo_cut_blocks(size_t n, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint32_t *contig_id,
+                            int k, uint32_t *blk_var_off, uint32_t *blk_contig)
+{
+    size_t i, nb = 0;
+    uint32_t last;
+    if (n == 0) return 0;
+    last = contig_id[0];
+    blk_var_off[0] = 0;
+    for (i = 1; i < n; i++) {
+        /* !vb.is_near_to_last(v) || last_seq_name != v.seq_name */
+        if (!mo_are_near(pos[i - 1], (int)ref_size[i - 1], (int)min_size[i - 1], 0, k, pos[i]) || last != contig_id[i]) {
+            if (blk_contig) blk_contig[nb] = last;
+            blk_var_off[++nb] = (uint32_t)i;
+            if (last != contig_id[i]) last = contig_id[i];
+        }
+    }
+    if (blk_contig) blk_contig[nb] = last;
+    blk_var_off[++nb] = (uint32_t)n;
+    return nb;
+}
+
+typedef struct {
+    const mo_bf *bf;
+    const mo_kmap *ref_bf;
+    uint32_t *cov;  /* per allele slot: running max of the signatures' means (set_coverages' allele_cov) */
+    const uint32_t *var_allele_off;
+    uint64_t n_kmers, n_sigs;
+} cover_ud;
+static int cover_emit(void *ud_, int v, int allele, const char *kmers, size_t n_kmers, size_t stride)
+{
+    cover_ud *ud = (cover_ud *)ud_;
+    unsigned curr_cov = 0;
+    int n = 0;
+    size_t i;
+    for (i = 0; i < n_kmers; i++) { /* main.cpp:164-176 */
+        const char *kmer = kmers + i * stride;
+        int w = allele == 0 ? mo_kmap_get_count(ud->ref_bf, kmer) : (int)mo_bf_get_count(ud->bf, kmer);
+        if (w > 0) {
+            curr_cov = (curr_cov * (unsigned)n + (unsigned)w) / (unsigned)(n + 1);
+            ++n;
+        }
+    }
+    if (curr_cov > ud->cov[ud->var_allele_off[v] + (uint32_t)allele]) ud->cov[ud->var_allele_off[v] + (uint32_t)allele] = curr_cov;
+    ud->n_kmers += n_kmers;
+    ud->n_sigs++;
+    return 0;
+}
+typedef struct {
+    mo_bf *bf;
+    mo_kmap *ref_bf;
+    uint64_t n_kmers;
+} index_ud;
+static int index_emit(void *ud_, int v, int allele, const char *kmers, size_t n_kmers, size_t stride)
+{
+    index_ud *ud = (index_ud *)ud_;
+    size_t i;
+    (void)v;
+    for (i = 0; i < n_kmers; i++) { /* add_kmers_to_bf, main.cpp:133-140 */
+        if (allele == 0) mo_kmap_add_key(ud->ref_bf, kmers + i * stride);
+        else mo_bf_add_key(ud->bf, kmers + i * stride);
+    }
+    ud->n_kmers += n_kmers;
+    return 0;
+}
+
+static mo_blk blk_view(const char *reference, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, size_t b, const int32_t *pos,
+                       const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                       const uint32_t *allele_off, const char *pool, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples, int haploid, int k)
+{
+    mo_blk B;
+    B.reference = reference + blk_ref_base[b];
+    B.ref_len = (int64_t)blk_ref_len[b];
+    B.pos = pos; B.ref_size = ref_size; B.min_size = min_size; B.present = present;
+    B.var_allele_off = var_allele_off; B.allele_off = allele_off; B.pool = pool; B.canon = canon; B.gt = gt;
+    B.n_samples = n_samples; B.haploid = haploid; B.k = k;
+    return B;
+}
+
+/* extract_kmers + set_coverages (main.cpp:556-557) for a batch of blocks; cov_out as set_variant_coverage leaves it
+ * (through a float, var_block.hpp:84).  stats_out (optional): [0] signature k-mers looked up, [1] signatures.
+ * Returns 0, or the (1-based, negated) block in which the reference would have thrown. */
+MO_API int64_t mo_cover_blocks(const mo_bf *bf, const mo_kmap *ref_bf, const char *reference, size_t n_blocks, const uint64_t *blk_ref_base,
+                               const uint32_t *blk_ref_len, const uint32_t *blk_var_off, const int32_t *pos, const uint32_t *ref_size,
+                               const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off, const uint32_t *allele_off,
+                               const char *pool, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples, int haploid, int k,
+                               uint32_t *cov_out, uint64_t *stats_out)
+{
+    size_t b, s;
+    const size_t n_slots = var_allele_off[blk_var_off[n_blocks]];
+    cover_ud ud = {bf, ref_bf, cov_out, var_allele_off, 0, 0};
+    for (s = 0; s < n_slots; s++) cov_out[s] = 0;
+    for (b = 0; b < n_blocks; b++) {
+        const mo_blk B = blk_view(reference, blk_ref_base, blk_ref_len, b, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, canon,
+                                  gt, n_samples, haploid, k);
+        if (blk_extract(&B, (int)blk_var_off[b], (int)blk_var_off[b + 1], cover_emit, &ud) != 0) return -(int64_t)(b + 1);
+    }
+    for (s = 0; s < n_slots; s++) { float f = (float)cov_out[s]; cov_out[s] = (uint32_t)f; }
+    if (stats_out) { stats_out[0] = ud.n_kmers; stats_out[1] = ud.n_sigs; }
+    return 0;
+}
+
+/* extract_kmers + add_kmers_to_bf (main.cpp:349-350) for a batch of blocks (index time: the blocks hold only the
+ * variants `index` keeps, main.cpp:332).  Same return convention. */
+MO_API int64_t mo_index_blocks(mo_bf *bf, mo_kmap *ref_bf, const char *reference, size_t n_blocks, const uint64_t *blk_ref_base,
+                               const uint32_t *blk_ref_len, const uint32_t *blk_var_off, const int32_t *pos, const uint32_t *ref_size,
+                               const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off, const uint32_t *allele_off,
+                               const char *pool, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples, int haploid, int k, uint64_t *stats_out)
+{
+    size_t b;
+    index_ud ud = {bf, ref_bf, 0};
+    for (b = 0; b < n_blocks; b++) {
+        const mo_blk B = blk_view(reference, blk_ref_base, blk_ref_len, b, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, canon,
+                                  gt, n_samples, haploid, k);
+        if (blk_extract(&B, (int)blk_var_off[b], (int)blk_var_off[b + 1], index_emit, &ud) != 0) return -(int64_t)(b + 1);
+    }
+    if (stats_out) stats_out[0] = ud.n_kmers;
+    return 0;
+}
+
+/* VB::genotype + the normalise / first-strict-max / GQ part of output_variants for every variant of a flat panel
+ * (main.cpp:558-559): gt2 = -1 in haploid mode; "nothing beats 0.0" comes back as 0 / 0 (best_geno "0/0" or "0"). */
+MO_API void mo_genotype_panel(const uint32_t *cov, const float *freq, const uint32_t *var_allele_off, size_t n_vars, float error_rate, int max_cov,
+                              int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq_out)
+{
+    size_t v;
+    for (v = 0; v < n_vars; v++) {
+        const uint32_t a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+        int cap = (int)(A * (A + 1) / 2 + A + 2), n, bi, gq;
+        int g1s[cap], g2s[cap];
+        double vals[cap];
+        n = mo_genotype(cov + a0, freq + a0, (int)A, error_rate, max_cov, haploid, g1s, g2s, vals, cap);
+        bi = mo_select_gt(vals, n, NULL, &gq);
+        gt1[v] = bi < 0 ? 0 : g1s[bi];
+        gt2[v] = bi < 0 ? (haploid ? -1 : 0) : g2s[bi];
+        gq_out[v] = gq;
+    }
+}

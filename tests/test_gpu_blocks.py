@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import vcf_synth
+from block_util import pack_blocks
 from malva_amd import BF_ALT, BF_CTX, Context
 from malva_amd.capi import rows_of
 from oracle import capi as ocapi
@@ -11,33 +12,6 @@ from oracle import pipeline
 from oracle.model import VCFReader, flatten_vk, read_fasta
 
 pytestmark = pytest.mark.gpu
-
-
-def pack_blocks(blocks, contig_base, contig_len):
-    """[(VB, contig name)] -> flat arrays of mg_cover_blocks"""
-    bb, bl, bo = [], [], [0]
-    pos, rs, ms, pr, vo, ao, pool, canon, gts = [], [], [], [], [0], [0], bytearray(), [], []
-    n_samples = None
-    for vb, name in blocks:
-        bb.append(contig_base.get(name, 0)); bl.append(contig_len.get(name, 0))
-        for v in vb.variants:
-            pos.append(v.ref_pos); rs.append(v.ref_size); ms.append(v.min_size if v.alts else v.ref_size); pr.append(int(v.is_present))
-            alleles = [v.ref_sub] + v.alts
-            for a, al in enumerate(alleles):
-                pool += al.encode(); ao.append(len(pool)); canon.append(v.get_allele_index(al))
-            vo.append(vo[-1] + len(alleles))
-            g = np.zeros(len(v.genotypes), dtype=np.uint16)
-            for s, ((a1, a2), ph) in enumerate(zip(v.genotypes, v.phasing)):
-                assert a1 < len(alleles) and a2 < len(alleles)
-                g[s] = a1 | (a2 << 7) | (int(ph) << 14)
-            gts.append(g)
-        bo.append(len(pos))
-    n_samples = max((len(g) for g in gts), default=0)
-    gt = np.zeros((len(pos), n_samples), dtype=np.uint16)
-    for i, g in enumerate(gts):
-        gt[i, :len(g)] = g           # non-present variants carry no genotypes; their rows are never read
-    return dict(blk_ref_base=bb, blk_ref_len=bl, blk_var_off=bo, pos=pos, ref_size=rs, min_size=ms, present=pr, var_allele_off=vo,
-                allele_off=ao, pool=np.frombuffer(bytes(pool), dtype=np.uint8), canon=canon, gt=gt, n_samples=n_samples)
 
 
 @pytest.mark.parametrize("seed,haploid,k,ref_k", [(31, False, 35, 43), (32, True, 35, 43), (33, False, 31, 41), (34, False, 21, 29),
