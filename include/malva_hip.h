@@ -234,6 +234,47 @@ int mg_index_blocks(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, 
                     const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
                     const uint16_t *gt, uint32_t n_samples, int haploid, uint8_t *overflow_out);
 
+/* ---- the record loop on a RESIDENT panel (main.cpp:522-579 / 309-370 with every array already in HBM) --------------------
+ * A panel is the kept records of a VCF (or of a batch of one) in file order, as flat arrays: every pointer below is a
+ * DEVICE pointer on the context's GPU, nothing is copied or re-uploaded, and the calls are asynchronous on the
+ * context's stream (mg_index_blocks_device excepted, see there).  Record v sits on sequence contig_id[v], which starts
+ * at contig_base[] in the buffer of mg_reference_upload and is contig_len[] long; the other arrays are those of
+ * mg_cover_blocks.  One step of `call` on a resident panel is
+ *     mg_cut_blocks_device -> mg_cover_blocks_device -> mg_genotype_device
+ * and of `index`:  mg_cut_blocks_device -> mg_index_blocks_device. */
+typedef struct mg_panel_dev {
+    uint64_t n_vars;
+    uint32_t n_contigs;
+    uint32_t n_samples;
+    const uint64_t *contig_base;     /* [n_contigs] */
+    const uint32_t *contig_len;      /* [n_contigs] */
+    const uint32_t *contig_id;       /* [n_vars]; contig_id[0] as for mg_cut_blocks */
+    const int32_t *pos;              /* [n_vars] Variant::ref_pos */
+    const uint32_t *ref_size;        /* [n_vars] */
+    const uint32_t *min_size;        /* [n_vars] */
+    const uint8_t *present;          /* [n_vars] Variant::is_present */
+    const uint32_t *var_allele_off;  /* [n_vars + 1] */
+    const uint32_t *allele_off;      /* [slots + 1] */
+    const char *pool;
+    const uint8_t *canon;            /* [slots] */
+    const uint16_t *gt;              /* [n_vars][n_samples] */
+} mg_panel_dev;
+/* The cut (main.cpp:341, 547) of all n_vars records: d_blk_var_off_out ([n_vars + 1] u32), d_n_blocks_out (one u64), and
+ * -- optional, NULL to skip -- d_var_block_out ([n_vars] u32: the block of every record, which the two calls below
+ * otherwise derive again).  Needs contig_id, pos, ref_size, min_size only. */
+int mg_cut_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, void *d_blk_var_off_out, void *d_var_block_out, void *d_n_blocks_out);
+/* extract_kmers + set_coverages (main.cpp:556-557) for every block: d_cov_out ([slots] u32) and d_overflow_out ([n_vars]
+ * u8) as mg_cover_blocks returns them.  A block is evaluated against the sequence of its first record (`last_seq_name` at
+ * the flush, main.cpp:556).  Blocks of one variant whose alleles are all shorter than k take the fused lone-variant kernels
+ * (those of mg_call_isolated), the others the enumerating kernel, launched as a persistent grid over their list. */
+int mg_cover_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d_blk_var_off, const void *d_var_block /* or NULL */,
+                           const void *d_n_blocks, int haploid, void *d_cov_out, void *d_overflow_out);
+/* extract_kmers + add_kmers_to_bf (main.cpp:349-350) for every block (the panel holds only what `index` keeps,
+ * main.cpp:332); d_overflow_out as mg_index_blocks.  The arrays stay where they are, but the call waits for the device
+ * twice on eight bytes: the exact map is sized from a counting pass before the insert pass runs. */
+int mg_index_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d_blk_var_off, const void *d_var_block /* or NULL */,
+                           const void *d_n_blocks, int haploid, void *d_overflow_out);
+
 /* Result codes of mg_genotype / mg_call_isolated per variant */
 #define MG_GT_NORMAL 0   /* likelihood list computed                              */
 #define MG_GT_OVERCOV 1  /* some allele > max_cov: (best_geno,0) per such allele  */
@@ -260,6 +301,10 @@ int mg_index_isolated(mg_ctx *ctx, size_t n_vars, const uint64_t *pos, const uin
 int mg_genotype(mg_ctx *ctx, const uint32_t *cov, const float *freq, const uint32_t *var_allele_off, size_t n_vars,
                 float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq,
                 uint8_t *status, double *probs, const uint64_t *var_gt_off);
+/* same, every array already resident on the device (asynchronous) */
+int mg_genotype_device(mg_ctx *ctx, const void *d_cov, const void *d_freq, const void *d_var_allele_off, size_t n_vars,
+                       float error_rate, int max_cov, int haploid, void *d_gt1, void *d_gt2, void *d_gq, void *d_status,
+                       void *d_probs, const void *d_var_gt_off);
 
 /* Fused device path for blocks that hold ONE variant whose alleles are all
  * shorter than k (the isolated-SNP/indel case): signature enumeration

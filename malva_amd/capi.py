@@ -104,6 +104,10 @@ def lib():
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
         "mg_cut_blocks": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "mg_cut_blocks_device": [vp, vp, vp, vp, vp],
+        "mg_cover_blocks_device": [vp, vp, vp, vp, vp, it, vp, vp],
+        "mg_index_blocks_device": [vp, vp, vp, vp, vp, it, vp],
+        "mg_genotype_device": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_index_isolated": [vp, sz, vp, vp, vp, vp, sz, vp, vp, vp],
         "mg_index_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp],
         "mg_reference_upload": [vp, vp, sz],
@@ -139,7 +143,8 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
-            "mg_counters_allreduce_all", "mg_cut_blocks", "mg_index_isolated",
+            "mg_counters_allreduce_all", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
+            "mg_index_isolated",
             "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_set_option", "mg_get_option"]
@@ -147,6 +152,13 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PanelDev(C.Structure):
+    """mg_panel_dev: a panel resident in HBM (every pointer a device pointer)"""
+    _fields_ = [("n_vars", C.c_uint64), ("n_contigs", C.c_uint32), ("n_samples", C.c_uint32), ("contig_base", C.c_void_p), ("contig_len", C.c_void_p),
+                ("contig_id", C.c_void_p), ("pos", C.c_void_p), ("ref_size", C.c_void_p), ("min_size", C.c_void_p), ("present", C.c_void_p),
+                ("var_allele_off", C.c_void_p), ("allele_off", C.c_void_p), ("pool", C.c_void_p), ("canon", C.c_void_p), ("gt", C.c_void_p)]
 
 
 def host_alloc(n_bytes):
@@ -505,6 +517,24 @@ class Context:
         nb = C.c_size_t(0)
         self._ck(self._L.mg_cut_blocks(self.h, n, _p(pos), _p(rs), _p(ms), _p(cid), _p(off), C.byref(nb)))
         return off[:nb.value + 1] if n else off[:0]
+
+    # the record loop on a resident panel (device pointers; asynchronous)
+    def cut_blocks_device(self, panel: PanelDev, d_blk_var_off, d_var_block, d_n_blocks):
+        v = C.c_void_p
+        self._ck(self._L.mg_cut_blocks_device(self.h, C.byref(panel), v(d_blk_var_off), v(d_var_block), v(d_n_blocks)))
+
+    def cover_blocks_device(self, panel: PanelDev, d_blk_var_off, d_var_block, d_n_blocks, haploid, d_cov, d_overflow):
+        v = C.c_void_p
+        self._ck(self._L.mg_cover_blocks_device(self.h, C.byref(panel), v(d_blk_var_off), v(d_var_block), v(d_n_blocks), int(haploid), v(d_cov), v(d_overflow)))
+
+    def index_blocks_device(self, panel: PanelDev, d_blk_var_off, d_var_block, d_n_blocks, haploid, d_overflow):
+        v = C.c_void_p
+        self._ck(self._L.mg_index_blocks_device(self.h, C.byref(panel), v(d_blk_var_off), v(d_var_block), v(d_n_blocks), int(haploid), v(d_overflow)))
+
+    def genotype_device(self, d_cov, d_freq, d_var_allele_off, n_vars, error_rate, max_cov, haploid, d_g1, d_g2, d_gq, d_st, d_probs=None, d_gt_off=None):
+        v = C.c_void_p
+        self._ck(self._L.mg_genotype_device(self.h, v(d_cov), v(d_freq), v(d_var_allele_off), n_vars, C.c_float(error_rate), max_cov, int(haploid),
+                                            v(d_g1), v(d_g2), v(d_gq), v(d_st), v(d_probs), v(d_gt_off)))
 
     def index_blocks(self, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off,
                      allele_off, pool, canon, gt, n_samples, haploid):

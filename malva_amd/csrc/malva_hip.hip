@@ -75,7 +75,9 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8];
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[11];
+    unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch
+    int blocks_grid[3] = {0, 0, 0};            // persistent grid of cover_blocks_kernel<MODE> (found at first use)
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
     float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
@@ -542,6 +544,8 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     for (auto &q : c->s_tk) hipFree(q.p);
     for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
+    for (auto &s : c->s_blk) hipFree(s.p);
+    hipFree(c->d_gen_count);
     hipFree(c->d_hit_count);
     hipFree(c->d_ln);
     hipFree(c->d_eps);
@@ -1746,6 +1750,23 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
     return MG_OK;
 }
 
+MG_EXPORT int mg_genotype_device(mg_ctx *c, const void *d_cov, const void *d_freq, const void *d_var_allele_off, size_t n_vars, float error_rate,
+                                 int max_cov, int haploid, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs, const void *d_var_gt_off)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (n_vars == 0) return MG_OK;
+    if (!d_cov || !d_freq || !d_var_allele_off || !d_gt1 || !d_gt2 || !d_gq || !d_status) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (d_probs && !d_var_gt_off) return fail(c, MG_ERR_ARG, "probs needs var_gt_off");
+    GenoParams p;
+    TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
+    hipLaunchKernelGGL(genotype_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u32 *)d_cov, (const float *)d_freq,
+                       (const u32 *)d_var_allele_off, (u64)n_vars, p, (i32 *)d_gt1, (i32 *)d_gt2, (i32 *)d_gq, (u8 *)d_status, (double *)d_probs,
+                       (const u64 *)d_var_gt_off);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+
 MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, const uint32_t *var_allele_off, size_t n_vars,
                           float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status,
                           double *probs, const uint64_t *var_gt_off)
@@ -1755,8 +1776,6 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
     if (n_vars == 0) return MG_OK;
     if (!cov || !freq || !var_allele_off || !gt1 || !gt2 || !gq || !status) return fail(c, MG_ERR_ARG, "NULL argument");
     if (probs && !var_gt_off) return fail(c, MG_ERR_ARG, "probs needs var_gt_off");
-    GenoParams p;
-    TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
     const size_t na = var_allele_off[n_vars];
     const size_t ng = probs ? var_gt_off[n_vars] : 0;
     void *d_cov, *d_freq, *d_off, *d_g1, *d_g2, *d_gq, *d_st, *d_pr = nullptr, *d_go = nullptr;
@@ -1771,10 +1790,7 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
         TRY(scratch(c, c->s_out, 8 * (ng ? ng : 1), &d_pr));
         TRY(upload(c, c->s_misc[5], var_gt_off, 8 * (n_vars + 1), &d_go));
     }
-    hipLaunchKernelGGL(genotype_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (const u32 *)d_cov, (const float *)d_freq,
-                       (const u32 *)d_off, (u64)n_vars, p, (i32 *)d_g1, (i32 *)d_g2, (i32 *)d_gq, (u8 *)d_st, (double *)d_pr,
-                       (const u64 *)d_go);
-    HIP_TRY(c, hipGetLastError());
+    TRY(mg_genotype_device(c, d_cov, d_freq, d_off, n_vars, error_rate, max_cov, haploid, d_g1, d_g2, d_gq, d_st, d_pr, d_go));
     HIP_TRY(c, hipMemcpyAsync(gt1, d_g1, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(gt2, d_g2, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(gq, d_gq, 4 * n_vars, hipMemcpyDeviceToHost, c->stream));
@@ -1785,11 +1801,192 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
 }
 
 namespace {
-// the flat description of a batch of blocks on the device (shared by the call-time and the index-time enumerator)
-int prepare_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
-                   const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
-                   const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples, int haploid,
-                   BlockBatch *out)
+// ---- blocks on the device ------------------------------------------------------------------------------------------------
+// flags (one byte per record, set at the first record of every block) -> blk_var_off / var_block / the block count:
+// per-tile counts are already in `tile_sums` (cut_flags_kernel / flag_count_kernel wrote them)
+int scan_flags(mg_ctx *c, u64 n, const u8 *d_flags, u32 *d_tile_sums, u32 *d_blk_var_off, u32 *d_var_block, unsigned long long *d_n_blocks)
+{
+    const u64 n_tiles = nblocks(n);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_tile_sums, n_tiles, c->d_hit_count + 2); // (the total is re-derived by the scatter)
+    hipLaunchKernelGGL(flag_scatter_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, n, d_flags, (const u32 *)d_tile_sums, d_blk_var_off, d_var_block,
+                       d_n_blocks);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+int check_panel(mg_ctx *c, const mg_panel_dev *p, bool need_gt)
+{
+    if (!p) return fail(c, MG_ERR_ARG, "NULL panel");
+    if (p->n_vars >= 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "fewer than 2^32 records per batch");
+    if (p->n_vars == 0) return MG_OK;
+    if (!p->contig_id || !p->pos || !p->ref_size || !p->min_size) return fail(c, MG_ERR_ARG, "NULL panel array");
+    if (need_gt && (!p->contig_base || !p->contig_len || !p->present || !p->var_allele_off || !p->allele_off || !p->pool || !p->canon || (p->n_samples && !p->gt)))
+        return fail(c, MG_ERR_ARG, "NULL panel array");
+    return MG_OK;
+}
+PanelView panel_view(const mg_panel_dev *p)
+{
+    PanelView P{};
+    P.contig_base = p->contig_base; P.contig_len = p->contig_len; P.contig_id = p->contig_id; P.pos = p->pos;
+    P.ref_size = p->ref_size; P.min_size = p->min_size; P.present = p->present; P.var_allele_off = p->var_allele_off;
+    P.allele_off = p->allele_off; P.canon = p->canon; P.gt = p->gt; P.n_samples = p->n_samples;
+    return P;
+}
+// everything the enumerating kernels need beyond the panel itself, derived on the device: blocks' sequences and walk
+// bounds, the lone-and-short records' inputs for the fused kernels, the list of the others
+struct BlocksWork {
+    BlockBatch B;
+    const u32 *gen_list;
+    unsigned long long *gen_count;
+    const u64 *iso_pos, *iso_pm;
+    const u8 *iso_flags;
+};
+int blocks_prepare(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, const u32 *d_var_block, const unsigned long long *d_n_blocks, int haploid,
+                   BlocksWork *out)
+{
+    const u64 n = p->n_vars;
+    if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
+    void *q[10];
+    TRY(scratch(c, c->s_blk[0], 8 * n, &q[0]));  // blk_ref_base
+    TRY(scratch(c, c->s_blk[1], 4 * n, &q[1]));  // blk_ref_len
+    TRY(scratch(c, c->s_blk[2], 4 * n, &q[2]));  // blk_max_gain
+    TRY(scratch(c, c->s_blk[3], n, &q[3]));      // blk_unsorted
+    TRY(scratch(c, c->s_blk[4], 8 * n, &q[4]));  // iso_pos
+    TRY(scratch(c, c->s_blk[5], 8 * n, &q[5]));  // iso_pm
+    TRY(scratch(c, c->s_blk[6], n, &q[6]));      // iso_flags
+    TRY(scratch(c, c->s_blk[7], 4 * n, &q[7]));  // gen_list
+    if (!d_var_block) { // derive it from the cut: heads -> scan
+        void *fl, *ts;
+        TRY(scratch(c, c->s_blk[8], 4 * n, &q[8]));
+        TRY(scratch(c, c->s_blk[9], n, &fl));
+        TRY(scratch(c, c->s_blk[10], 4 * (u64)nblocks(n) + 4, &ts));
+        HIP_TRY(c, hipMemsetAsync(fl, 0, n, c->stream));
+        hipLaunchKernelGGL(block_heads_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, d_blk_var_off, d_n_blocks, n, (u8 *)fl);
+        hipLaunchKernelGGL(flag_count_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, n, (const u8 *)fl, (u32 *)ts);
+        TRY(scan_flags(c, n, (const u8 *)fl, (u32 *)ts, nullptr, (u32 *)q[8], nullptr));
+        d_var_block = (const u32 *)q[8];
+    }
+    HIP_TRY(c, hipMemsetAsync(q[2], 0, 4 * n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(q[3], 0, n, c->stream));
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
+    unsigned long long *gen_count = c->d_gen_count;
+    HIP_TRY(c, hipMemsetAsync(gen_count, 0, 8, c->stream));
+    hipLaunchKernelGGL(blocks_meta_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, panel_view(p), n, d_blk_var_off, d_var_block, (int)c->k, haploid, (u64 *)q[0],
+                       (u32 *)q[1], (u32 *)q[2], (u8 *)q[3], (u64 *)q[4], (u64 *)q[5], (u8 *)q[6], (u32 *)q[7], gen_count);
+    HIP_TRY(c, hipGetLastError());
+    BlockBatch B{};
+    B.reference = c->d_ref;
+    B.blk_ref_base = (const u64 *)q[0]; B.blk_ref_len = (const u32 *)q[1]; B.blk_var_off = d_blk_var_off; B.var_block = d_var_block;
+    B.pos = p->pos; B.ref_size = p->ref_size; B.min_size = p->min_size; B.present = p->present; B.var_allele_off = p->var_allele_off;
+    B.allele_off = p->allele_off; B.pool = (const u8 *)p->pool; B.canon = p->canon; B.gt = p->gt;
+    B.blk_unsorted = (const u8 *)q[3]; B.blk_max_gain = (const u32 *)q[2];
+    B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
+    B.set_limit = c->blocks_set_limit;
+    out->B = B;
+    out->gen_list = (const u32 *)q[7];
+    out->gen_count = gen_count;
+    out->iso_pos = (const u64 *)q[4]; out->iso_pm = (const u64 *)q[5]; out->iso_flags = (const u8 *)q[6];
+    return MG_OK;
+}
+// persistent grid of the enumerating kernel: as many workgroups as are resident together
+template <int MODE> unsigned blocks_grid(mg_ctx *c)
+{
+    int &g = c->blocks_grid[MODE];
+    if (!g) {
+        int per_cu = 0, cus = 0, dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cover_blocks_kernel<MODE>, TPB, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        g = cus * per_cu;
+    }
+    return (unsigned)g;
+}
+} // namespace
+
+// block cutting for a batch of kept records in file order (main.cpp:341, 547; var_block.hpp:77-80), on the device
+MG_EXPORT int mg_cut_blocks_device(mg_ctx *c, const mg_panel_dev *p, void *d_blk_var_off_out, void *d_var_block_out, void *d_n_blocks_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    TRY(check_panel(c, p, false));
+    if (!d_n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (p->n_vars == 0) {
+        HIP_TRY(c, hipMemsetAsync(d_n_blocks_out, 0, 8, c->stream));
+        return MG_OK;
+    }
+    if (!d_blk_var_off_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    const u64 n = p->n_vars;
+    void *d_cut, *d_ts;
+    TRY(scratch(c, c->s_blk[9], n, &d_cut));
+    TRY(scratch(c, c->s_blk[10], 4 * (u64)nblocks(n) + 4, &d_ts));
+    hipLaunchKernelGGL(cut_flags_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, n, (const int *)p->pos, (const u32 *)p->ref_size, (const u32 *)p->min_size,
+                       (const u32 *)p->contig_id, (int)c->k, (u8 *)d_cut, (u32 *)d_ts);
+    return scan_flags(c, n, (const u8 *)d_cut, (u32 *)d_ts, (u32 *)d_blk_var_off_out, (u32 *)d_var_block_out, (unsigned long long *)d_n_blocks_out);
+}
+
+MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint32_t *contig_id,
+                            uint32_t *blk_var_off_out, size_t *n_blocks_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    *n_blocks_out = 0;
+    if (n_vars == 0) return MG_OK;
+    if (!pos || !ref_size || !min_size || !contig_id || !blk_var_off_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (n_vars >= 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "mg_cut_blocks takes fewer than 2^32 records per batch");
+    void *d_pos, *d_rs, *d_ms, *d_cid, *d_off;
+    TRY(upload(c, c->s_misc[0], pos, 4 * n_vars, &d_pos));
+    TRY(upload(c, c->s_misc[1], ref_size, 4 * n_vars, &d_rs));
+    TRY(upload(c, c->s_misc[2], min_size, 4 * n_vars, &d_ms));
+    TRY(upload(c, c->s_misc[3], contig_id, 4 * n_vars, &d_cid));
+    TRY(scratch(c, c->s_out, 4 * (n_vars + 1), &d_off));
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
+    mg_panel_dev p{};
+    p.n_vars = n_vars;
+    p.pos = (const int32_t *)d_pos; p.ref_size = (const uint32_t *)d_rs; p.min_size = (const uint32_t *)d_ms; p.contig_id = (const uint32_t *)d_cid;
+    TRY(mg_cut_blocks_device(c, &p, d_off, nullptr, c->d_gen_count + 1));
+    unsigned long long nb = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nb, c->d_gen_count + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(blk_var_off_out, d_off, 4 * (nb + 1), hipMemcpyDeviceToHost));
+    *n_blocks_out = (size_t)nb;
+    return MG_OK;
+}
+
+// VB::extract_kmers + set_coverages (main.cpp:556-557) for every block of a resident panel
+MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const void *d_blk_var_off, const void *d_var_block, const void *d_n_blocks, int haploid,
+                                     void *d_cov_out, void *d_overflow_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    TRY(check_panel(c, p, true));
+    if (p->n_vars == 0) return MG_OK;
+    if (!d_blk_var_off || !d_n_blocks || !d_cov_out || !d_overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
+    if (!c->map.slots) TRY(map_reserve(c, 0));
+    BlocksWork W{};
+    TRY(blocks_prepare(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &W));
+    const u64 n = p->n_vars;
+    HIP_TRY(c, hipMemsetAsync(d_overflow_out, 0, n, c->stream));
+    // lone and short records: the fused kernels (records of the other class have their flag clear and get zeros, which
+    // the enumerating kernel then overwrites)
+    u32 *need_slow = (u32 *)(c->d_hit_count + 3);
+    if (++c->iso_call_no == 0) c->iso_call_no = 1;
+    hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
+                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no);
+    hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
+                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no);
+    hipLaunchKernelGGL(cover_blocks_kernel<0>, dim3(blocks_grid<0>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
+                       (u32 *)d_cov_out, (u8 *)d_overflow_out, IndexEmit{nullptr, nullptr, 0u});
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+
+namespace {
+// the host forms' panel: every block its own "sequence" (blk_ref_base / blk_ref_len as the caller gives them)
+int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                  const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                  const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples,
+                  mg_panel_dev *out, void **d_blk_var_off, void **d_var_block, void **d_n_blocks)
 {
     if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off || !pool || !canon ||
         (n_samples && !gt))
@@ -1803,7 +2000,6 @@ int prepare_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, con
         if (blk_ref_base[b] + blk_ref_len[b] > c->ref_len) return fail(c, MG_ERR_ARG, "block %zu lies outside the uploaded reference", b);
         for (u32 v = blk_var_off[b]; v < blk_var_off[b + 1]; ++v) var_block[v] = (u32)b;
     }
-    BlockBatch B{};
     void *d[14];
     TRY(upload(c, c->s_misc[0], blk_ref_base, 8 * n_blocks, &d[0]));
     TRY(upload(c, c->s_misc[1], blk_ref_len, 4 * n_blocks, &d[1]));
@@ -1818,26 +2014,21 @@ int prepare_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, con
     TRY(upload(c, c->s_open[0], pool, pool_len, &d[10]));
     TRY(upload(c, c->s_open[1], canon, na, &d[11]));
     TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
-    // per block: sorted positions? largest ref_size - min_size (they bound the chain walks, bk_chains)
-    std::vector<u8> blk_sorted(n_blocks, 1);
-    std::vector<u32> blk_max_gain(n_blocks, 0);
-    for (size_t b = 0; b < n_blocks; ++b)
-        for (u32 v = blk_var_off[b]; v < blk_var_off[b + 1]; ++v) {
-            if (v > blk_var_off[b] && pos[v] < pos[v - 1]) blk_sorted[b] = 0;
-            if (ref_size[v] >= min_size[v]) blk_max_gain[b] = std::max(blk_max_gain[b], ref_size[v] - min_size[v]);
-        }
-    void *d_sorted, *d_gain;
-    TRY(upload(c, c->s_bin[0], blk_sorted.data(), n_blocks, &d_sorted));
-    TRY(upload(c, c->s_bin[1], blk_max_gain.data(), 4 * n_blocks, &d_gain));
-    B.reference = c->d_ref;
-    B.blk_ref_base = (const u64 *)d[0]; B.blk_ref_len = (const u32 *)d[1]; B.blk_var_off = (const u32 *)d[2];
-    B.var_block = (const u32 *)d[3]; B.pos = (const i32 *)d[4]; B.ref_size = (const u32 *)d[5]; B.min_size = (const u32 *)d[6];
-    B.present = (const u8 *)d[7]; B.var_allele_off = (const u32 *)d[8]; B.allele_off = (const u32 *)d[9]; B.pool = (const u8 *)d[10];
-    B.canon = (const u8 *)d[11]; B.gt = (const uint16_t *)d[12];
-    B.blk_sorted = (const u8 *)d_sorted; B.blk_max_gain = (const u32 *)d_gain;
-    B.n_samples = n_samples; B.haploid = haploid; B.k = (int)c->k;
-    B.set_limit = c->blocks_set_limit;
-    *out = B;
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
+    const unsigned long long nb = n_blocks;
+    HIP_TRY(c, hipMemcpyAsync(c->d_gen_count + 1, &nb, 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // (`nb` and `var_block` live on this frame)
+    mg_panel_dev p{};
+    p.n_vars = n_vars;
+    p.n_contigs = (uint32_t)n_blocks;
+    p.contig_base = (const uint64_t *)d[0]; p.contig_len = (const uint32_t *)d[1]; p.contig_id = (const uint32_t *)d[3];
+    p.pos = (const int32_t *)d[4]; p.ref_size = (const uint32_t *)d[5]; p.min_size = (const uint32_t *)d[6]; p.present = (const uint8_t *)d[7];
+    p.var_allele_off = (const uint32_t *)d[8]; p.allele_off = (const uint32_t *)d[9]; p.pool = (const char *)d[10]; p.canon = (const uint8_t *)d[11];
+    p.gt = (const uint16_t *)d[12]; p.n_samples = n_samples;
+    *out = p;
+    *d_blk_var_off = d[2];
+    *d_var_block = d[3];
+    *d_n_blocks = c->d_gen_count + 1;
     return MG_OK;
 }
 } // namespace
@@ -1853,55 +2044,66 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     if (n_vars == 0) return MG_OK;
     if (!cov_out || !overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
-    if (!c->map.slots) TRY(map_reserve(c, 0));
-    BlockBatch B{};
-    TRY(prepare_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool,
-                       pool_len, canon, gt, n_samples, haploid, &B));
+    mg_panel_dev p{};
+    void *d_bo, *d_vb, *d_nb;
+    TRY(upload_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb));
     const size_t na = var_allele_off[n_vars];
     void *d_cov, *d_ovf;
     TRY(scratch(c, c->s_out, 4 * na, &d_cov));
     TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
-    hipLaunchKernelGGL(cover_blocks_kernel<0>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c),
-                       (u32 *)d_cov, (u8 *)d_ovf, IndexEmit{nullptr, nullptr, 0u});
-    HIP_TRY(c, hipGetLastError());
+    TRY(mg_cover_blocks_device(c, &p, d_bo, d_vb, d_nb, haploid, d_cov, d_ovf));
     HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov, 4 * na, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }
 
-// block cutting for a batch of kept records in file order (main.cpp:341, 547; var_block.hpp:77-80), on the device
-MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint32_t *contig_id,
-                            uint32_t *blk_var_off_out, size_t *n_blocks_out)
+// index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for every block of a resident panel.  Synchronises
+// twice on eight bytes: the exact map is sized from the counting pass before the insert pass runs.
+MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const void *d_blk_var_off, const void *d_var_block, const void *d_n_blocks, int haploid,
+                                     void *d_overflow_out)
 {
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
-    if (!n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
-    *n_blocks_out = 0;
-    if (n_vars == 0) return MG_OK;
-    if (!pos || !ref_size || !min_size || !contig_id || !blk_var_off_out) return fail(c, MG_ERR_ARG, "NULL argument");
-    if (n_vars >= 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "mg_cut_blocks takes fewer than 2^32 records per batch");
-    void *d_pos, *d_rs, *d_ms, *d_cid, *d_cut, *d_off;
-    TRY(upload(c, c->s_misc[0], pos, 4 * n_vars, &d_pos));
-    TRY(upload(c, c->s_misc[1], ref_size, 4 * n_vars, &d_rs));
-    TRY(upload(c, c->s_misc[2], min_size, 4 * n_vars, &d_ms));
-    TRY(upload(c, c->s_misc[3], contig_id, 4 * n_vars, &d_cid));
-    TRY(scratch(c, c->s_irr, n_vars, &d_cut));
-    TRY(scratch(c, c->s_out, 4 * (n_vars + 1), &d_off));
-    unsigned long long *d_nb = c->d_hit_count + 3; // a free word outside any scan
-    hipLaunchKernelGGL(cut_flags_kernel, dim3(nblocks(n_vars)), dim3(TPB), 0, c->stream, (u64)n_vars, (const int *)d_pos, (const u32 *)d_rs, (const u32 *)d_ms,
-                       (const u32 *)d_cid, (int)c->k, (u8 *)d_cut);
-    hipLaunchKernelGGL(cut_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, (u64)n_vars, (const u8 *)d_cut, (u32 *)d_off, d_nb);
+    TRY(check_panel(c, p, true));
+    if (p->n_vars == 0) return MG_OK;
+    if (!d_blk_var_off || !d_n_blocks || !d_overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_index_blocks after mg_bf_finalize");
+    const u64 n = p->n_vars;
+    if (c->map.rows_total + n >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "exact map: more than 2^32-1 insertion rows");
+    TRY(map_reserve(c, n)); // the lone records' REF keys take insertion rows rows_total + v; may grow and re-hash the table: before the kernels, never under one
+    BlocksWork W{};
+    TRY(blocks_prepare(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &W));
+    c->gate_dirty = true;
+    // lone and short records (flag set by blocks_meta_kernel; the others' flag is clear: iso_index_kernel leaves them alone)
+    hipLaunchKernelGGL(iso_index_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
+                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out);
     HIP_TRY(c, hipGetLastError());
-    unsigned long long nb = 0;
-    HIP_TRY(c, hipMemcpyAsync(&nb, d_nb, 8, hipMemcpyDeviceToHost, c->stream));
+    c->map.rows_total += n;
+    unsigned long long *d_cursor = c->d_gen_count + 1;
+    // pass 1: how many exact-map insertion rows the other records need, and which of them exceed a device capacity
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
+    hipLaunchKernelGGL(cover_blocks_kernel<1>, dim3(blocks_grid<1>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
+                       (u32 *)nullptr, (u8 *)d_overflow_out, IndexEmit{nullptr, d_cursor, 0u});
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long rows = 0;
+    HIP_TRY(c, hipMemcpyAsync(&rows, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(blk_var_off_out, d_off, 4 * (nb + 1), hipMemcpyDeviceToHost));
-    *n_blocks_out = (size_t)nb;
+    if (rows) {
+        TRY(map_reserve(c, rows)); // between the passes
+        // pass 2: insert.  Every REF k-mer takes the next insertion row of the batch (ids are then whatever order the
+        // device reached them in: the index FILE, which every GPU of a call loads alike, is what fixes the counter layout)
+        HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
+    }
+    hipLaunchKernelGGL(cover_blocks_kernel<2>, dim3(blocks_grid<2>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
+                       (u32 *)nullptr, (u8 *)d_overflow_out, IndexEmit{nullptr, d_cursor, (u32)c->map.rows_total});
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->map.rows_total += rows;
     return MG_OK;
 }
 
-// index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for a batch of blocks, on the device
 MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
                               const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
                               const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
@@ -1913,32 +2115,15 @@ MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     if (n_vars == 0) return MG_OK;
     if (!overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
     if (c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_index_blocks after mg_bf_finalize");
-    if (!c->map.slots) TRY(map_reserve(c, 0));
-    BlockBatch B{};
-    TRY(prepare_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool,
-                       pool_len, canon, gt, n_samples, haploid, &B));
+    mg_panel_dev p{};
+    void *d_bo, *d_vb, *d_nb;
+    TRY(upload_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb));
     void *d_ovf;
     TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
-    unsigned long long *d_cursor = c->d_hit_count; // a free word outside any scan
-    // pass 1: how many exact-map insertion rows the batch needs, and which variants exceed a device capacity
-    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
-    hipLaunchKernelGGL(cover_blocks_kernel<1>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c), (u32 *)nullptr,
-                       (u8 *)d_ovf, IndexEmit{nullptr, d_cursor, 0u});
-    HIP_TRY(c, hipGetLastError());
-    unsigned long long rows = 0;
-    HIP_TRY(c, hipMemcpyAsync(&rows, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    TRY(map_reserve(c, rows)); // may grow and re-hash the table: between the passes, never under a kernel
-    // pass 2: insert.  Every REF k-mer takes the next insertion row of the batch (ids are then whatever order the
-    // device reached them in: the index FILE, which every GPU of a call loads alike, is what fixes the counter layout)
-    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
-    c->gate_dirty = true;
-    hipLaunchKernelGGL(cover_blocks_kernel<2>, dim3((unsigned)n_vars), dim3(TPB), 0, c->stream, B, (u64)n_vars, view(c, MG_BF_ALT), view(c), (u32 *)nullptr,
-                       (u8 *)d_ovf, IndexEmit{nullptr, d_cursor, (u32)c->map.rows_total});
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->map.rows_total += rows;
+    HIP_TRY(c, hipMemsetAsync(d_ovf, 0, n_vars, c->stream));
+    TRY(mg_index_blocks_device(c, &p, d_bo, d_vb, d_nb, haploid, d_ovf));
+    HIP_TRY(c, hipMemcpy(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost));
     return MG_OK;
 }
 

@@ -319,7 +319,7 @@ struct BlockBatch {
     const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
     const u32 *blk_ref_len;   //            and its length
     const u32 *blk_var_off;   // [n_blocks + 1]
-    const u8 *blk_sorted;     // per block: positions never decrease along the block (any sane VCF)
+    const u8 *blk_unsorted;   // per block: some position decreases along the block (no sane VCF: the walks then run to the block's end)
     const u32 *blk_max_gain;  //            max over its variants of ref_size - min_size
     const u32 *var_block;     // [n_vars] block of each variant
     const i32 *pos;           // 0-based position in the contig
@@ -362,41 +362,140 @@ __device__ __forceinline__ bool near_f32(int lhs_sum, int k, int rhs_pos) { retu
 //   cut[i] = contig[i] != contig[i-1]  ||  !are_near(record i-1, record i)          (cut[0] = 1)
 // and the blocks are the runs between cuts.  One thread per record.
 __global__ void __launch_bounds__(TPB) cut_flags_kernel(u64 n, const int *__restrict__ pos, const u32 *__restrict__ ref_size, const u32 *__restrict__ min_size,
-                                                        const u32 *__restrict__ contig, int k, u8 *__restrict__ cut)
+                                                        const u32 *__restrict__ contig, int k, u8 *__restrict__ cut, u32 *__restrict__ tile_sums)
 {
-    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    cut[i] = i == 0 || contig[i] != contig[i - 1] || !near_f32(pos[i - 1] + (int)ref_size[i - 1] - (int)min_size[i - 1] - 1, k, pos[i]);
-}
-// blk_var_off[b] = index of the first record of block b, blk_var_off[n_blocks] = n; one workgroup walks the flags in tiles
-// (a batch is a few hundred thousand records at most: the walk is a few microseconds per 10^5)
-__global__ void __launch_bounds__(1024) cut_offsets_kernel(u64 n, const u8 *__restrict__ cut, u32 *__restrict__ blk_var_off, unsigned long long *n_blocks_out)
-{
-    __shared__ u32 sh_wave[16];
-    __shared__ u32 sh_run;
-    if (threadIdx.x == 0) sh_run = 0;
+    __shared__ u32 sh_n;
+    if (threadIdx.x == 0) sh_n = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (u64 base = 0; base < n; base += 1024) {
-        const u64 i = base + threadIdx.x;
-        const bool f = i < n && cut[i];
-        const u64 mask = __ballot(f);
-        if (lane == 0) sh_wave[wave] = (u32)__popcll(mask);
-        __syncthreads();
-        u32 before = sh_run;
-        for (int w = 0; w < wave; ++w) before += sh_wave[w];
-        if (f) blk_var_off[before + __popcll(mask & ((1ULL << lane) - 1))] = (u32)i;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 t = 0;
-            for (int w = 0; w < 16; ++w) t += sh_wave[w];
-            sh_run += t;
-        }
-        __syncthreads();
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    bool f = false;
+    if (i < n) {
+        f = i == 0 || contig[i] != contig[i - 1] || !near_f32(pos[i - 1] + (int)ref_size[i - 1] - (int)min_size[i - 1] - 1, k, pos[i]);
+        cut[i] = f;
     }
-    if (threadIdx.x == 0) {
-        blk_var_off[sh_run] = (u32)n;
-        *n_blocks_out = sh_run;
+    const u64 mask = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&sh_n, (u32)__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh_n;
+}
+// flags -> per-tile counts (for flags that did not come from cut_flags_kernel)
+__global__ void __launch_bounds__(TPB) flag_count_kernel(u64 n, const u8 *__restrict__ flags, u32 *__restrict__ tile_sums)
+{
+    __shared__ u32 sh_n;
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 mask = __ballot(i < n && flags[i]);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&sh_n, (u32)__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = sh_n;
+}
+// heads of the blocks of an existing cut: flags[blk_var_off[b]] = 1
+__global__ void __launch_bounds__(TPB) block_heads_kernel(const u32 *__restrict__ blk_var_off, const unsigned long long *__restrict__ n_blocks, u64 n, u8 *__restrict__ flags)
+{
+    const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (b < *n_blocks && blk_var_off[b] < n) flags[blk_var_off[b]] = 1;
+}
+// With the tiles' counts scanned (tile_scan_kernel): blk_var_off[b] = first record of block b, blk_var_off[n_blocks] = n,
+// var_block[i] = block of record i.  Any of the three outputs may be NULL.
+__global__ void __launch_bounds__(TPB) flag_scatter_kernel(u64 n, const u8 *__restrict__ flags, const u32 *__restrict__ tile_base, u32 *__restrict__ blk_var_off,
+                                                           u32 *__restrict__ var_block, unsigned long long *n_blocks_out)
+{
+    __shared__ u32 sh_wave[TPB / 64];
+    const u64 i = (u64)blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool f = i < n && flags[i];
+    const u64 mask = __ballot(f);
+    if (lane == 0) sh_wave[wave] = (u32)__popcll(mask);
+    __syncthreads();
+    u32 before = tile_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) before += sh_wave[w];
+    const u32 incl = before + (u32)__popcll(mask & ((2ULL << lane) - 1)); // flags in [tile start, i]
+    if (i < n) {
+        if (f && blk_var_off) blk_var_off[incl - 1] = (u32)i;
+        if (var_block) var_block[i] = incl - 1;
+        if (i == n - 1) {
+            if (blk_var_off) blk_var_off[incl] = (u32)n;
+            if (n_blocks_out) *n_blocks_out = incl;
+        }
+    }
+}
+
+// ---- a batch of blocks described on the device -----------------------------------------------------------------------
+// What prepare_blocks used to compute on the host, per record v of a batch whose blocks are already cut (blk_var_off,
+// var_block): the block's sequence (that of its first record: `last_seq_name` at the flush, main.cpp:556), the two
+// bounds of the chain walks, and the record's class:
+//   lone and short  a block of ONE variant whose alleles are all shorter than k, at most 64 of them, flanks inside the
+//                   sequence: the fused lone-variant kernels (iso_cover_kernel / iso_index_kernel) take it -- its offset
+//                   in the uploaded reference, the mask of the alleles some panel haplotype carries (build_alleles_combs
+//                   on a chain of one, var_block.hpp:734-786) and the eligibility flag (var_block.hpp:104) are written here;
+//   anything else   appended to `gen_list` for cover_blocks_kernel.
+// blk_max_gain and blk_unsorted must be zeroed before the launch.
+struct PanelView {
+    const u64 *contig_base;
+    const u32 *contig_len, *contig_id;
+    const i32 *pos;
+    const u32 *ref_size, *min_size;
+    const u8 *present;
+    const u32 *var_allele_off, *allele_off;
+    const u8 *canon;
+    const uint16_t *gt;
+    u32 n_samples;
+};
+__global__ void __launch_bounds__(TPB) blocks_meta_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block, int k, int haploid,
+                                                          u64 *__restrict__ blk_ref_base, u32 *__restrict__ blk_ref_len, u32 *blk_max_gain, u8 *blk_unsorted,
+                                                          u64 *__restrict__ iso_pos, u64 *__restrict__ iso_pm, u8 *__restrict__ iso_flags, u32 *__restrict__ gen_list,
+                                                          unsigned long long *gen_count)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    bool general = false;
+    if (v < n_vars) {
+        const u32 blk = var_block[v];
+        const u32 b0 = blk_var_off[blk], b1 = blk_var_off[blk + 1];
+        const u32 cid = P.contig_id[b0];
+        const u64 cbase = P.contig_base[cid];
+        const u32 clen = P.contig_len[cid];
+        if (v == b0) {
+            blk_ref_base[blk] = cbase;
+            blk_ref_len[blk] = clen;
+        }
+        const u32 rs = P.ref_size[v], ms = P.min_size[v];
+        const i32 p = P.pos[v];
+        if (b1 - b0 > 1) {
+            if (rs > ms) atomicMax(&blk_max_gain[blk], rs - ms);
+            if (v > b0 && p < P.pos[v - 1]) blk_unsorted[blk] = 1;
+        }
+        const u32 a0 = P.var_allele_off[v], A = P.var_allele_off[v + 1] - a0;
+        bool lone = b1 - b0 == 1 && A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
+        if (lone)
+            for (u32 a = 0; a < A; ++a) lone = lone && (int)(P.allele_off[a0 + a + 1] - P.allele_off[a0 + a]) < k;
+        if (lone) {
+            const bool eligible = P.present[v] && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
+            u64 mask = 0;
+            if (eligible)
+                for (u32 s = 0; s < P.n_samples; ++s) {
+                    const u32 g = P.gt[v * P.n_samples + s];
+                    mask |= 1ULL << P.canon[a0 + (g & 127)];
+                    if (!haploid) mask |= 1ULL << P.canon[a0 + ((g >> 7) & 127)];
+                }
+            iso_pos[v] = cbase + (u64)p;
+            iso_pm[v] = mask;
+            iso_flags[v] = eligible ? 1 : 0;
+        } else {
+            iso_pos[v] = cbase; // (never read: the flag is clear)
+            iso_pm[v] = 0;
+            iso_flags[v] = 0;
+            general = true;
+        }
+    }
+    // the general records' list: order is irrelevant (one workgroup per record, independent), one atomic per wave
+    const u64 m = __ballot(general);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(gen_count, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (general) gen_list[base + __popcll(m & ((1ULL << lane) - 1))] = (u32)v;
     }
 }
 
@@ -416,7 +515,7 @@ __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, 
     // The reference walks to the end of the block whatever happens (var_block.hpp:436-525: O(B) per variant, O(B^2) per
     // block).  Nothing can join a chain once the walk is beyond the reach of every chain -- positions only move away and
     // a chain's reach grows only when something joins -- so with sorted positions the walk stops there: same chains.
-    const bool sorted = B.blk_sorted[B.var_block[i]];
+    const bool sorted = !B.blk_unsorted[B.var_block[i]];
     const int max_gain = (int)B.blk_max_gain[B.var_block[i]];
     for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
         if (sorted) {
@@ -558,8 +657,12 @@ template <int MODE> __device__ __forceinline__ bool bk_index_emit(const u8 *buf,
 
 // MODE 0: call time, coverage of every allele (set_coverages).  MODE 1 / 2: index time, see bk_index_emit; `overflow` then
 // carries MODE 1's verdict into MODE 2 (a variant flagged there is skipped here and left to the host).
+// The grid is persistent: workgroup w takes the records list[w], list[w + gridDim.x], ... of `list` (*list_n entries:
+// the records blocks_meta_kernel did not hand to the lone-variant kernels), so that neither the list's length nor the
+// launch of millions of workgroups needs the host.
 template <int MODE>
-__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_vars, BFView bf, MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit)
+__global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u32 *__restrict__ list, const unsigned long long *__restrict__ list_n, BFView bf,
+                                                           MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit)
 {
     __shared__ BkChains sh_left, sh_right;
     __shared__ int sh_bad, sh_eligible;
@@ -569,10 +672,12 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     __shared__ unsigned long long sh_set[BK_SET_CAP]; // distinct picks of the chain in hand: code + 1, 0 = free
     __shared__ u32 sh_set_n;
     __shared__ u32 sh_emit;
-    const int g = blockIdx.x;
-    if ((u64)g >= n_vars) return;
-    if (MODE == 2 && overflow[g]) return; // flagged by the counting pass: the host enumerates this variant's block
     emit.sh_emit = &sh_emit;
+    const u64 n_list = *list_n;
+    for (u64 item = blockIdx.x; item < n_list; item += gridDim.x) {
+    __syncthreads(); // the previous record's shared state is done with
+    const int g = (int)list[item];
+    if (MODE == 2 && overflow[g]) continue; // flagged by the counting pass: the host enumerates this variant's block
     if (threadIdx.x == 0) sh_emit = 0;
     const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
     const u32 blk = B.var_block[g];
@@ -596,7 +701,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
         if (threadIdx.x == 0) overflow[g] = 1;
         if (MODE == 0)
             for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = 0;
-        return;
+        continue;
     }
     u8 *buf = sh_buf[threadIdx.x];
     bool bad = false;
@@ -775,5 +880,6 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, u64 n_v
     if (MODE == 1 && threadIdx.x == 0 && !sh_bad && sh_emit) atomicAdd(emit.cursor, (unsigned long long)sh_emit); // rows the insert pass will need
     if (MODE == 0)
         for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
+    } // next record of the list
 }
 

@@ -334,3 +334,357 @@ def device_table(panel: Panel, n_rows, k, ref_k, seed, device, plant_variants=No
            "site_cnt": d_cnt[where].cpu().numpy().astype(np.int64), "site_var": var, "site_hap": hap, "site_off": off}
     torch.cuda.synchronize()
     return out
+
+
+# ---- flat panels with CLUSTERS (the general-block path): BASELINE config C4 as SURVEY 8(d) draws it, and config C5 -----------
+
+@dataclass
+class FlatPanel:
+    """The kept records of a panel in file order as the flat arrays of include/malva_hip.h's mg_panel_dev (+ frequencies
+    and a donor).  Sequences are concatenated in `genome`; record v sits on sequence contig_id[v] at 0-based `pos[v]`."""
+    genome: np.ndarray            # uint8 ASCII, all sequences concatenated
+    contig_names: list
+    contig_base: np.ndarray       # uint64 [n_contigs]
+    contig_len: np.ndarray        # uint32 [n_contigs]
+    contig_id: np.ndarray         # uint32 [n]
+    pos: np.ndarray               # int32 [n]
+    ref_size: np.ndarray          # uint32 [n]
+    min_size: np.ndarray          # uint32 [n]  (Variant::min_size over REF and ALTs)
+    present: np.ndarray           # uint8 [n]   (Variant::is_present)
+    var_allele_off: np.ndarray    # uint32 [n + 1]
+    allele_off: np.ndarray        # uint32 [slots + 1]
+    pool: np.ndarray              # uint8 allele bytes
+    canon: np.ndarray             # uint8 [slots] first allele of the variant with the same text
+    freq: np.ndarray              # float32 [slots]
+    gt: np.ndarray                # uint16 [n, n_samples]: a1 | a2 << 7 | phased << 14
+    n_samples: int
+    donor_gt: np.ndarray          # int8 [n, 2]
+
+    @property
+    def n(self):
+        return len(self.pos)
+
+    def gpos(self):
+        """offset of every record in the concatenated genome"""
+        return self.contig_base[self.contig_id].astype(np.int64) + self.pos.astype(np.int64)
+
+    def allele(self, v, a):
+        s = int(self.var_allele_off[v]) + a
+        return bytes(self.pool[self.allele_off[s]:self.allele_off[s + 1]])
+
+    def head(self, n):
+        """the first n records as a panel of their own (same genome)"""
+        na = int(self.var_allele_off[n])
+        return FlatPanel(genome=self.genome, contig_names=self.contig_names, contig_base=self.contig_base, contig_len=self.contig_len,
+                         contig_id=self.contig_id[:n], pos=self.pos[:n], ref_size=self.ref_size[:n], min_size=self.min_size[:n], present=self.present[:n],
+                         var_allele_off=self.var_allele_off[:n + 1], allele_off=self.allele_off[:na + 1], pool=self.pool[:int(self.allele_off[na])],
+                         canon=self.canon[:na], freq=self.freq[:na], gt=self.gt[:n], n_samples=self.n_samples, donor_gt=self.donor_gt[:n])
+
+
+def _canon_of(var_allele_off, allele_off, pool):
+    """first allele of the variant with the same text, per slot (Variant::get_allele_index, variant.hpp:228-240); numpy, vectorised
+    over the common case (all alleles of a variant differ in their first 8 bytes or length) with a loop for the rest"""
+    na = int(var_allele_off[-1])
+    canon = np.zeros(na, dtype=np.uint8)
+    A = np.diff(var_allele_off.astype(np.int64))
+    local = np.arange(na, dtype=np.int64) - np.repeat(var_allele_off[:-1].astype(np.int64), A)
+    canon[:] = local
+    alen = np.diff(allele_off.astype(np.int64))
+    multi = np.nonzero(A > 2)[0]
+    for v in multi:                      # duplicates can only occur among ALTs (or an ALT spelled like REF): rare, checked by text
+        a0 = int(var_allele_off[v])
+        seen = {}
+        for a in range(int(A[v])):
+            t = bytes(pool[allele_off[a0 + a]:allele_off[a0 + a + 1]])
+            canon[a0 + a] = seen.setdefault(t, a)
+    two = np.nonzero(A == 2)[0]
+    if two.size:                         # biallelic: ALT == REF text?
+        s0 = var_allele_off[two].astype(np.int64)
+        same_len = alen[s0] == alen[s0 + 1]
+        for v in two[same_len]:
+            a0 = int(var_allele_off[v])
+            if bytes(pool[allele_off[a0]:allele_off[a0 + 1]]) == bytes(pool[allele_off[a0 + 1]:allele_off[a0 + 2]]):
+                canon[a0 + 1] = 0
+    return canon
+
+
+def clustered_snp_panel(n_vars, seed, n_contigs=24, mean_spacing=38, cluster_frac=0.10, max_cluster=4, cluster_span=17, n_samples=2, k=35):
+    """BASELINE config C4's panel as SURVEY 8(d) draws it: biallelic SNPs at ~`mean_spacing` nt mean spacing, `cluster_frac` of
+    them in clusters of 2..max_cluster within `cluster_span` nt, on `n_contigs` sequences (a 3.1e9-nt genome at 8e7 SNPs: 24
+    sequences keep positions inside int32, as a VCF's do).  Gaps between units are drawn from [k/2 + 3, 2 mean - k/2 - 3], so
+    the units are apart by more than are_near's reach at low positions; beyond 2^24 the reference's float rule (var_block.hpp
+    :417-423) joins a few more neighbours, which is the reference's semantics, not the generator's.  n_samples diploid phased
+    samples, GT bits random, forced so that every ALT is carried at least once (else is_present filtering drops it)."""
+    rng = np.random.default_rng(seed)
+    n_clustered = int(round(n_vars * cluster_frac))
+    sizes = []
+    left = n_clustered
+    csz = rng.integers(2, max_cluster + 1, size=max(1, n_clustered // 2 + 1))
+    cs = np.cumsum(csz)
+    n_cl = int(np.searchsorted(cs, left, side="right"))
+    csz = csz[:n_cl]
+    left -= int(csz.sum())
+    n_single = n_vars - int(csz.sum())
+    unit = np.concatenate([np.ones(n_single, dtype=np.int64), csz.astype(np.int64)])
+    rng.shuffle(unit)
+    U = unit.size
+    # offsets inside clusters: distinct values of 1..cluster_span, sorted (first member at 0)
+    is_cl = unit > 1
+    ncl = int(is_cl.sum())
+    offs = np.zeros((ncl, max_cluster), dtype=np.int64)
+    if ncl:
+        perm = rng.permuted(np.tile(np.arange(1, cluster_span + 1, dtype=np.int8), (ncl, 1)), axis=1)[:, :max_cluster - 1].astype(np.int64)
+        take = unit[is_cl][:, None] - 1 > np.arange(max_cluster - 1)[None, :]
+        perm = np.where(take, perm, 1 << 20)
+        perm.sort(axis=1)
+        offs[:, 1:] = perm
+    half = (k + 1) // 2
+    lo_gap, hi_gap = half + 3, max(half + 4, 2 * mean_spacing - half - 3)
+    gap = rng.integers(lo_gap, hi_gap + 1, size=U).astype(np.int64)         # from the END of the previous unit to this unit's first record
+    span = np.zeros(U, dtype=np.int64)
+    if ncl:
+        last = np.take_along_axis(offs, (unit[is_cl] - 1)[:, None], axis=1)[:, 0]
+        span[is_cl] = last
+    # deal the units over the sequences in order: unit u -> sequence u * n_contigs // U
+    cid_u = (np.arange(U, dtype=np.int64) * n_contigs) // U
+    first = 1000
+    step = gap + np.concatenate([[0], span[:-1]])
+    run = np.cumsum(step)
+    firsts = np.searchsorted(cid_u, np.arange(n_contigs))
+    base_run = run[firsts] - gap[firsts]                                        # what the run held before each sequence's first unit
+    start = first + run - np.repeat(base_run, np.diff(np.append(firsts, U)))
+    # records
+    rec_unit = np.repeat(np.arange(U), unit)
+    within = np.arange(n_vars, dtype=np.int64) - np.repeat(np.cumsum(unit) - unit, unit)
+    pos = start[rec_unit].copy()
+    if ncl:
+        cl_index = np.cumsum(is_cl) - 1
+        m = is_cl[rec_unit]
+        pos[m] += offs[cl_index[rec_unit[m]], within[m]]
+    contig_id = cid_u[rec_unit].astype(np.uint32)
+    ends = np.zeros(n_contigs, dtype=np.int64)
+    np.maximum.at(ends, contig_id, pos)
+    contig_len = (ends + 1000).astype(np.uint32)
+    contig_base = np.zeros(n_contigs, dtype=np.uint64)
+    contig_base[1:] = np.cumsum(contig_len.astype(np.uint64))[:-1]
+    genome = random_genome(int(contig_len.astype(np.int64).sum()), seed + 1)
+    gpos = contig_base[contig_id].astype(np.int64) + pos
+    ref_code = CODE[genome[gpos]]
+    alt_code = (ref_code + 1 + rng.integers(0, 3, size=n_vars, dtype=np.uint8)) % 4
+    pool = np.empty(2 * n_vars, dtype=np.uint8)
+    pool[0::2] = genome[gpos]
+    pool[1::2] = BASES[alt_code]
+    af = ((1 + rng.integers(0, 4999, size=n_vars)) / 10000.0).astype(np.float32)
+    freq = np.empty(2 * n_vars, dtype=np.float32)
+    freq[1::2] = af
+    freq[0::2] = (1.0 - af.astype(np.float64)).astype(np.float32)
+    bits = rng.integers(0, 2, size=(n_vars, n_samples, 2), dtype=np.uint8)
+    none = ~bits.reshape(n_vars, -1).any(axis=1)
+    bits[none, 0, 0] = 1
+    gt = (bits[:, :, 0].astype(np.uint16) | (bits[:, :, 1].astype(np.uint16) << 7) | np.uint16(1 << 14))
+    donor = rng.integers(0, 2, size=(n_vars, 2), dtype=np.int8)
+    ones = np.ones(n_vars, dtype=np.uint32)
+    return FlatPanel(genome=genome, contig_names=[str(i + 1) for i in range(n_contigs)], contig_base=contig_base, contig_len=contig_len,
+                     contig_id=contig_id, pos=pos.astype(np.int32), ref_size=ones, min_size=ones.copy(), present=np.ones(n_vars, dtype=np.uint8),
+                     var_allele_off=(2 * np.arange(n_vars + 1)).astype(np.uint32), allele_off=np.arange(2 * n_vars + 1, dtype=np.uint32), pool=pool,
+                     canon=np.tile(np.array([0, 1], dtype=np.uint8), n_vars), freq=freq, gt=gt, n_samples=n_samples, donor_gt=donor)
+
+
+def indel_panel(n_clusters, seed, k=35, n_samples=8, n_contigs=2, unphased_frac=0.5, max_cluster=6, cluster_gap=400):
+    """BASELINE config C5's panel: clusters of 1..max_cluster records mixing SNPs, MNPs, 1-30 nt deletions and
+    1-60 nt insertions (some of k bases and more: the sliding-signature path), up to 3 ALTs, a few records overlapping the
+    deletion before them, `n_samples` samples of which `unphased_frac` of the genotypes are unphased; clusters `cluster_gap`
+    nt apart on average.  Runs haploid (first allele of every genotype) and diploid from the same arrays."""
+    rng = np.random.default_rng(seed)
+    csz = rng.integers(1, max_cluster + 1, size=n_clusters).astype(np.int64)
+    n = int(csz.sum())
+    rec_cl = np.repeat(np.arange(n_clusters), csz)
+    within = np.arange(n, dtype=np.int64) - np.repeat(np.cumsum(csz) - csz, csz)
+    kind = rng.random(n)
+    # REF length: SNP / insertion anchor 1; MNP 2..6; deletion 2..31
+    is_mnp = (kind >= 0.40) & (kind < 0.55)
+    is_del = (kind >= 0.55) & (kind < 0.75)
+    is_ins = kind >= 0.75
+    ref_len = np.ones(n, dtype=np.int64)
+    ref_len[is_mnp] = rng.integers(2, 7, size=int(is_mnp.sum()))
+    ref_len[is_del] = rng.integers(2, 32, size=int(is_del.sum()))
+    n_alt = np.where(rng.random(n) < 0.85, 1, rng.integers(2, 4, size=n)).astype(np.int64)
+    A = n_alt + 1
+    vo = np.zeros(n + 1, dtype=np.int64)
+    vo[1:] = np.cumsum(A)
+    na = int(vo[-1])
+    slot_var = np.repeat(np.arange(n), A)
+    slot_a = np.arange(na, dtype=np.int64) - vo[slot_var]
+    alen = np.ones(na, dtype=np.int64)
+    ref_slot = slot_a == 0
+    alen[ref_slot] = ref_len
+    v_of = slot_var
+    alt = ~ref_slot
+    r = rng.random(na)
+    mnp_alt = alt & is_mnp[v_of]
+    alen[mnp_alt] = ref_len[v_of[mnp_alt]]                                        # MNP: same length
+    del_alt = alt & is_del[v_of]
+    alen[del_alt] = np.where(r[del_alt] < 0.8, 1, rng.integers(1, 6, size=int(del_alt.sum())))
+    ins_alt = alt & is_ins[v_of]
+    long_ins = ins_alt & (r < 0.06)
+    alen[ins_alt] = rng.integers(2, 61, size=int(ins_alt.sum()))
+    alen[long_ins] = rng.integers(k, k + 26, size=int(long_ins.sum()))           # alleles of k bases and more
+    ao = np.zeros(na + 1, dtype=np.int64)
+    ao[1:] = np.cumsum(alen)
+    # positions: inside a cluster the next record starts 1..20 nt behind the previous one's REF span -- or, one time in
+    # ten, inside it (overlapping records: the walks' "shorten and retry" branch)
+    adv = ref_len + rng.integers(0, 20, size=n)
+    inside = (rng.random(n) < 0.10) & (ref_len > 1)
+    adv[inside] = rng.integers(1, np.maximum(ref_len[inside], 2))
+    cl_step = rng.integers(cluster_gap // 2, cluster_gap * 3 // 2 + 1, size=n_clusters).astype(np.int64) + 2 * k + 140
+    prev_adv = np.concatenate([[0], adv[:-1]])
+    prev_adv[within == 0] = 0
+    cl_of = rec_cl
+    cid_cl = (np.arange(n_clusters, dtype=np.int64) * n_contigs) // n_clusters
+    firsts = np.searchsorted(cid_cl, np.arange(n_contigs))
+    # cluster start = running sum of (cluster step + the previous cluster's extent) inside its sequence
+    ext = np.zeros(n_clusters, dtype=np.int64)
+    np.add.at(ext, cl_of, prev_adv)
+    last_ref = np.zeros(n_clusters, dtype=np.int64)
+    np.maximum.at(last_ref, cl_of, ref_len)
+    step = cl_step + np.concatenate([[0], (ext + last_ref)[:-1]])
+    run = np.cumsum(step)
+    base_run = run[firsts] - cl_step[firsts]
+    cl_start = 500 + run - np.repeat(base_run, np.diff(np.append(firsts, n_clusters)))
+    off_in = np.cumsum(prev_adv) - np.repeat((np.cumsum(prev_adv) - prev_adv)[np.cumsum(csz) - csz], csz)
+    pos = cl_start[cl_of] + off_in
+    contig_id = cid_cl[cl_of].astype(np.uint32)
+    ends = np.zeros(n_contigs, dtype=np.int64)
+    np.maximum.at(ends, contig_id, pos + ref_len)
+    contig_len = (ends + 500 + 2 * k).astype(np.uint32)
+    contig_base = np.zeros(n_contigs, dtype=np.uint64)
+    contig_base[1:] = np.cumsum(contig_len.astype(np.uint64))[:-1]
+    genome = random_genome(int(contig_len.astype(np.int64).sum()), seed + 1)
+    gpos = contig_base[contig_id].astype(np.int64) + pos
+    pool = BASES[rng.integers(0, 4, size=int(ao[-1]), dtype=np.uint8)]
+    # REF alleles spell the genome
+    rs = np.nonzero(ref_slot)[0]
+    idx = np.repeat(ao[rs], ref_len) + (np.arange(int(ref_len.sum()), dtype=np.int64) - np.repeat(np.cumsum(ref_len) - ref_len, ref_len))
+    src = np.repeat(gpos, ref_len) + (np.arange(int(ref_len.sum()), dtype=np.int64) - np.repeat(np.cumsum(ref_len) - ref_len, ref_len))
+    pool[idx] = genome[src]
+    # one-base ALTs of one-base REFs differ from REF
+    snp_alt = alt & (alen == 1) & (ref_len[v_of] == 1)
+    sidx = ao[:-1][snp_alt]
+    pool[sidx] = BASES[(CODE[genome[gpos[v_of[snp_alt]]]] + 1 + rng.integers(0, 3, size=sidx.size, dtype=np.uint8)) % 4]
+    min_size = np.full(n, 1 << 30, dtype=np.int64)
+    np.minimum.at(min_size, v_of, alen)
+    # frequencies: AF per ALT = (1 + draw % 2999) / 10000 (sums stay below 1), f[0] = (float)(1 - sum)  (variant.hpp:134-146)
+    freq = np.zeros(na, dtype=np.float32)
+    freq[alt] = ((1 + rng.integers(0, 2999, size=int(alt.sum()))) / 10000.0).astype(np.float32)
+    acc = np.zeros(n, dtype=np.float64)
+    np.add.at(acc, v_of, freq.astype(np.float64))
+    freq[ref_slot] = (1.0 - acc).astype(np.float32)
+    # genotypes
+    a1 = (rng.random((n, n_samples)) * A[:, None]).astype(np.uint16)
+    a2 = (rng.random((n, n_samples)) * A[:, None]).astype(np.uint16)
+    hom_ref = rng.random((n, n_samples)) < 0.45
+    a1[hom_ref] = 0
+    a2[hom_ref & (rng.random((n, n_samples)) < 0.8)] = 0
+    carried = (a1 > 0).any(axis=1)
+    a1[~carried, 0] = 1                                                           # every record carries an ALT in some first haplotype
+    phased = rng.random((n, n_samples)) >= unphased_frac
+    gt = a1 | (a2 << 7) | (phased.astype(np.uint16) << 14)
+    donor = np.stack([(rng.random(n) * A).astype(np.int8), (rng.random(n) * A).astype(np.int8)], axis=1)
+    vo32, ao32 = vo.astype(np.uint32), ao.astype(np.uint32)
+    return FlatPanel(genome=genome, contig_names=[str(i + 1) for i in range(n_contigs)], contig_base=contig_base, contig_len=contig_len,
+                     contig_id=contig_id, pos=pos.astype(np.int32), ref_size=ref_len.astype(np.uint32), min_size=min_size.astype(np.uint32),
+                     present=np.ones(n, dtype=np.uint8), var_allele_off=vo32, allele_off=ao32, pool=pool, canon=_canon_of(vo32, ao32, pool), freq=freq,
+                     gt=gt.astype(np.uint16), n_samples=n_samples, donor_gt=donor)
+
+
+def donor_rows(panel: FlatPanel, ref_k, max_records=None, margin=None):
+    """ref_k-mers of the two donor haplotypes around the panel's records -> (hi, lo) M-form, not canonicalised, duplicates
+    removed.  The donor carries donor_gt[v][h] at every record that does not overlap the previous applied one (else REF).
+    Built cluster by cluster: records closer than 2 ref_k share a stretch of the haplotype.  `max_records` bounds the work
+    (the first so many records)."""
+    n = panel.n if max_records is None else min(panel.n, int(max_records))
+    margin = ref_k if margin is None else margin
+    gpos = panel.gpos()
+    his, los = [], []
+    for h in range(2):
+        pieces = []                                   # the haplotype around the records, stretches separated by 'N'
+        v = 0
+        while v < n:
+            cid = panel.contig_id[v]
+            cb, cl = int(panel.contig_base[cid]), int(panel.contig_len[cid])
+            s0 = max(cb, int(gpos[v]) - margin)
+            cur = s0
+            out = []
+            w = v
+            while w < n and panel.contig_id[w] == cid and (w == v or int(gpos[w]) <= end_reach):
+                p = int(gpos[w])
+                if p >= cur:                          # not overlapping what was applied before
+                    out.append(panel.genome[cur:p])
+                    a = int(panel.donor_gt[w, h])
+                    s = int(panel.var_allele_off[w]) + a
+                    out.append(panel.pool[panel.allele_off[s]:panel.allele_off[s + 1]])
+                    cur = p + int(panel.ref_size[w])
+                end_reach = max(cur, p + int(panel.ref_size[w])) + 2 * margin
+                w += 1
+            out.append(panel.genome[cur:min(cb + cl, cur + margin)])
+            pieces.append(np.concatenate(out))
+            pieces.append(np.frombuffer(b"N", dtype=np.uint8))
+            v = w
+        hap = np.concatenate(pieces)
+        if hap.size >= ref_k:
+            codes = CODE[hap]
+            bad = np.concatenate([[0], np.cumsum(codes > 3)])
+            ok = (bad[ref_k:] - bad[:-ref_k]) == 0
+            starts = np.nonzero(ok)[0]
+            for a in range(0, starts.size, 1 << 20):
+                st = starts[a:a + (1 << 20)]
+                hi, lo = pack_codes(codes[st[:, None] + np.arange(ref_k)[None, :]])
+                his.append(hi); los.append(lo)
+    hi, lo = np.concatenate(his), np.concatenate(los)
+    key = np.unique(np.stack([hi, lo], axis=1), axis=0)
+    return key[:, 0].copy(), key[:, 1].copy()
+
+
+def flat_kmer_table(panel: FlatPanel, n_rows, k, ref_k, seed, max_records=None):
+    """KMC-style table for a FlatPanel: the donor's ref_k-mers around the records (donor_rows) topped up to n_rows with
+    uniform random ref_k-mers, canonical, counts in [2, 63], shuffled -> (hi, lo, cnt)"""
+    rng = np.random.default_rng(seed)
+    hi, lo = donor_rows(panel, ref_k, max_records)
+    if hi.size > n_rows:
+        sel = rng.permutation(hi.size)[:n_rows]
+        hi, lo = hi[sel], lo[sel]
+    n_rand = n_rows - hi.size
+    mh, ml = _mask(ref_k)
+    rh = rng.integers(0, 1 << 63, size=n_rand, dtype=np.uint64) * U(2) + rng.integers(0, 2, size=n_rand, dtype=np.uint64)
+    rl = rng.integers(0, 1 << 63, size=n_rand, dtype=np.uint64) * U(2) + rng.integers(0, 2, size=n_rand, dtype=np.uint64)
+    hi = np.concatenate([hi, rh & mh]); lo = np.concatenate([lo, rl & ml])
+    hi, lo = canonical_m(hi, lo, ref_k)
+    perm = rng.permutation(n_rows)
+    cnt = (2 + rng.integers(0, 62, size=n_rows)).astype(np.uint32)
+    return hi[perm], lo[perm], cnt
+
+
+def write_vcf_fasta(panel: FlatPanel, prefix, freq_key="AF"):
+    """the panel as <prefix>.fa + <prefix>.vcf (diploid GT columns as held), so the same records can go through the CLI
+    and through the oracle's VCF model"""
+    with open(prefix + ".fa", "w") as fh:
+        for name, b, l in zip(panel.contig_names, panel.contig_base, panel.contig_len):
+            fh.write(">%s\n" % name)
+            seq = panel.genome[int(b):int(b) + int(l)].tobytes().decode()
+            for a in range(0, len(seq), 1 << 16):
+                fh.write(seq[a:a + (1 << 16)] + "\n")
+    samples = ["S%d" % i for i in range(panel.n_samples)]
+    with open(prefix + ".vcf", "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##INFO=<ID=%s,Number=A,Type=Float,Description=\"af\">\n"
+                 "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n" % freq_key)
+        for name, l in zip(panel.contig_names, panel.contig_len):
+            fh.write("##contig=<ID=%s,length=%d>\n" % (name, int(l)))
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n")
+        for v in range(panel.n):
+            a0, a1 = int(panel.var_allele_off[v]), int(panel.var_allele_off[v + 1])
+            alleles = [panel.allele(v, a) .decode() for a in range(a1 - a0)]
+            g = panel.gt[v]
+            gts = ["%d%s%d" % (int(x) & 127, "|" if (int(x) >> 14) & 1 else "/", (int(x) >> 7) & 127) for x in g]
+            af = ",".join(repr(float(np.float32(f))) for f in panel.freq[a0 + 1:a1])
+            fh.write("%s\t%d\t.\t%s\t%s\t.\t.\t%s=%s\tGT\t%s\n" % (panel.contig_names[int(panel.contig_id[v])], int(panel.pos[v]) + 1, alleles[0],
+                                                               ",".join(alleles[1:]), freq_key, af, "\t".join(gts)))

@@ -1,0 +1,106 @@
+"""The record loop on a RESIDENT panel (mg_cut_blocks_device -> mg_cover_blocks_device -> mg_genotype_device, and
+mg_index_blocks_device) against the C oracle's block path (oracle/malva_oracle.c: mo_cut_blocks, mo_index_blocks,
+mo_cover_blocks, mo_genotype_panel -- itself pinned to the Python model in tests/test_oracle_blocks_cpu.py), on the two
+recipes BASELINE.json names for the general-block path: config C4's clustered SNP panel as SURVEY 8(d) draws it (38 nt mean
+spacing, a tenth of the records in clusters of <= 4 within 17 nt, positions beyond 2^25 where are_near runs in float) and
+config C5's indel / MNP clusters (k35 r63, haploid and diploid).  Every array stays in HBM between the calls; bits, keys,
+counters, cuts, coverages, GT and GQ must equal the oracle's, likelihoods within 1e-6 (they are bit-equal)."""
+import numpy as np
+import pytest
+
+from gpu_util import map_values_by_key
+from malva_amd import BF_ALT, BF_CTX, Context, synth
+from malva_amd.resident import ResidentPanel
+from oracle import capi as ocapi
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6        # north_star's tolerance on normalised likelihoods
+
+
+def oracle_blocks(panel, k):
+    off, bc = ocapi.cut_blocks(panel.pos, panel.ref_size, panel.min_size, panel.contig_id, k)
+    return dict(blk_ref_base=panel.contig_base[bc], blk_ref_len=panel.contig_len[bc], blk_var_off=off, pos=panel.pos, ref_size=panel.ref_size,
+                min_size=panel.min_size, present=panel.present, var_allele_off=panel.var_allele_off, allele_off=panel.allele_off, pool=panel.pool,
+                canon=panel.canon, gt=panel.gt, n_samples=panel.n_samples)
+
+
+def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general):
+    args = oracle_blocks(panel, k)
+    sizes = np.diff(args["blk_var_off"].astype(np.int64))
+    assert (sizes > 1).sum() >= min_general, "the recipe drew too few general blocks: %d" % (sizes > 1).sum()
+    # ---- index: the oracle's, then the device's from the resident panel ----
+    obf, octx, omap = ocapi.BF(bits), ocapi.BF(bits), ocapi.KMAP()
+    ocapi.index_blocks(obf, omap, panel.genome, **args, haploid=haploid, k=k)
+    obf.switch_mode()
+    for b, l in zip(panel.contig_base, panel.contig_len):
+        ocapi.ref_scan(obf, octx, panel.genome[int(b):int(b) + int(l)].tobytes(), k, ref_k)
+    octx.switch_mode()
+    with Context(k, ref_k, bits) as ctx:
+        ctx.reference_upload(panel.genome)
+        rp = ResidentPanel(panel, 0, haploid=haploid)
+        ovf = rp.index(ctx)
+        assert ovf.sum() == 0, "%d records handed back at index time" % int(ovf.sum())
+        ctx.bf_finalize(BF_ALT)
+        for b, l in zip(panel.contig_base, panel.contig_len):
+            ctx.ref_scan(panel.genome[int(b):int(b) + int(l)])
+        ctx.bf_finalize(BF_CTX)
+        assert np.array_equal(ctx.bf_export_sparse(BF_ALT)[2], obf.set_positions())
+        assert np.array_equal(ctx.bf_export_sparse(BF_CTX)[2], octx.set_positions())
+        keys, _ = ctx.map_export()
+        assert sorted(keys) == sorted(k_ for k_, _ in omap.items())
+        # ---- scan: the donor's ref_k-mers around the first `plant` records + random rows ----
+        hi, lo, cnt = synth.flat_kmer_table(panel, n_rows, k, ref_k, seed=7, max_records=plant)
+        ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        ctx.kmc_scan(hi, lo, cnt)
+        assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
+        assert map_values_by_key(ctx) == dict(omap.items())
+        # ---- call: cut, cover, genotype, everything resident ----
+        rp.call_step(ctx)
+        got = rp.results()
+        assert np.array_equal(got["blk_var_off"], args["blk_var_off"])
+        assert got["overflow"].sum() == 0, "%d records handed back at call time" % int(got["overflow"].sum())
+        stats = {}
+        want_cov = ocapi.cover_blocks(obf, omap, panel.genome, **args, haploid=haploid, k=k, stats=stats)
+        assert np.array_equal(got["cov"], want_cov)
+        assert (want_cov > 0).sum() > plant // 2
+        g1, g2, gq = ocapi.genotype_panel(want_cov, panel.freq, panel.var_allele_off, 0.001, 200, haploid)
+        assert np.array_equal(got["g1"], g1) and np.array_equal(got["g2"], g2) and np.array_equal(got["gq"], gq)
+        assert ((g1 > 0) | (g2 > 0)).sum() > plant // 20
+        # likelihood lists of a sample of records, through the oracle's per-variant form
+        rng = np.random.default_rng(1)
+        goff = rp.t["gt_off"].cpu().numpy().view(np.uint64)
+        worst = 0.0
+        for v in rng.choice(panel.n, size=min(panel.n, 3000), replace=False):
+            a0, a1 = int(panel.var_allele_off[v]), int(panel.var_allele_off[v + 1])
+            gts = ocapi.genotype(want_cov[a0:a1], panel.freq[a0:a1], 0.001, 200, haploid)
+            if got["status"][v] != 0:
+                continue
+            _, _, norm = ocapi.select_gt([g[2] for g in gts])
+            mine = got["probs"][int(goff[v]):int(goff[v + 1])]
+            assert len(mine) == len(norm)
+            both = ~(np.isnan(norm) & np.isnan(mine))
+            worst = max(worst, float(np.max(np.abs(norm[both] - mine[both]), initial=0.0)))
+        assert worst <= TOL
+        # the same call step again: the resident arrays were not consumed
+        rp.call_step(ctx)
+        again = rp.results()
+        assert np.array_equal(again["cov"], got["cov"]) and np.array_equal(again["gq"], got["gq"])
+    return stats
+
+
+def test_c4_recipe_clustered_snps_beyond_2_to_the_25():
+    """~38 nt mean spacing, 10 % of the SNPs in clusters of <= 4 within 17 nt; ONE sequence so that most
+    positions lie beyond 2^24 (float are_near) -- at 1.2e6 records the last sit near 4.4e7."""
+    k, ref_k = 35, 43
+    panel = synth.clustered_snp_panel(1_200_000, seed=41, n_contigs=1)
+    assert panel.pos.max() > (1 << 25)
+    stats = run_recipe(panel, k, ref_k, False, 1 << 30, n_rows=3_000_000, plant=20_000, min_general=30_000)
+    assert stats["signatures"] > 2 * panel.n
+
+
+@pytest.mark.parametrize("haploid", [False, True])
+def test_c5_recipe_indel_mnp_clusters_r63(haploid):
+    """clusters of <= 6 mixing SNPs, MNPs, deletions, insertions (some >= k), <= 3 ALTs, 8 samples half
+    unphased; k35 r63"""
+    panel = synth.indel_panel(60_000, seed=52 + int(haploid))
+    run_recipe(panel, 35, 63, haploid, 1 << 28, n_rows=2_000_000, plant=15_000, min_general=30_000)
