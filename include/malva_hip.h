@@ -265,8 +265,10 @@ typedef struct mg_panel_dev {
 int mg_cut_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, void *d_blk_var_off_out, void *d_var_block_out, void *d_n_blocks_out);
 /* extract_kmers + set_coverages (main.cpp:556-557) for every block: d_cov_out ([slots] u32) and d_overflow_out ([n_vars]
  * u8) as mg_cover_blocks returns them.  A block is evaluated against the sequence of its first record (`last_seq_name` at
- * the flush, main.cpp:556).  Blocks of one variant whose alleles are all shorter than k take the fused lone-variant kernels
- * (those of mg_call_isolated), the others the enumerating kernel, launched as a persistent grid over their list. */
+ * the flush, main.cpp:556).  Three tiers (csrc/block_pipeline.h): blocks of one variant whose alleles are all shorter than k
+ * take the fused lone-variant lookup of mg_call_isolated; the other records a pipeline of flat kernels (one thread per record
+ * for the chain walks, one wave per chain for the distinct haplotype picks, one thread per signature k-mer); what exceeds
+ * that pipeline's capacities the workgroup-per-record kernel; what exceeds ITS capacities is flagged in d_overflow_out. */
 int mg_cover_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d_blk_var_off, const void *d_var_block /* or NULL */,
                            const void *d_n_blocks, int haploid, void *d_cov_out, void *d_overflow_out);
 /* extract_kmers + add_kmers_to_bf (main.cpp:349-350) for every block (the panel holds only what `index` keeps,
@@ -361,6 +363,11 @@ int mg_debug_packed_index(mg_ctx *ctx, int which, const uint64_t *hi, const uint
  * [2] hit kernel (with the ticket form [0] is its two passes together); rows_out[0] = rows that passed the gate (last chunk),
  * rows_out[1] = rows whose bf bit was set (whole call) */
 int mg_scan_stats(mg_ctx *ctx, float *ms_out, uint64_t *rows_out);
+/* timing and counts of the most recent mg_cover_blocks_device (waits for it): ms_out[0] tier 1 (classification + the
+ * lone-variant lookups), [1] tier 2 (the flat pipeline: chain walks, distinct picks, one thread per signature k-mer), [2] tier 3
+ * (the workgroup-per-record kernel on what tier 2 handed on) + the final pass; counts_out[0] records beyond tier 1, [1] signature
+ * k-mers of the lone records, [2] signature k-mers tiers 2 and 3 assembled, [3] records tier 3 took */
+int mg_blocks_stats(mg_ctx *ctx, float *ms_out, uint64_t *counts_out);
 /* 0 disables the cache-resident summary bitmaps (A/B switch; results identical) */
 int mg_set_option(mg_ctx *ctx, const char *name, int64_t value);
 /* reads an option back, plus "pregate_k" (0: single-level gate), "scan_bins" (slices the

@@ -122,6 +122,7 @@ def lib():
         "mg_debug_bf_index": [vp, it, vp, sz, sz, vp],
         "mg_debug_packed_index": [vp, it, vp, vp, sz, u32, vp],
         "mg_scan_stats": [vp, vp, vp],
+        "mg_blocks_stats": [vp, vp, vp],
         "mg_set_option": [vp, cp, i64],
         "mg_get_option": [vp, cp, C.POINTER(C.c_int64)],
     }
@@ -147,7 +148,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_index_isolated",
             "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
-            "mg_debug_packed_index", "mg_scan_stats", "mg_set_option", "mg_get_option"]
+            "mg_debug_packed_index", "mg_scan_stats", "mg_blocks_stats", "mg_set_option", "mg_get_option"]
 
 
 def _p(a):
@@ -433,6 +434,13 @@ class Context:
         nr = (C.c_uint64 * 2)()
         self._ck(self._L.mg_scan_stats(self.h, ms, nr))
         return float(ms[0]), float(ms[1]), float(ms[2]), int(nr[0]), int(nr[1])
+
+    def blocks_stats(self):
+        """-> (tier 1 ms, tier 2 ms, tier 3 ms, records beyond tier 1, lone signature k-mers, general signature k-mers, records tier 3 took)"""
+        ms = (C.c_float * 3)()
+        nr = (C.c_uint64 * 4)()
+        self._ck(self._L.mg_blocks_stats(self.h, ms, nr))
+        return float(ms[0]), float(ms[1]), float(ms[2]), int(nr[0]), int(nr[1]), int(nr[2]), int(nr[3])
 
     # counters exchange
     def counters_size(self):

@@ -1,0 +1,560 @@
+// block_pipeline.h -- the record loop's per-block work on a resident panel, as tiers of flat kernels.
+// Part of the malva_hip translation unit: included by malva_hip.hip inside its anonymous namespace, after variant_kernels.h.
+//
+// VB::extract_kmers (var_block.hpp:95-219) with its helpers (:436-786) + set_coverages (main.cpp:151-184) / add_kmers_to_bf
+// (main.cpp:122-144) for every record of a panel whose blocks are cut.  cover_blocks_kernel (variant_kernels.h) gives a
+// whole workgroup to one record and walks its chains on one lane: right for a panel of tens of thousands of samples and
+// blocks of thousands of records, 70-130 us per record for a cluster of four SNPs and two samples.  Most records of a
+// real panel are of the second kind, so the work is dealt out by what it is made of instead:
+//
+//   tier 1  panel_lone_kernel         a block of ONE variant with short alleles (nine records in ten): classification fused
+//                                     with the lone-variant lookup of mg_call_isolated, two threads per record; every
+//                                     other record is appended to the general list
+//   tier 2  fw_walk_kernel            one THREAD per general record: the two chain walks (get_combs_on_the_left / _right)
+//                                     in private memory, every (left, right) pair written out as a 32-byte descriptor
+//           fw_picks_kernel           one WAVE per descriptor, lanes over the panel's samples: the distinct haplotype picks
+//                                     along the chain (build_alleles_combs' unordered_set) in a per-wave LDS set, written
+//                                     out as (descriptor, pick) items
+//           fw_eval_kernel            one THREAD per item: assemble the signature k-mer in 2-bit form, canonical, XXH3,
+//                                     lookup (or insert), atomicMax into the allele's coverage
+//   tier 3  cover_blocks_kernel       whatever exceeds a capacity of tier 2 (chains, reach, code width, distinct picks,
+//                                     a base outside ACGT, an allele of k bases or more on its own, more than FW_MAX_SAMPLES
+//                                     samples), from a compacted list; what exceeds ITS capacities is flagged for the host
+//
+// Every count lives on the device: the general list is processed in rounds of a fixed number of records whose buffers
+// are sized by the round, rounds beyond the list's end find nothing to do, and no launch waits for the host.
+#pragma once
+
+constexpr int FW_MAXC = 6;           // chains per side
+constexpr int FW_MAXM = 10;          // members per chain side
+constexpr int FW_REACH = 120;        // records a walk may move away from its variant (members are stored as int8 offsets)
+constexpr int FW_SET = 512;          // slots of a wave's LDS set of distinct picks (at most 3/4 used)
+constexpr int FW_MAXU = 12;          // unphased chain length (2^12 mixes per sample)
+constexpr u32 FW_MAX_SAMPLES = 512;  // larger panels take the workgroup kernel (its 256 threads stride over the samples)
+constexpr int FW_COMBS_PER_REC = 8;  // descriptors a round's buffer holds per record of the round (average; a record may use 36)
+constexpr int FW_ITEMS_PER_REC = 32; // items likewise
+
+struct FwSide {
+    int n;
+    int len[FW_MAXC];
+    int sum[FW_MAXC];
+    signed char mem[FW_MAXC][FW_MAXM]; // offsets from the variant
+};
+struct __attribute__((aligned(16))) CombDesc {
+    u32 g;   // the variant the chain is built around
+    u32 cid; // sequence its block is evaluated against
+    u8 m, jm; // members, index of g among them
+    signed char rel[22]; // members as offsets from g, left to right
+};
+static_assert(sizeof(CombDesc) == 32, "one descriptor per 32 bytes");
+struct __attribute__((aligned(16))) PickItem {
+    u32 comb;
+    u32 pad;
+    u64 code; // allele of member j at bits [shift_j, shift_j + bits_j), bits_j = ceil(log2(alleles of member j)) (1 for two)
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int fw_bits(u32 n_alleles) { return n_alleles <= 2 ? 1 : 32 - __clz((int)n_alleles - 1); }
+
+// ---- tier 1 ------------------------------------------------------------------------------------------------------------------
+// counters: [0] general records listed, [2] signature k-mers of the lone records
+struct LoneClass {
+    bool lone, eligible;
+    u64 site, mask;
+    u32 a0, A;
+};
+__device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32 *blk_var_off, const u32 *var_block, u64 v, int k, int haploid)
+{
+    LoneClass c{};
+    const u32 blk = var_block[v];
+    const u32 b0 = blk_var_off[blk], b1 = blk_var_off[blk + 1];
+    const u32 cid = P.contig_id[b0];
+    const u64 cbase = P.contig_base[cid];
+    const u32 clen = P.contig_len[cid];
+    const i32 p = P.pos[v];
+    const u32 rs = P.ref_size[v];
+    c.a0 = P.var_allele_off[v];
+    c.A = P.var_allele_off[v + 1] - c.a0;
+    // a block of one variant, alleles all shorter than k (at most 64 of them: the presence mask), flanks inside the sequence
+    bool lone = b1 - b0 == 1 && c.A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
+    if (lone)
+        for (u32 a = 0; a < c.A; ++a) lone = lone && (int)(P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a]) < k;
+    c.lone = lone;
+    if (!lone) return c;
+    c.eligible = P.present[v] && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
+    u64 mask = 0;
+    if (c.eligible) // build_alleles_combs on a chain of one (var_block.hpp:734-786): the alleles some panel haplotype carries
+        for (u32 s = 0; s < P.n_samples; ++s) {
+            const u32 g = P.gt[v * P.n_samples + s];
+            mask |= 1ULL << P.canon[c.a0 + (g & 127)];
+            if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
+        }
+    c.mask = mask;
+    c.site = cbase + (u64)p;
+    return c;
+}
+// every lane of the wave calls this
+__device__ __forceinline__ void list_append(bool take, u32 value, u32 *list, unsigned long long *count)
+{
+    const u64 m = __ballot(take);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (take) list[base + __popcll(m & ((1ULL << lane) - 1))] = value;
+}
+template <bool SLOW>
+__global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
+                                                         const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 *cov_out,
+                                                         u32 *need_slow, u32 call_no, u32 *gen_list, unsigned long long *counters)
+{
+    if (SLOW && *need_slow != call_no) return;
+    const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 v = t >> 1;
+    const bool in = v < n_vars;
+    LoneClass c{};
+    if (in) c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+    if (!SLOW) {
+        list_append(in && !c.lone && !(t & 1), (u32)v, gen_list, counters);
+        u32 sigs = in && c.lone && !(t & 1) ? (u32)__popcll(c.mask) : 0;
+        for (int d = 32; d; d >>= 1) sigs += __shfl_xor(sigs, d, 64);
+        if ((threadIdx.x & 63) == 0 && sigs) atomicAdd(counters + 2, (unsigned long long)sigs);
+    }
+    if (in && c.lone) iso_cover_body<SLOW>(reference, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
+}
+// index time: lone records are inserted here (REF key of record v takes insertion row row0 + v), the others listed
+__global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
+                                                               const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 row0,
+                                                               u8 *overflow, u32 *gen_list, unsigned long long *counters)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    const bool in = v < n_vars;
+    LoneClass c{};
+    if (in) c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+    list_append(in && !c.lone, (u32)v, gen_list, counters);
+    if (in && c.lone && c.eligible && !iso_index_body(reference, c.site, c.a0, c.A, c.mask, P.allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
+}
+
+// ---- tier 2 ------------------------------------------------------------------------------------------------------------------
+struct FlatWork {
+    const u32 *gen_list;
+    const unsigned long long *gen_count;
+    u64 base, round_len; // this round: entries [base, base + round_len) of the list
+    CombDesc *combs;
+    u32 comb_cap;
+    PickItem *items;
+    u32 item_cap;
+    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved
+    u8 *fb_flag;                  // [n_vars] the record goes to the workgroup kernel
+};
+
+// get_combs_on_the_right (step +1, var_block.hpp:436-525) / _left (step -1, :534-624) in private memory; false: a capacity
+__device__ bool fw_walk(const BlockBatch &B, int b0, int b1, int i, int step, FwSide *out)
+{
+    const int k = B.k;
+    auto ov = [&](int x, int y) { // overlapping(left, right) with (x, y) given in scan order
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return B.pos[l] <= B.pos[r] && B.pos[r] < B.pos[l] + (int)B.ref_size[l];
+    };
+    auto nr = [&](int x, int y, int extra) {
+        const int l = step > 0 ? x : y, r = step > 0 ? y : x;
+        return near_f32(B.pos[l] + (int)B.ref_size[l] - (int)B.min_size[l] - 1 + extra, k, B.pos[r]);
+    };
+    out->n = 0;
+    bool halt = false;
+    for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
+        if (j - i > FW_REACH || i - j > FW_REACH) return false; // (the reference walks to the block's end: so does the workgroup kernel)
+        if (!B.present[j]) continue;
+        if (ov(i, j)) continue;
+        const int gain = (int)B.ref_size[j] - (int)B.min_size[j];
+        if (out->n == 0) {
+            if (nr(i, j, 0)) {
+                out->mem[0][0] = (signed char)(j - i);
+                out->len[0] = 1;
+                out->sum[0] = gain;
+                out->n = 1;
+            }
+            continue;
+        }
+        bool added = false;
+        const int n0 = out->n;
+        for (int c = 0; c < n0; ++c) {
+            if (!ov(i + out->mem[c][out->len[c] - 1], j)) {
+                added = true;
+                if (nr(i, j, out->sum[c])) {
+                    if (out->len[c] >= FW_MAXM) return false;
+                    out->mem[c][out->len[c]++] = (signed char)(j - i);
+                    out->sum[c] += gain;
+                }
+            }
+        }
+        if (!added) {
+            for (int c = 0; c < n0; ++c) {
+                int len = out->len[c], ns = out->sum[c];
+                while (len > 0 && ov(i + out->mem[c][len - 1], j)) {
+                    const int m = i + out->mem[c][len - 1];
+                    ns -= (int)B.ref_size[m] - (int)B.min_size[m];
+                    --len;
+                }
+                if (nr(i, j, ns)) {
+                    added = true;
+                    if (out->n >= FW_MAXC || len + 1 > FW_MAXM) return false;
+                    const int d = out->n++;
+                    for (int q = 0; q < len; ++q) out->mem[d][q] = out->mem[c][q];
+                    out->mem[d][len] = (signed char)(j - i);
+                    out->len[d] = len + 1;
+                    out->sum[d] = ns + gain;
+                }
+            }
+            if (!added) halt = true;
+        }
+    }
+    return true;
+}
+
+// MODE 0 call time, 1 index time counting pass, 2 index time insert pass (skips what pass 1 flagged)
+template <int MODE>
+__global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, u32 *cov_out, u8 *overflow)
+{
+    const u64 tid = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 idx = W.base + tid;
+    const bool in = tid < W.round_len && idx < *W.gen_count;
+    FwSide L, R;
+    L.n = R.n = 0;
+    u32 g = 0, cid = 0, n_combs = 0;
+    if (in) {
+        g = W.gen_list[idx];
+        const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
+        const u32 blk = B.var_block[g];
+        const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
+        cid = B.contig_id[b0];
+        const i32 ref_len = (i32)B.contig_len[cid];
+        if (MODE == 0)
+            for (u32 a = 0; a < A; ++a) cov_out[a0 + a] = 0;
+        bool skip = MODE == 2 && (overflow[g] || W.fb_flag[g]);
+        if (!skip && (A > 127 || B.k > MG_MAX_PACKED_K)) { // what the workgroup kernel flags at once
+            if (MODE != 2) overflow[g] = 1;
+            skip = true;
+        }
+        if (!skip && B.n_samples > FW_MAX_SAMPLES) {
+            W.fb_flag[g] = 1;
+            skip = true;
+        }
+        const bool eligible = B.present[g] && B.pos[g] >= B.k && B.pos[g] <= ref_len - B.k; // var_block.hpp:104
+        if (!skip && eligible) {
+            if (fw_walk(B, b0, b1, (int)g, -1, &L) && fw_walk(B, b0, b1, (int)g, +1, &R)) n_combs = (u32)((L.n ? L.n : 1) * (R.n ? R.n : 1));
+            else W.fb_flag[g] = 1;
+        }
+    }
+    // room for the wave's descriptors: one atomic
+    const int lane = threadIdx.x & 63;
+    u32 incl = n_combs;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    const u32 total = __shfl(incl, 63, 64);
+    if (!total) return;
+    unsigned long long base = 0;
+    if (lane == 63) base = atomicAdd(&W.counters[0], (unsigned long long)total);
+    base = __shfl(base, 63, 64);
+    if (base + total > W.comb_cap) { // (an average of FW_COMBS_PER_REC per record of the round was not enough)
+        if (n_combs) W.fb_flag[g] = 1;
+        CombDesc none{};                   // what of the reservation lies inside the buffer must not be read as descriptors
+        for (u64 q = base + lane; q < W.comb_cap && q < base + total; q += 64) W.combs[q] = none;
+        return;
+    }
+    if (!n_combs) return;
+    CombDesc *out = W.combs + base + (incl - n_combs);
+    const int nl = L.n ? L.n : 1, nrr = R.n ? R.n : 1;
+    for (int c = 0; c < nl * nrr; ++c) { // combine_combs (var_block.hpp:630-677): every left chain (reversed) + the variant + every right chain
+        const int cl = c / nrr, cr = c % nrr;
+        const int len_l = L.n ? L.len[cl] : 0, len_r = R.n ? R.len[cr] : 0;
+        CombDesc d;
+        d.g = g;
+        d.cid = cid;
+        d.m = (u8)(len_l + 1 + len_r);
+        d.jm = (u8)len_l;
+        for (int j = 0; j < 22; ++j) d.rel[j] = 0;
+        for (int j = 0; j < len_l; ++j) d.rel[j] = L.mem[cl][len_l - 1 - j];
+        for (int j = 0; j < len_r; ++j) d.rel[len_l + 1 + j] = R.mem[cr][j];
+        out[c] = d;
+    }
+}
+
+// build_alleles_combs + combine_haplotypes (var_block.hpp:709-786) for one chain: the distinct picks of all panel samples
+constexpr int FW_WAVES = TPB / 64;
+__global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
+{
+    __shared__ unsigned long long sh_set[FW_WAVES][FW_SET]; // code + 1, 0 = free
+    __shared__ unsigned short sh_list[FW_WAVES][FW_SET];    // slots taken, in the order they were taken
+    __shared__ u32 sh_n[FW_WAVES];
+    __shared__ u8 sh_bits[FW_WAVES][24], sh_shift[FW_WAVES][24];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long *set = sh_set[wave];
+    unsigned short *list = sh_list[wave];
+    for (int i = lane; i < FW_SET; i += 64) set[i] = 0;
+    if (lane == 0) sh_n[wave] = 0;
+    wave_sync();
+    const u64 n_combs = min((unsigned long long)W.comb_cap, W.counters[0]);
+    const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    for (u64 ci = (u64)blockIdx.x * FW_WAVES + wave; ci < n_combs; ci += n_waves) {
+        const CombDesc d = W.combs[ci];
+        const int m = d.m;
+        const u32 g = d.g;
+        if (m == 0 || __shfl((int)W.fb_flag[g], 0, 64)) continue; // (wave-uniform; m == 0: a reservation that did not fit)
+        if (lane < m) {
+            const u32 v = g + d.rel[lane];
+            sh_bits[wave][lane] = (u8)fw_bits(B.var_allele_off[v + 1] - B.var_allele_off[v]);
+        }
+        wave_sync();
+        if (lane == 0) {
+            int sh = 0;
+            for (int j = 0; j < m; ++j) {
+                sh_shift[wave][j] = (u8)(sh > 255 ? 255 : sh);
+                sh += sh_bits[wave][j];
+            }
+            sh_shift[wave][m] = (u8)(sh > 255 ? 255 : sh);
+        }
+        wave_sync();
+        bool fail = sh_shift[wave][m] > 63; // the pick does not fit a 63-bit code
+        auto insert = [&](unsigned long long code) {
+            u32 at = (u32)((code * 0x9E3779B97F4A7C15ULL) >> 40) & (FW_SET - 1);
+            for (int tries = 0; tries < FW_SET; ++tries) {
+                const unsigned long long seen = atomicCAS(&set[at], 0ULL, code + 1);
+                if (seen == 0ULL) {
+                    const u32 q = atomicAdd(&sh_n[wave], 1u);
+                    if (q < FW_SET) list[q] = (unsigned short)at;
+                    return;
+                }
+                if (seen == code + 1) return;
+                at = (at + 1) & (FW_SET - 1);
+            }
+        };
+        if (!fail)
+            for (u32 s = lane; s < B.n_samples; s += 64) {
+                if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break; // too many distinct picks for the set: the workgroup kernel takes the record
+                bool phased = true;
+                unsigned long long c1 = 0, c2 = 0;
+                for (int j = 0; j < m; ++j) {
+                    const u32 v = g + d.rel[j];
+                    const u32 gt = B.gt[(u64)v * B.n_samples + s];
+                    phased = phased && ((gt >> 14) & 1);
+                    c1 |= (unsigned long long)(gt & 127) << sh_shift[wave][j];
+                    c2 |= (unsigned long long)((gt >> 7) & 127) << sh_shift[wave][j];
+                }
+                if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): the workgroup kernel's
+                    const u32 a0 = B.var_allele_off[g];
+                    const u32 l1 = B.allele_off[a0 + (u32)c1 + 1] - B.allele_off[a0 + (u32)c1], l2 = B.allele_off[a0 + (u32)c2 + 1] - B.allele_off[a0 + (u32)c2];
+                    if ((int)l1 >= B.k || (!B.haploid && (int)l2 >= B.k)) {
+                        fail = true;
+                        break;
+                    }
+                }
+                if (B.haploid) insert(c1);
+                else if (phased) {
+                    insert(c1);
+                    insert(c2);
+                } else if (m > FW_MAXU) {
+                    fail = true;
+                    break;
+                } else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
+                    const unsigned long long diff = c1 ^ c2;
+                    unsigned long long code = c1;
+                    insert(code);
+                    for (u32 i = 1; i < (1u << m); ++i) {
+                        const int j = __ffs((int)i) - 1;
+                        const unsigned long long fm = ((1ULL << sh_bits[wave][j]) - 1) << sh_shift[wave][j];
+                        code ^= diff & fm;
+                        if (diff & fm) insert(code);
+                        if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break;
+                    }
+                }
+            }
+        wave_sync();
+        const u32 n = sh_n[wave];
+        fail = __any(fail) || n > FW_SET * 3 / 4;
+        const u32 n_used = n < FW_SET ? n : FW_SET;
+        if (!fail && n) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&W.counters[1], (unsigned long long)n);
+            base = __shfl(base, 0, 64);
+            if (base + n > W.item_cap) {
+                fail = true;
+                for (u64 q = base + lane; q < W.item_cap && q < base + n; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
+            } else
+                for (u32 i = lane; i < n; i += 64) W.items[base + i] = PickItem{(u32)ci, 0u, set[list[i]] - 1};
+        }
+        if (fail && lane == 0) W.fb_flag[g] = 1;
+        for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
+        if (n > FW_SET) // (the list lost entries: clear the whole set)
+            for (int i = lane; i < FW_SET; i += 64) set[i] = 0;
+        wave_sync();
+        if (lane == 0) sh_n[wave] = 0;
+        wave_sync();
+    }
+}
+
+// one signature k-mer: assembly in 2-bit form, canonical, XXH3, then MODE 0 lookup + max into the allele's coverage,
+// MODE 1 count the REF k-mers, MODE 2 insert
+template <int MODE>
+__global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, BFView bf, MapView map, u32 *cov_out, u8 *overflow, unsigned long long *cursor, u32 row0,
+                                                      unsigned long long *n_evaluated)
+{
+    const u64 n_items = min((unsigned long long)W.item_cap, W.counters[1]);
+    const u64 n_threads = (u64)gridDim.x * TPB;
+    const int k = B.k;
+    u32 evaluated = 0, ref_rows = 0;
+    for (u64 it = (u64)blockIdx.x * TPB + threadIdx.x; it < n_items; it += n_threads) {
+        const PickItem item = W.items[it];
+        if (item.comb == 0xFFFFFFFFu) continue; // a reservation that did not fit
+        const CombDesc d = W.combs[item.comb];
+        const u32 g = d.g;
+        if (W.fb_flag[g]) continue;
+        const int m = d.m, jm = d.jm;
+        const u8 *ref = B.reference + B.contig_base[d.cid];
+        const i32 ref_len = (i32)B.contig_len[d.cid];
+        // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
+        int len_v = 0, mid_pos = 0, mid_len = 0, sh = 0;
+        u32 mid_allele = 0;
+        const int first_pos = B.pos[g + d.rel[0]];
+        int last_end = 0;
+        for (int j = 0; j < m; ++j) {
+            const u32 v = g + d.rel[j];
+            const u32 s0 = B.var_allele_off[v];
+            const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
+            const u32 a = (u32)(item.code >> sh) & ((1u << bits) - 1);
+            sh += bits;
+            const int al = (int)(B.allele_off[s0 + a + 1] - B.allele_off[s0 + a]);
+            if (j == jm) {
+                mid_pos = len_v;
+                mid_len = al;
+                mid_allele = a;
+            }
+            len_v += al;
+            last_end = B.pos[v] + (int)B.ref_size[v];
+            if (j + 1 < m) len_v += B.pos[g + d.rel[j + 1]] - last_end;
+        }
+        const u32 a0 = B.var_allele_off[g];
+        const u32 mid_canon = B.canon[a0 + mid_allele];
+        const int first_part = mid_pos + mid_len / 2;
+        const int mp = k / 2 - first_part;                 // missing_prefix (negative: cut)
+        const int ms = (k + 1) / 2 - (len_v - first_part); // missing_suffix
+        if (first_pos - (mp > 0 ? mp : 0) < 0 || last_end + (ms > 0 ? ms : 0) > ref_len) {
+            if (MODE != 2) overflow[g] = 1; // the reference clips or throws here: the host path's
+            continue;
+        }
+        // W[x] = Vext[x - mp] for x in [0, k), Vext = V with the reference continuing on both sides
+        U128 Lf{0, 0};
+        bool ok = k >= 17 && k <= MG_MAX_PACKED_K;
+        auto put = [&](int x, u32 byte) {
+            bool o;
+            const u64 code = acgt_code(byte, &o);
+            ok = ok && o;
+            if (x < 32) Lf.lo |= code << (2 * x);
+            else Lf.hi |= code << (2 * (x - 32));
+        };
+        for (int x = 0; x < mp && x < k; ++x) put(x, ref[first_pos - mp + x]);
+        int vs = 0;
+        sh = 0;
+        for (int j = 0; j < m; ++j) {
+            const u32 v = g + d.rel[j];
+            const u32 s0 = B.var_allele_off[v];
+            const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
+            const u32 a = (u32)(item.code >> sh) & ((1u << bits) - 1);
+            sh += bits;
+            const u8 *ap = B.pool + B.allele_off[s0 + a];
+            const int al = (int)(B.allele_off[s0 + a + 1] - B.allele_off[s0 + a]);
+            for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) put(x, ap[x - mp - vs]);
+            vs += al;
+            if (j + 1 < m) {
+                const int gs = B.pos[v] + (int)B.ref_size[v];
+                const int gl = B.pos[g + d.rel[j + 1]] - gs;
+                for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) put(x, ref[gs + (x - mp - vs)]);
+                vs += gl;
+            }
+        }
+        for (int x = max(0, len_v + mp); x < k; ++x) put(x, ref[last_end + (x - mp - len_v)]);
+        if (!ok) { // a base outside ACGT (or a k the packed form does not hold): the byte-wise path of the workgroup kernel
+            W.fb_flag[g] = 1;
+            continue;
+        }
+        ++evaluated;
+        const U128 mk = mask128(2 * k);
+        const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
+        const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+        const U128 key = lt128(Lf, rc) ? Lf : rc;
+        const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
+        const u64 idx = mod_size(h, bf.mod);
+        const bool is_ref = mid_canon == 0;
+        if (MODE == 0) {
+            i32 w;
+            if (is_ref) {
+                const long long id = k == (int)map.klen ? map_find_id(map, key, h, idx) : -1;
+                w = id >= 0 ? (i32)map.vals[id] : 0;
+            } else {
+                const long long rank = bucket_rank(map, idx);
+                w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
+            }
+            if (w > 0) atomicMax(&cov_out[a0 + mid_canon], (u32)w);
+        } else if (is_ref) {
+            if (MODE == 1) ++ref_rows;
+            else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+        } else if (MODE == 2) {
+            atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
+            gate_set(bf, idx);
+        }
+    }
+    if (MODE == 1) {
+        for (int dd = 32; dd; dd >>= 1) ref_rows += __shfl_xor(ref_rows, dd, 64);
+        if ((threadIdx.x & 63) == 0 && ref_rows) atomicAdd(cursor, (unsigned long long)ref_rows);
+    }
+    if (n_evaluated) {
+        for (int dd = 32; dd; dd >>= 1) evaluated += __shfl_xor(evaluated, dd, 64);
+        if ((threadIdx.x & 63) == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
+    }
+}
+
+// A/B and tests (use_flat_tier = 0): every general record is handed on to the workgroup kernel
+__global__ void __launch_bounds__(TPB) flag_all_kernel(const u32 *__restrict__ gen_list, const unsigned long long *__restrict__ gen_count, u8 *fb_flag, u32 *cov_out,
+                                                       const u32 *__restrict__ var_allele_off)
+{
+    const u64 n = *gen_count;
+    const u64 n_threads = (u64)gridDim.x * TPB;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += n_threads) {
+        const u32 g = gen_list[i];
+        fb_flag[g] = 1;
+        if (cov_out)
+            for (u32 a = var_allele_off[g]; a < var_allele_off[g + 1]; ++a) cov_out[a] = 0;
+    }
+}
+// the general records tier 2 handed on -> a list for the workgroup kernel
+__global__ void __launch_bounds__(TPB) fb_compact_kernel(const u32 *__restrict__ gen_list, const unsigned long long *__restrict__ gen_count, const u8 *__restrict__ fb_flag,
+                                                         u32 *fb_list, unsigned long long *fb_count)
+{
+    const u64 n = *gen_count;
+    const u64 n_threads = (u64)gridDim.x * TPB;
+    for (u64 base = (u64)blockIdx.x * TPB; base < n; base += n_threads) { // (whole waves stay together: list_append ballots)
+        const u64 i = base + threadIdx.x;
+        const u32 g = i < n ? gen_list[i] : 0;
+        list_append(i < n && fb_flag[g], g, fb_list, fb_count);
+    }
+}
+// coverages as set_variant_coverage leaves them (through a float, var_block.hpp:84); zero where the record goes to the host
+__global__ void __launch_bounds__(TPB) fw_finish_kernel(BlockBatch B, const u32 *__restrict__ gen_list, const unsigned long long *__restrict__ gen_count,
+                                                        const u8 *__restrict__ overflow, u32 *cov_out)
+{
+    const u64 n = *gen_count;
+    const u64 n_threads = (u64)gridDim.x * TPB;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += n_threads) {
+        const u32 g = gen_list[i];
+        const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
+        const bool host = overflow[g];
+        for (u32 a = 0; a < A; ++a) cov_out[a0 + a] = host ? 0 : (u32)(float)cov_out[a0 + a];
+    }
+}

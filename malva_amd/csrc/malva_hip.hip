@@ -36,6 +36,7 @@ constexpr int TPB = 256;
 #include "store_kernels.h"
 #include "scan_kernels.h"
 #include "variant_kernels.h"
+#include "block_pipeline.h"
 
 } // namespace
 
@@ -76,8 +77,12 @@ struct mg_ctx {
     BFState bf[2];
     MapState map;
     Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[11];
-    unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch
+    unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch,
+                                               // [2] signature k-mers of the lone records, [3] of the others (mg_blocks_stats)
+    hipEvent_t ev_b[4] = {nullptr, nullptr, nullptr, nullptr}; // mg_cover_blocks_device: before / after the preparation, the lone kernels, the enumerating kernel
+    bool blocks_stats_valid = false;
     int blocks_grid[3] = {0, 0, 0};            // persistent grid of cover_blocks_kernel<MODE> (found at first use)
+    int use_flat_tier = 1;                     // 0: every general record takes the workgroup kernel (A/B, tests)
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
     float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
@@ -513,6 +518,8 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipDeviceSynchronize();
     comm_drop(c);
     if (c->ev_x) hipEventDestroy(c->ev_x);
+    for (auto &e : c->ev_b)
+        if (e) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]);
         if (c->ev_free[i]) hipEventDestroy(c->ev_free[i]);
@@ -584,6 +591,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "blocks_set_limit")) c->blocks_set_limit = (u32)std::min<int64_t>(std::max<int64_t>(value, 0), BK_SET_CAP / 2);
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
+    else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
@@ -626,6 +634,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     if (!strcmp(name, "use_summary")) *value = c->use_summary;
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
     else if (!strcmp(name, "use_partition")) *value = c->use_partition;
+    else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
     else if (!strcmp(name, "gate_log2")) *value = c->gate_log2;
     else if (!strcmp(name, "gate_k")) *value = c->gate_k;
     else if (!strcmp(name, "pregate_log2")) *value = c->pregate_log2;
@@ -1831,63 +1840,100 @@ PanelView panel_view(const mg_panel_dev *p)
     P.allele_off = p->allele_off; P.canon = p->canon; P.gt = p->gt; P.n_samples = p->n_samples;
     return P;
 }
-// everything the enumerating kernels need beyond the panel itself, derived on the device: blocks' sequences and walk
-// bounds, the lone-and-short records' inputs for the fused kernels, the list of the others
-struct BlocksWork {
+// The tiers of block_pipeline.h over one resident panel.  Counts stay on the device; c->d_gen_count holds
+//   [0] general records listed by tier 1   [1] insertion-row cursor (index time) / block count of a host-form batch
+//   [2] signature k-mers of the lone records   [3] signature k-mers tiers 2 and 3 assembled   [4] records tier 3 took
+struct BlocksRun {
+    mg_ctx *c;
+    const mg_panel_dev *p;
     BlockBatch B;
-    const u32 *gen_list;
-    unsigned long long *gen_count;
-    const u64 *iso_pos, *iso_pm;
-    const u8 *iso_flags;
+    PanelView P;
+    u32 *gen_list, *fb_list;
+    u8 *fb_flag;
+    CombDesc *combs;
+    PickItem *items;
+    unsigned long long *round_counters;
+    u64 round, n_rounds;
+    int cus;
 };
-int blocks_prepare(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, const u32 *d_var_block, const unsigned long long *d_n_blocks, int haploid,
-                   BlocksWork *out)
+int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, const u32 *d_var_block, const unsigned long long *d_n_blocks, int haploid, BlocksRun *out)
 {
     const u64 n = p->n_vars;
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
-    void *q[10];
-    TRY(scratch(c, c->s_blk[0], 8 * n, &q[0]));  // blk_ref_base
-    TRY(scratch(c, c->s_blk[1], 4 * n, &q[1]));  // blk_ref_len
-    TRY(scratch(c, c->s_blk[2], 4 * n, &q[2]));  // blk_max_gain
-    TRY(scratch(c, c->s_blk[3], n, &q[3]));      // blk_unsorted
-    TRY(scratch(c, c->s_blk[4], 8 * n, &q[4]));  // iso_pos
-    TRY(scratch(c, c->s_blk[5], 8 * n, &q[5]));  // iso_pm
-    TRY(scratch(c, c->s_blk[6], n, &q[6]));      // iso_flags
-    TRY(scratch(c, c->s_blk[7], 4 * n, &q[7]));  // gen_list
+    BlocksRun R{};
+    R.c = c;
+    R.p = p;
+    R.round = std::min<u64>(n, 1ULL << 22);
+    R.n_rounds = (n + R.round - 1) / R.round;
+    void *q[8];
+    TRY(scratch(c, c->s_blk[0], 4 * n, &q[0]));                                                   // gen_list
+    TRY(scratch(c, c->s_blk[1], 4 * n, &q[1]));                                                   // fb_list
+    TRY(scratch(c, c->s_blk[2], n, &q[2]));                                                       // fb_flag
+    TRY(scratch(c, c->s_blk[3], sizeof(CombDesc) * (R.round * FW_COMBS_PER_REC + 64), &q[3]));    // one round's descriptors
+    TRY(scratch(c, c->s_blk[4], sizeof(PickItem) * (R.round * FW_ITEMS_PER_REC + 64), &q[4]));    // one round's items
+    TRY(scratch(c, c->s_blk[5], 16 * R.n_rounds, &q[5]));                                         // per round: descriptors, items reserved
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
-        TRY(scratch(c, c->s_blk[8], 4 * n, &q[8]));
+        TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
         TRY(scratch(c, c->s_blk[9], n, &fl));
         TRY(scratch(c, c->s_blk[10], 4 * (u64)nblocks(n) + 4, &ts));
         HIP_TRY(c, hipMemsetAsync(fl, 0, n, c->stream));
         hipLaunchKernelGGL(block_heads_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, d_blk_var_off, d_n_blocks, n, (u8 *)fl);
         hipLaunchKernelGGL(flag_count_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, n, (const u8 *)fl, (u32 *)ts);
-        TRY(scan_flags(c, n, (const u8 *)fl, (u32 *)ts, nullptr, (u32 *)q[8], nullptr));
-        d_var_block = (const u32 *)q[8];
+        TRY(scan_flags(c, n, (const u8 *)fl, (u32 *)ts, nullptr, (u32 *)q[6], nullptr));
+        d_var_block = (const u32 *)q[6];
     }
-    HIP_TRY(c, hipMemsetAsync(q[2], 0, 4 * n, c->stream));
-    HIP_TRY(c, hipMemsetAsync(q[3], 0, n, c->stream));
-    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
-    unsigned long long *gen_count = c->d_gen_count;
-    HIP_TRY(c, hipMemsetAsync(gen_count, 0, 8, c->stream));
-    hipLaunchKernelGGL(blocks_meta_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, panel_view(p), n, d_blk_var_off, d_var_block, (int)c->k, haploid, (u64 *)q[0],
-                       (u32 *)q[1], (u32 *)q[2], (u8 *)q[3], (u64 *)q[4], (u64 *)q[5], (u8 *)q[6], (u32 *)q[7], gen_count);
-    HIP_TRY(c, hipGetLastError());
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 64));
     BlockBatch B{};
     B.reference = c->d_ref;
-    B.blk_ref_base = (const u64 *)q[0]; B.blk_ref_len = (const u32 *)q[1]; B.blk_var_off = d_blk_var_off; B.var_block = d_var_block;
+    B.contig_base = p->contig_base; B.contig_len = p->contig_len; B.contig_id = p->contig_id;
+    B.blk_var_off = d_blk_var_off; B.var_block = d_var_block;
     B.pos = p->pos; B.ref_size = p->ref_size; B.min_size = p->min_size; B.present = p->present; B.var_allele_off = p->var_allele_off;
     B.allele_off = p->allele_off; B.pool = (const u8 *)p->pool; B.canon = p->canon; B.gt = p->gt;
-    B.blk_unsorted = (const u8 *)q[3]; B.blk_max_gain = (const u32 *)q[2];
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
-    out->B = B;
-    out->gen_list = (const u32 *)q[7];
-    out->gen_count = gen_count;
-    out->iso_pos = (const u64 *)q[4]; out->iso_pm = (const u64 *)q[5]; out->iso_flags = (const u8 *)q[6];
+    R.B = B;
+    R.P = panel_view(p);
+    R.gen_list = (u32 *)q[0]; R.fb_list = (u32 *)q[1]; R.fb_flag = (u8 *)q[2];
+    R.combs = (CombDesc *)q[3]; R.items = (PickItem *)q[4]; R.round_counters = (unsigned long long *)q[5];
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&R.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) R.cus = 256;
+    *out = R;
     return MG_OK;
 }
-// persistent grid of the enumerating kernel: as many workgroups as are resident together
+// tier 2 over the whole general list, round by round
+template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, unsigned long long *d_cursor, u32 row0, unsigned long long *d_evaluated)
+{
+    mg_ctx *c = R.c;
+    if (c->use_flat_tier == 0) { // A/B and tests: everything general goes to the workgroup kernel
+        hipLaunchKernelGGL(flag_all_kernel, dim3(R.cus * 8), dim3(TPB), 0, c->stream, (const u32 *)R.gen_list, (const unsigned long long *)c->d_gen_count, R.fb_flag,
+                           MODE == 0 ? d_cov : (u32 *)nullptr, R.B.var_allele_off);
+        HIP_TRY(c, hipGetLastError());
+        return MG_OK;
+    }
+    HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 16 * R.n_rounds, c->stream));
+    for (u64 r = 0; r < R.n_rounds; ++r) {
+        FlatWork W{};
+        W.gen_list = R.gen_list;
+        W.gen_count = c->d_gen_count;
+        W.base = r * R.round;
+        W.round_len = R.round;
+        W.combs = R.combs;
+        W.comb_cap = (u32)(R.round * FW_COMBS_PER_REC);
+        W.items = R.items;
+        W.item_cap = (u32)(R.round * FW_ITEMS_PER_REC);
+        W.counters = R.round_counters + 2 * r;
+        W.fb_flag = R.fb_flag;
+        hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
+        hipLaunchKernelGGL(fw_picks_kernel, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W);
+        hipLaunchKernelGGL(fw_eval_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
+                           d_evaluated);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return MG_OK;
+}
+// persistent grid of the workgroup kernel: as many workgroups as are resident together
 template <int MODE> unsigned blocks_grid(mg_ctx *c)
 {
     int &g = c->blocks_grid[MODE];
@@ -1899,6 +1945,21 @@ template <int MODE> unsigned blocks_grid(mg_ctx *c)
         g = cus * per_cu;
     }
     return (unsigned)g;
+}
+// tier 3: what tier 2 handed on, compacted, through the workgroup kernel
+template <int MODE> int blocks_tier3(BlocksRun &R, bool compact, u32 *d_cov, u8 *d_overflow, unsigned long long *d_cursor, u32 row0, unsigned long long *d_evaluated)
+{
+    mg_ctx *c = R.c;
+    unsigned long long *fb_count = c->d_gen_count + 4;
+    if (compact) { // (the insert pass of `index` walks the counting pass's list)
+        HIP_TRY(c, hipMemsetAsync(fb_count, 0, 8, c->stream));
+        hipLaunchKernelGGL(fb_compact_kernel, dim3(R.cus * 8), dim3(TPB), 0, c->stream, (const u32 *)R.gen_list, (const unsigned long long *)c->d_gen_count,
+                           (const u8 *)R.fb_flag, R.fb_list, fb_count);
+    }
+    hipLaunchKernelGGL(cover_blocks_kernel<MODE>, dim3(blocks_grid<MODE>(c)), dim3(TPB), 0, c->stream, R.B, (const u32 *)R.fb_list, (const unsigned long long *)fb_count,
+                       view(c, MG_BF_ALT), view(c), d_cov, d_overflow, IndexEmit{nullptr, d_cursor, row0}, d_evaluated);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
 }
 } // namespace
 
@@ -1939,7 +2000,7 @@ MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const 
     TRY(upload(c, c->s_misc[2], min_size, 4 * n_vars, &d_ms));
     TRY(upload(c, c->s_misc[3], contig_id, 4 * n_vars, &d_cid));
     TRY(scratch(c, c->s_out, 4 * (n_vars + 1), &d_off));
-    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 64));
     mg_panel_dev p{};
     p.n_vars = n_vars;
     p.pos = (const int32_t *)d_pos; p.ref_size = (const uint32_t *)d_rs; p.min_size = (const uint32_t *)d_ms; p.contig_id = (const uint32_t *)d_cid;
@@ -1963,21 +2024,50 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     if (!d_blk_var_off || !d_n_blocks || !d_cov_out || !d_overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     if (!c->map.slots) TRY(map_reserve(c, 0));
-    BlocksWork W{};
-    TRY(blocks_prepare(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &W));
+    for (auto &e : c->ev_b)
+        if (!e) HIP_TRY(c, hipEventCreate(&e));
+    c->blocks_stats_valid = false;
+    HIP_TRY(c, hipEventRecord(c->ev_b[0], c->stream));
+    BlocksRun R{};
+    TRY(blocks_setup(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &R));
     const u64 n = p->n_vars;
     HIP_TRY(c, hipMemsetAsync(d_overflow_out, 0, n, c->stream));
-    // lone and short records: the fused kernels (records of the other class have their flag clear and get zeros, which
-    // the enumerating kernel then overwrites)
+    HIP_TRY(c, hipMemsetAsync(R.fb_flag, 0, n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_gen_count, 0, 64, c->stream));
+    // tier 1: lone and short records (classification fused in); everything else is listed
     u32 *need_slow = (u32 *)(c->d_hit_count + 3);
     if (++c->iso_call_no == 0) c->iso_call_no = 1;
-    hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
-                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no);
-    hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
-                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no);
-    hipLaunchKernelGGL(cover_blocks_kernel<0>, dim3(blocks_grid<0>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
-                       (u32 *)d_cov_out, (u8 *)d_overflow_out, IndexEmit{nullptr, nullptr, 0u});
+    hipLaunchKernelGGL(panel_lone_kernel<false>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
+                       (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
+    hipLaunchKernelGGL(panel_lone_kernel<true>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
+                       (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_b[1], c->stream));
+    TRY(blocks_tier2<0>(R, (u32 *)d_cov_out, (u8 *)d_overflow_out, nullptr, 0u, c->d_gen_count + 3));
+    HIP_TRY(c, hipEventRecord(c->ev_b[2], c->stream));
+    TRY(blocks_tier3<0>(R, true, (u32 *)d_cov_out, (u8 *)d_overflow_out, nullptr, 0u, c->d_gen_count + 3));
+    hipLaunchKernelGGL(fw_finish_kernel, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, (const u32 *)R.gen_list, (const unsigned long long *)c->d_gen_count,
+                       (const u8 *)d_overflow_out, (u32 *)d_cov_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_b[3], c->stream));
+    c->blocks_stats_valid = true;
+    return MG_OK;
+}
+
+// timing and counts of the most recent mg_cover_blocks_device (waits for it)
+MG_EXPORT int mg_blocks_stats(mg_ctx *c, float *ms_out, uint64_t *counts_out)
+{
+    const DeviceGuard on_device(c);
+    if (!c || !ms_out || !counts_out) return MG_ERR_ARG;
+    if (!c->blocks_stats_valid) return fail(c, MG_ERR_STATE, "no mg_cover_blocks_device yet");
+    HIP_TRY(c, hipEventSynchronize(c->ev_b[3]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(c, hipEventElapsedTime(&ms_out[i], c->ev_b[i], c->ev_b[i + 1]));
+    unsigned long long h[8];
+    HIP_TRY(c, hipMemcpy(h, c->d_gen_count, 64, hipMemcpyDeviceToHost));
+    counts_out[0] = h[0];
+    counts_out[1] = h[2];
+    counts_out[2] = h[3];
+    counts_out[3] = h[4];
     return MG_OK;
 }
 
@@ -2014,7 +2104,7 @@ int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, cons
     TRY(upload(c, c->s_open[0], pool, pool_len, &d[10]));
     TRY(upload(c, c->s_open[1], canon, na, &d[11]));
     TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
-    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 16));
+    if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 64));
     const unsigned long long nb = n_blocks;
     HIP_TRY(c, hipMemcpyAsync(c->d_gen_count + 1, &nb, 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream)); // (`nb` and `var_block` live on this frame)
@@ -2060,7 +2150,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
 }
 
 // index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for every block of a resident panel.  Synchronises
-// twice on eight bytes: the exact map is sized from the counting pass before the insert pass runs.
+// once on eight bytes: the exact map is sized from the counting pass before the insert pass runs.
 MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const void *d_blk_var_off, const void *d_var_block, const void *d_n_blocks, int haploid,
                                      void *d_overflow_out)
 {
@@ -2073,32 +2163,31 @@ MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     const u64 n = p->n_vars;
     if (c->map.rows_total + n >= 0xFFFFFFFFULL) return fail(c, MG_ERR_LIMIT, "exact map: more than 2^32-1 insertion rows");
     TRY(map_reserve(c, n)); // the lone records' REF keys take insertion rows rows_total + v; may grow and re-hash the table: before the kernels, never under one
-    BlocksWork W{};
-    TRY(blocks_prepare(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &W));
+    BlocksRun R{};
+    TRY(blocks_setup(c, p, (const u32 *)d_blk_var_off, (const u32 *)d_var_block, (const unsigned long long *)d_n_blocks, haploid, &R));
     c->gate_dirty = true;
-    // lone and short records (flag set by blocks_meta_kernel; the others' flag is clear: iso_index_kernel leaves them alone)
-    hipLaunchKernelGGL(iso_index_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, n, W.iso_pos, p->var_allele_off, p->allele_off,
-                       (const u8 *)p->pool, W.iso_pm, W.iso_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out);
+    HIP_TRY(c, hipMemsetAsync(d_overflow_out, 0, n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(R.fb_flag, 0, n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_gen_count, 0, 64, c->stream));
+    // tier 1: lone and short records are inserted at once; everything else is listed
+    hipLaunchKernelGGL(panel_lone_index_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref, (const u8 *)p->pool,
+                       (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count);
     HIP_TRY(c, hipGetLastError());
     c->map.rows_total += n;
     unsigned long long *d_cursor = c->d_gen_count + 1;
-    // pass 1: how many exact-map insertion rows the other records need, and which of them exceed a device capacity
-    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
-    hipLaunchKernelGGL(cover_blocks_kernel<1>, dim3(blocks_grid<1>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
-                       (u32 *)nullptr, (u8 *)d_overflow_out, IndexEmit{nullptr, d_cursor, 0u});
-    HIP_TRY(c, hipGetLastError());
+    // pass 1: how many exact-map insertion rows the other records need; which of them go to tier 3, which to the host
+    TRY(blocks_tier2<1>(R, nullptr, (u8 *)d_overflow_out, d_cursor, 0u, nullptr));
+    TRY(blocks_tier3<1>(R, true, nullptr, (u8 *)d_overflow_out, d_cursor, 0u, nullptr));
     unsigned long long rows = 0;
     HIP_TRY(c, hipMemcpyAsync(&rows, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (rows) {
-        TRY(map_reserve(c, rows)); // between the passes
-        // pass 2: insert.  Every REF k-mer takes the next insertion row of the batch (ids are then whatever order the
-        // device reached them in: the index FILE, which every GPU of a call loads alike, is what fixes the counter layout)
-        HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
-    }
-    hipLaunchKernelGGL(cover_blocks_kernel<2>, dim3(blocks_grid<2>(c)), dim3(TPB), 0, c->stream, W.B, W.gen_list, W.gen_count, view(c, MG_BF_ALT), view(c),
-                       (u32 *)nullptr, (u8 *)d_overflow_out, IndexEmit{nullptr, d_cursor, (u32)c->map.rows_total});
-    HIP_TRY(c, hipGetLastError());
+    if (rows) TRY(map_reserve(c, rows)); // between the passes
+    // pass 2: insert.  Every REF k-mer takes the next insertion row of the batch (ids are then whatever order the
+    // device reached them in: the index FILE, which every GPU of a call loads alike, is what fixes the counter layout).
+    // The records keep the tier pass 1 gave them (its flags stand), so the rows counted are the rows used.
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, 8, c->stream));
+    TRY(blocks_tier2<2>(R, nullptr, (u8 *)d_overflow_out, d_cursor, (u32)c->map.rows_total, nullptr));
+    TRY(blocks_tier3<2>(R, false, nullptr, (u8 *)d_overflow_out, d_cursor, (u32)c->map.rows_total, nullptr));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->map.rows_total += rows;
     return MG_OK;

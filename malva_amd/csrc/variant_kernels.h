@@ -130,22 +130,16 @@ __device__ __forceinline__ void span_pack(const SpanWords &s, int n, u64 *codes,
 //       (kept out of the first kernel because its generic XXH3 alone needs 190 VGPRs)
 //   iso_genotype_kernel: one thread per variant
 constexpr u32 ISO_SLOW = 0xFFFFFFFFu; // never a coverage: those are float-rounded counts below 2^31
+// one thread's share (alleles of parity `par`) of a lone variant: `site` = its offset in the uploaded reference,
+// pm = mask of the alleles some panel haplotype carries, live = eligible (var_block.hpp:104)
 template <bool SLOW>
-__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off,
-                                                        const u32 *allele_off, const u8 *pool, const u64 *present_mask,
-                                                        const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow,
-                                                        u32 call_no)
+__device__ __forceinline__ void iso_cover_body(const u8 *reference, u64 site_off, u32 a0, u32 A, bool live, u64 pm_in, u32 par, const u32 *allele_off,
+                                               const u8 *pool, int k, const BFView &bf, const MapView &map, u32 *cov_out, u32 *need_slow, u32 call_no)
 {
-    if (SLOW && *need_slow != call_no) return;
-    const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
-    const u64 v = t >> 1;
-    if (v >= n_vars) return;
-    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
     const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
     u32 *cov = cov_out + a0;
-    const bool live = flags[v] & 1;
-    const u64 pm = live ? present_mask[v] : 0;
-    const u8 *site = reference + pos[v];
+    const u64 pm = live ? pm_in : 0;
+    const u8 *site = reference + site_off;
     const int lmax = k / 2, rmax = (k + 1) / 2;
     const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
     // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
@@ -155,7 +149,7 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
         span_pack(ls, lmax, &lf, &lbad);
         span_pack(rs, rmax, &rf, &rbad);
     }
-    for (u32 a = (u32)(t & 1); a < A; a += 2) {
+    for (u32 a = par; a < A; a += 2) {
         if (SLOW) {
             if (cov[a] != ISO_SLOW) continue;
             const int alen = (int)(allele_off[a0 + a + 1] - allele_off[a0 + a]);
@@ -212,6 +206,20 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
         cov[a] = out;
     }
 }
+template <bool SLOW>
+__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off,
+                                                        const u32 *allele_off, const u8 *pool, const u64 *present_mask,
+                                                        const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow,
+                                                        u32 call_no)
+{
+    if (SLOW && *need_slow != call_no) return;
+    const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
+    const u64 v = t >> 1;
+    if (v >= n_vars) return;
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    const bool live = flags[v] & 1;
+    iso_cover_body<SLOW>(reference, pos[v], a0, A, live, live ? present_mask[v] : 0, (u32)(t & 1), allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
+}
 
 __global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32 *var_allele_off, const float *freq, GenoParams p,
                                                            const u32 *cov, i32 *gt1, i32 *gt2, i32 *gq, u8 *status, double *probs,
@@ -230,24 +238,15 @@ __global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32
 // signatures are assembled exactly as iso_cover_kernel's fast path assembles them.  A variant with a base outside ACGT
 // in its window or alleles, more than 64 alleles, or k outside 17..64 is only flagged (nothing of it is inserted): the
 // host enumerates it (extract_lone) and inserts through the batch calls.  Variant v's REF key takes insertion row row0 + v.
-__global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off, const u32 *allele_off,
-                                                        const u8 *pool, const u64 *present_mask, const u8 *flags, int k, BFView bf, MapView map, u32 row0,
-                                                        u8 *overflow)
+// returns false when nothing of the variant was inserted (the host enumerates it)
+__device__ __forceinline__ bool iso_index_body(const u8 *reference, u64 site_off, u32 a0, u32 A, u64 pm, const u32 *allele_off, const u8 *pool, int k,
+                                               const BFView &bf, const MapView &map, u32 my_row, u32 row0)
 {
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (v >= n_vars) return;
-    overflow[v] = 0;
-    if (!(flags[v] & 1)) return; // not present, or within k of a contig end: no k-mers (var_block.hpp:104)
-    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
-    const u64 pm = present_mask[v];
-    if (pm == 0) return;
+    if (pm == 0) return true;
     const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
-    const u8 *site = reference + pos[v];
+    const u8 *site = reference + site_off;
     const int lmax = k / 2, rmax = (k + 1) / 2;
-    if (k < 17 || k > MG_MAX_PACKED_K || A > 64 || k != (int)map.klen) {
-        overflow[v] = 1;
-        return;
-    }
+    if (k < 17 || k > MG_MAX_PACKED_K || A > 64 || k != (int)map.klen) return false;
     u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
     {
         const SpanWords ls = span_load(site - lmax, lmax), rs = span_load(site + ref_size, rmax);
@@ -286,22 +285,31 @@ __global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64
     };
     U128 key;
     for (u32 a = 0; a < A; ++a) // first: can every carried allele be done here?
-        if (((pm >> a) & 1) && !signature(a, &key)) {
-            overflow[v] = 1;
-            return;
-        }
+        if (((pm >> a) & 1) && !signature(a, &key)) return false;
     for (u32 a = 0; a < A; ++a) {
         if (!((pm >> a) & 1)) continue;
         signature(a, &key);
         const u64 h = xxh3_packed(key, k);
         if (a == 0)
-            map_insert_key(map, bf, key, h, row0 + (u32)v, row0);
+            map_insert_key(map, bf, key, h, my_row, row0);
         else {
             const u64 idx = mod_size(h, bf.mod);
             atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
             gate_set(bf, idx);
         }
     }
+    return true;
+}
+__global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off, const u32 *allele_off,
+                                                        const u8 *pool, const u64 *present_mask, const u8 *flags, int k, BFView bf, MapView map, u32 row0,
+                                                        u8 *overflow)
+{
+    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (v >= n_vars) return;
+    overflow[v] = 0;
+    if (!(flags[v] & 1)) return; // not present, or within k of a contig end: no k-mers (var_block.hpp:104)
+    const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
+    if (!iso_index_body(reference, pos[v], a0, A, present_mask[v], allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
 }
 
 // ---- general blocks on the device: chains, haplotype picks, signature assembly, lookup, coverage -----------
@@ -316,11 +324,11 @@ __global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64
 // `overflow` and its block is redone by the host enumerator + mg_lookup_cover / mg_*_insert, so results never depend on them.
 struct BlockBatch {
     const u8 *reference;      // concatenated contigs (mg_reference_upload)
-    const u64 *blk_ref_base;  // per block: offset of the contig the block is evaluated against
-    const u32 *blk_ref_len;   //            and its length
+    const u64 *contig_base;   // per sequence: its offset in `reference`
+    const u32 *contig_len;    //               and its length
+    const u32 *contig_id;     // [n_vars] sequence of each record; a block is evaluated against the sequence of its FIRST record
+                              // (`last_seq_name` at the flush, main.cpp:556)
     const u32 *blk_var_off;   // [n_blocks + 1]
-    const u8 *blk_unsorted;   // per block: some position decreases along the block (no sane VCF: the walks then run to the block's end)
-    const u32 *blk_max_gain;  //            max over its variants of ref_size - min_size
     const u32 *var_block;     // [n_vars] block of each variant
     const i32 *pos;           // 0-based position in the contig
     const u32 *ref_size, *min_size;
@@ -421,16 +429,7 @@ __global__ void __launch_bounds__(TPB) flag_scatter_kernel(u64 n, const u8 *__re
     }
 }
 
-// ---- a batch of blocks described on the device -----------------------------------------------------------------------
-// What prepare_blocks used to compute on the host, per record v of a batch whose blocks are already cut (blk_var_off,
-// var_block): the block's sequence (that of its first record: `last_seq_name` at the flush, main.cpp:556), the two
-// bounds of the chain walks, and the record's class:
-//   lone and short  a block of ONE variant whose alleles are all shorter than k, at most 64 of them, flanks inside the
-//                   sequence: the fused lone-variant kernels (iso_cover_kernel / iso_index_kernel) take it -- its offset
-//                   in the uploaded reference, the mask of the alleles some panel haplotype carries (build_alleles_combs
-//                   on a chain of one, var_block.hpp:734-786) and the eligibility flag (var_block.hpp:104) are written here;
-//   anything else   appended to `gen_list` for cover_blocks_kernel.
-// blk_max_gain and blk_unsorted must be zeroed before the launch.
+// a resident panel as the kernels see it (include/malva_hip.h: mg_panel_dev)
 struct PanelView {
     const u64 *contig_base;
     const u32 *contig_len, *contig_id;
@@ -442,64 +441,8 @@ struct PanelView {
     const uint16_t *gt;
     u32 n_samples;
 };
-__global__ void __launch_bounds__(TPB) blocks_meta_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block, int k, int haploid,
-                                                          u64 *__restrict__ blk_ref_base, u32 *__restrict__ blk_ref_len, u32 *blk_max_gain, u8 *blk_unsorted,
-                                                          u64 *__restrict__ iso_pos, u64 *__restrict__ iso_pm, u8 *__restrict__ iso_flags, u32 *__restrict__ gen_list,
-                                                          unsigned long long *gen_count)
-{
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
-    bool general = false;
-    if (v < n_vars) {
-        const u32 blk = var_block[v];
-        const u32 b0 = blk_var_off[blk], b1 = blk_var_off[blk + 1];
-        const u32 cid = P.contig_id[b0];
-        const u64 cbase = P.contig_base[cid];
-        const u32 clen = P.contig_len[cid];
-        if (v == b0) {
-            blk_ref_base[blk] = cbase;
-            blk_ref_len[blk] = clen;
-        }
-        const u32 rs = P.ref_size[v], ms = P.min_size[v];
-        const i32 p = P.pos[v];
-        if (b1 - b0 > 1) {
-            if (rs > ms) atomicMax(&blk_max_gain[blk], rs - ms);
-            if (v > b0 && p < P.pos[v - 1]) blk_unsorted[blk] = 1;
-        }
-        const u32 a0 = P.var_allele_off[v], A = P.var_allele_off[v + 1] - a0;
-        bool lone = b1 - b0 == 1 && A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
-        if (lone)
-            for (u32 a = 0; a < A; ++a) lone = lone && (int)(P.allele_off[a0 + a + 1] - P.allele_off[a0 + a]) < k;
-        if (lone) {
-            const bool eligible = P.present[v] && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
-            u64 mask = 0;
-            if (eligible)
-                for (u32 s = 0; s < P.n_samples; ++s) {
-                    const u32 g = P.gt[v * P.n_samples + s];
-                    mask |= 1ULL << P.canon[a0 + (g & 127)];
-                    if (!haploid) mask |= 1ULL << P.canon[a0 + ((g >> 7) & 127)];
-                }
-            iso_pos[v] = cbase + (u64)p;
-            iso_pm[v] = mask;
-            iso_flags[v] = eligible ? 1 : 0;
-        } else {
-            iso_pos[v] = cbase; // (never read: the flag is clear)
-            iso_pm[v] = 0;
-            iso_flags[v] = 0;
-            general = true;
-        }
-    }
-    // the general records' list: order is irrelevant (one workgroup per record, independent), one atomic per wave
-    const u64 m = __ballot(general);
-    if (m) {
-        const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(gen_count, (unsigned long long)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (general) gen_list[base + __popcll(m & ((1ULL << lane) - 1))] = (u32)v;
-    }
-}
 
-__device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, BkChains *out)
+__device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, bool sorted, int max_gain, BkChains *out)
 {
     const int k = B.k;
     auto ov = [&](int x, int y) { // overlapping(left, right) with (x, y) given in scan order
@@ -515,8 +458,7 @@ __device__ bool bk_chains(const BlockBatch &B, int b0, int b1, int i, int step, 
     // The reference walks to the end of the block whatever happens (var_block.hpp:436-525: O(B) per variant, O(B^2) per
     // block).  Nothing can join a chain once the walk is beyond the reach of every chain -- positions only move away and
     // a chain's reach grows only when something joins -- so with sorted positions the walk stops there: same chains.
-    const bool sorted = !B.blk_unsorted[B.var_block[i]];
-    const int max_gain = (int)B.blk_max_gain[B.var_block[i]];
+    // (`sorted`: positions never decrease along the block, `max_gain`: its largest ref_size - min_size -- the workgroup looks)
     for (int j = i + step; j >= b0 && j < b1 && !halt; j += step) {
         if (sorted) {
             int max_sum = 0;
@@ -658,14 +600,14 @@ template <int MODE> __device__ __forceinline__ bool bk_index_emit(const u8 *buf,
 // MODE 0: call time, coverage of every allele (set_coverages).  MODE 1 / 2: index time, see bk_index_emit; `overflow` then
 // carries MODE 1's verdict into MODE 2 (a variant flagged there is skipped here and left to the host).
 // The grid is persistent: workgroup w takes the records list[w], list[w + gridDim.x], ... of `list` (*list_n entries:
-// the records blocks_meta_kernel did not hand to the lone-variant kernels), so that neither the list's length nor the
-// launch of millions of workgroups needs the host.
+// the records the faster tiers handed on), so that neither the list's length nor the launch of millions of workgroups
+// needs the host.
 template <int MODE>
 __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u32 *__restrict__ list, const unsigned long long *__restrict__ list_n, BFView bf,
-                                                           MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit)
+                                                           MapView map, u32 *cov_out, u8 *overflow, IndexEmit emit, unsigned long long *n_evaluated)
 {
     __shared__ BkChains sh_left, sh_right;
-    __shared__ int sh_bad, sh_eligible;
+    __shared__ int sh_bad, sh_eligible, sh_unsorted, sh_max_gain;
     __shared__ u32 sh_cov[128];
     __shared__ u32 sh_slide[4]; // alleles (bit mask, 128 bits) that some sample carries alone and whole (len >= k)
     __shared__ u8 sh_buf[TPB][MG_MAX_PACKED_K];
@@ -673,6 +615,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
     __shared__ u32 sh_set_n;
     __shared__ u32 sh_emit;
     emit.sh_emit = &sh_emit;
+    u32 evaluated = 0; // signature k-mers this thread assembled and looked up (or inserted)
     const u64 n_list = *list_n;
     for (u64 item = blockIdx.x; item < n_list; item += gridDim.x) {
     __syncthreads(); // the previous record's shared state is done with
@@ -682,8 +625,9 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
     const u32 a0 = B.var_allele_off[g], A = B.var_allele_off[g + 1] - a0;
     const u32 blk = B.var_block[g];
     const int b0 = (int)B.blk_var_off[blk], b1 = (int)B.blk_var_off[blk + 1];
-    const u8 *ref = B.reference + B.blk_ref_base[blk];
-    const i32 ref_len = (i32)B.blk_ref_len[blk];
+    const u32 cid = B.contig_id[b0];
+    const u8 *ref = B.reference + B.contig_base[cid];
+    const i32 ref_len = (i32)B.contig_len[cid];
     const int k = B.k;
     for (u32 a = threadIdx.x; a < 128; a += TPB) sh_cov[a] = 0;
     if (threadIdx.x < 4) sh_slide[threadIdx.x] = 0;
@@ -691,11 +635,24 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
         sh_bad = (A > 127 || k > MG_MAX_PACKED_K) ? 1 : 0;
         sh_eligible = B.present[g] && B.pos[g] >= k && B.pos[g] <= ref_len - k; // var_block.hpp:104
         sh_left.n = sh_right.n = 0;
+        sh_unsorted = 0;
+        sh_max_gain = 0;
+    }
+    __syncthreads();
+    // what bounds the walks: is the block sorted, and its largest ref_size - min_size (all threads look)
+    if (sh_eligible && !sh_bad) {
+        int mg_ = 0, un = 0;
+        for (int j = b0 + (int)threadIdx.x; j < b1; j += TPB) {
+            if (B.ref_size[j] > B.min_size[j]) mg_ = max(mg_, (int)(B.ref_size[j] - B.min_size[j]));
+            if (j > b0 && B.pos[j] < B.pos[j - 1]) un = 1;
+        }
+        if (mg_) atomicMax(&sh_max_gain, mg_);
+        if (un) sh_unsorted = 1;
     }
     __syncthreads();
     // the two walks (get_combs_on_the_left / _right) are independent: one lane of wave 0 and one of wave 1 take one each
     if (sh_eligible && !sh_bad && (threadIdx.x == 0 || threadIdx.x == 64))
-        if (!bk_chains(B, b0, b1, g, threadIdx.x == 0 ? -1 : +1, threadIdx.x == 0 ? &sh_left : &sh_right)) atomicOr(&sh_bad, 1);
+        if (!bk_chains(B, b0, b1, g, threadIdx.x == 0 ? -1 : +1, !sh_unsorted, sh_max_gain, threadIdx.x == 0 ? &sh_left : &sh_right)) atomicOr(&sh_bad, 1);
     __syncthreads();
     if (sh_bad) {
         if (threadIdx.x == 0) overflow[g] = 1;
@@ -769,6 +726,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
                 }
             }
             for (int x = max(0, len_v + mp); x < k; ++x) buf[x] = ref[last_end + (x - mp - len_v)];
+            ++evaluated;
             if (MODE == 0) {
                 const i32 w = bk_weight(buf, k, mid_canon == 0, bf, map);
                 if (w > 0) atomicMax(&sh_cov[mid_canon], (u32)w);
@@ -863,6 +821,7 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
         i32 n = 0;
         for (int p = 0; p + k <= al; ++p) {
             for (int x = 0; x < k; ++x) buf[x] = ap[p + x];
+            ++evaluated;
             if (MODE != 0) {
                 if (!bk_index_emit<MODE>(buf, k, a == 0, bf, map, emit)) sh_bad = 1;
                 continue;
@@ -881,5 +840,9 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
     if (MODE == 0)
         for (u32 a = threadIdx.x; a < A; a += TPB) cov_out[a0 + a] = sh_bad ? 0 : (u32)(float)sh_cov[a];
     } // next record of the list
+    if (n_evaluated) {
+        for (int d = 32; d; d >>= 1) evaluated += __shfl_xor(evaluated, d, 64);
+        if ((threadIdx.x & 63) == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
+    }
 }
 

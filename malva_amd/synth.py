@@ -374,11 +374,35 @@ class FlatPanel:
 
     def head(self, n):
         """the first n records as a panel of their own (same genome)"""
-        na = int(self.var_allele_off[n])
+        return self.slice(0, n)
+
+    def slice(self, a, b):
+        """records [a, b) as a panel of their own (same genome and sequences)"""
+        s0, s1 = int(self.var_allele_off[a]), int(self.var_allele_off[b])
+        p0, p1 = int(self.allele_off[s0]), int(self.allele_off[s1])
         return FlatPanel(genome=self.genome, contig_names=self.contig_names, contig_base=self.contig_base, contig_len=self.contig_len,
-                         contig_id=self.contig_id[:n], pos=self.pos[:n], ref_size=self.ref_size[:n], min_size=self.min_size[:n], present=self.present[:n],
-                         var_allele_off=self.var_allele_off[:n + 1], allele_off=self.allele_off[:na + 1], pool=self.pool[:int(self.allele_off[na])],
-                         canon=self.canon[:na], freq=self.freq[:na], gt=self.gt[:n], n_samples=self.n_samples, donor_gt=self.donor_gt[:n])
+                         contig_id=self.contig_id[a:b], pos=self.pos[a:b], ref_size=self.ref_size[a:b], min_size=self.min_size[a:b], present=self.present[a:b],
+                         var_allele_off=(self.var_allele_off[a:b + 1] - self.var_allele_off[a]).astype(np.uint32),
+                         allele_off=(self.allele_off[s0:s1 + 1] - self.allele_off[s0]).astype(np.uint32), pool=self.pool[p0:p1],
+                         canon=self.canon[s0:s1], freq=self.freq[s0:s1], gt=self.gt[a:b], n_samples=self.n_samples, donor_gt=self.donor_gt[a:b])
+
+    def split_points(self, parts, min_gap=64):
+        """record indices 0 = c_0 <= c_1 <= ... <= c_parts = n that cut the panel into `parts` nearly equal runs WITHOUT cutting a
+        block: every cut sits where the next record is on another sequence or more than `min_gap` nt behind the previous one
+        (beyond are_near's reach for any k <= 64, float rounding included)"""
+        n = self.n
+        ok = np.ones(n + 1, dtype=bool)
+        if n > 1:
+            far = (np.diff(self.pos.astype(np.int64)) > min_gap + self.ref_size[:-1].astype(np.int64)) | (np.diff(self.contig_id.astype(np.int64)) != 0)
+            ok[1:n] = far
+        cand = np.nonzero(ok)[0]
+        cuts = [0]
+        for r in range(1, parts):
+            want = n * r // parts
+            j = int(np.searchsorted(cand, want))
+            cuts.append(int(cand[min(j, cand.size - 1)]))
+        cuts.append(n)
+        return cuts
 
 
 def _canon_of(var_allele_off, allele_off, pool):
@@ -688,3 +712,87 @@ def write_vcf_fasta(panel: FlatPanel, prefix, freq_key="AF"):
             af = ",".join(repr(float(np.float32(f))) for f in panel.freq[a0 + 1:a1])
             fh.write("%s\t%d\t.\t%s\t%s\t.\t.\t%s=%s\tGT\t%s\n" % (panel.contig_names[int(panel.contig_id[v])], int(panel.pos[v]) + 1, alleles[0],
                                                                ",".join(alleles[1:]), freq_key, af, "\t".join(gts)))
+
+
+def device_table_flat(panel: FlatPanel, n_rows, k, ref_k, seed, device, plant_records=None, offsets=(-2, -1, 0, 1, 2), chunk=2_000_000):
+    """kmer table for a FlatPanel drawn ON THE GPU (torch: random bits, gathers and a scatter): uniform random ref_k-mers with
+    the donor's windows around the first `plant_records` records planted at distinct random places.  SNP-only panels
+    (clustered_snp_panel) get their windows from the two donor haplotypes held on the device -- centred windows at `offsets`
+    around every record, neighbours' donor alleles included; panels with indels take donor_rows() on the host.  Rows are
+    not canonicalised (the scan does that).  -> dict: d_hi, d_lo (int64 bit patterns), d_cnt (int32), n, n_site"""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_plant = panel.n if plant_records is None else min(panel.n, int(plant_records))
+
+    def bits32(n):
+        return torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device=dev, generator=g)
+    top = 2 * ref_k - 64
+    d_lo = (bits32(n_rows) << 32) | bits32(n_rows)
+    if top >= 64:
+        d_hi = (bits32(n_rows) << 32) | bits32(n_rows)
+    elif top > 0:
+        d_hi = ((bits32(n_rows) << 32) | bits32(n_rows)) & ((1 << top) - 1)
+    else:
+        d_hi = torch.zeros(n_rows, dtype=torch.int64, device=dev)
+        if top < 0:
+            d_lo = d_lo & ((1 << (2 * ref_k)) - 1)
+    d_cnt = torch.randint(2, 64, (n_rows,), dtype=torch.int32, device=dev, generator=g)
+    snp_only = bool((panel.ref_size[:n_plant] == 1).all()) and bool((np.diff(panel.allele_off[:int(panel.var_allele_off[n_plant]) + 1].astype(np.int64)) == 1).all())
+    his, los = [], []
+    if n_plant and snp_only:
+        code_t = torch.from_numpy(CODE.astype(np.int64)).to(dev)
+        gpos = panel.gpos()[:n_plant]
+        centre = (ref_k - k) // 2 + k // 2
+        genome_t = torch.from_numpy(panel.genome).to(dev)
+        cb = panel.contig_base[panel.contig_id[:n_plant]].astype(np.int64)
+        ce = cb + panel.contig_len[panel.contig_id[:n_plant]].astype(np.int64)
+        for h in range(2):
+            hap = genome_t.clone()
+            slot = panel.var_allele_off[:n_plant].astype(np.int64) + panel.donor_gt[:n_plant, h].astype(np.int64)
+            hap[torch.from_numpy(gpos).to(dev)] = torch.from_numpy(panel.pool[panel.allele_off[slot]]).to(dev)
+            for d in offsets:
+                start = gpos - centre + d
+                keep = (start >= cb) & (start + ref_k <= ce)
+                if h == 1:           # a homozygous donor's window is listed once (KMC lists distinct k-mers)... unless a neighbour differs
+                    keep &= True
+                st = torch.from_numpy(start[keep]).to(dev)
+                for a in range(0, st.numel(), chunk):
+                    s_ = st[a:a + chunk]
+                    w = code_t[hap[s_[:, None] + torch.arange(ref_k, device=dev)[None, :]].to(torch.int64)]     # [m, ref_k] codes 0..3 (255: non-ACGT)
+                    good = (w <= 3).all(dim=1)
+                    w = w[good]
+                    hi = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
+                    lo = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
+                    for i in range(ref_k):
+                        sh = 2 * (ref_k - 1 - i)
+                        if sh >= 64:
+                            hi |= w[:, i] << (sh - 64)
+                        else:
+                            lo |= w[:, i] << sh
+                    his.append(hi); los.append(lo)
+            del hap
+        del genome_t
+        hi_t, lo_t = torch.cat(his), torch.cat(los)
+        pair = torch.unique(torch.stack([hi_t, lo_t], dim=1), dim=0)          # distinct ref_k-mers, as KMC lists them
+        hi_t, lo_t = pair[:, 0].contiguous(), pair[:, 1].contiguous()
+    elif n_plant:
+        hi, lo = donor_rows(panel, ref_k, n_plant)
+        hi_t, lo_t = torch.from_numpy(hi.view(np.int64)).to(dev), torch.from_numpy(lo.view(np.int64)).to(dev)
+    else:
+        hi_t = lo_t = torch.zeros(0, dtype=torch.int64, device=dev)
+    n_site = int(hi_t.numel())
+    if n_site > n_rows:
+        sel = torch.randperm(n_site, device=dev, generator=g)[:n_rows]
+        hi_t, lo_t, n_site = hi_t[sel], lo_t[sel], n_rows
+    if n_site:
+        stride = n_rows // n_site
+        where = torch.arange(n_site, dtype=torch.int64, device=dev) * stride
+        if stride > 1:
+            where += torch.randint(0, stride, (n_site,), dtype=torch.int64, device=dev, generator=g)
+        where = where[torch.randperm(n_site, device=dev, generator=g)] if n_site < (1 << 31) else where
+        d_hi[where] = hi_t
+        d_lo[where] = lo_t
+    torch.cuda.synchronize()
+    return {"d_hi": d_hi, "d_lo": d_lo, "d_cnt": d_cnt, "n": n_rows, "n_site": n_site}

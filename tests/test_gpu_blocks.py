@@ -14,27 +14,31 @@ from oracle.model import VCFReader, flatten_vk, read_fasta
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("seed,haploid,k,ref_k", [(31, False, 35, 43), (32, True, 35, 43), (33, False, 31, 41), (34, False, 21, 29),
                                                   (35, True, 63, 64), (36, False, 35, 63)])
-def test_device_enumeration_matches_oracle(tmp_path, seed, haploid, k, ref_k):
-    _run_case(tmp_path, seed, haploid, k, ref_k, dense=False)
+def test_device_enumeration_matches_oracle(tmp_path, seed, haploid, k, ref_k, flat):
+    """flat = 1: the tiers as the library deals the records out (csrc/block_pipeline.h); flat = 0: every general record
+    through the workgroup-per-record kernel"""
+    _run_case(tmp_path, seed, haploid, k, ref_k, dense=False, flat=flat)
 
 
+@pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("seed,haploid", [(41, False), (42, True), (43, False)])
-def test_dense_clusters_hit_the_device_capacities(tmp_path, seed, haploid):
+def test_dense_clusters_hit_the_device_capacities(tmp_path, seed, haploid, flat):
     """6-15 variants inside 22 bp with overlapping deletions: long chains, many chains per side, long unphased runs.
     Whatever the device does not hand back must still equal the oracle, and it must hand back only a minority."""
-    _run_case(tmp_path, seed, haploid, 35, 43, dense=True)
+    _run_case(tmp_path, seed, haploid, 35, 43, dense=True, flat=flat)
 
 
 @pytest.mark.parametrize("seed,haploid,dense,limit", [(51, False, False, 0), (52, True, False, 1), (53, False, True, 2)])
 def test_direct_evaluation_when_the_pick_set_overflows(tmp_path, seed, haploid, dense, limit):
     """the kernel keeps a chain's distinct haplotype picks in an LDS set and evaluates each once; with the set limited
     to 0..2 picks nearly every chain overflows it and every sample's pick is evaluated directly: same coverages"""
-    _run_case(tmp_path, seed, haploid, 35, 43, dense=dense, set_limit=limit)
+    _run_case(tmp_path, seed, haploid, 35, 43, dense=dense, set_limit=limit, flat=0)
 
 
-def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
+def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None, flat=1):
     prefix = str(tmp_path / "case")
     contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=40 if dense else 120, vcf_strip_chr=True,
                                            dense=dense, n_samples=4 if dense else 5)
@@ -48,6 +52,7 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None):
     refs = read_fasta(fa, True)
     # the same index and counters on the device, through the ASCII batch calls
     ctx = Context(k, ref_k, opt.bf_size)
+    ctx.set_option("use_flat_tier", flat)
     if set_limit is not None:
         ctx.set_option("blocks_set_limit", set_limit)
     bits = idx.bf.set_positions()
@@ -215,9 +220,10 @@ def test_blocks_cut_on_the_device(k):
         assert np.array_equal(ctx.cut_blocks(pos[:1025], ref_size[:1025], min_size[:1025], contig[:1025]), np.array([w for w in want if w < 1025] + [1025], dtype=np.uint32))
 
 
+@pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("seed,haploid,k,ref_k,dense", [(61, False, 35, 43, False), (62, True, 35, 43, False), (63, False, 31, 41, False),
                                                         (64, False, 35, 63, False), (65, False, 35, 43, True), (66, True, 35, 43, True)])
-def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k, dense):
+def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k, dense, flat):
     """mg_index_blocks: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) on the device.  The blocks `index`
     keeps (present variants only) go through it; what it hands back (overflow) is enumerated by the oracle's model and
     inserted through the batch calls, exactly as the CLI does with its host enumerator.  The resulting `bf` bits and
@@ -234,6 +240,7 @@ def test_index_time_enumeration_on_the_device(tmp_path, seed, haploid, k, ref_k,
     for n in names:
         base[n] = off; off += len(refs[n])
     with Context(k, ref_k, opt.bf_size) as ctx:
+        ctx.set_option("use_flat_tier", flat)
         ctx.reference_upload("".join(refs[n] for n in names).encode())
         blocks = []
         for vb, reference, used in pipeline._blocks(VCFReader(vcf, "-"), opt, refs, True):       # for_index: main.cpp:332
