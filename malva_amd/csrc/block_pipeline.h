@@ -108,36 +108,63 @@ __device__ __forceinline__ void list_append(bool take, u32 value, u32 *list, uns
     base = __shfl(base, leader, 64);
     if (take) list[base + __popcll(m & ((1ULL << lane) - 1))] = value;
 }
+constexpr int LONE_TILES = 8; // tiles of TPB / 2 records a workgroup of panel_lone_kernel takes (one list reservation per workgroup:
+                              // a returning atomic per wave on ONE counter serialises at ~10 ns each -- 3 ms per 5e6 records)
 template <bool SLOW>
 __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                          const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 *cov_out,
                                                          u32 *need_slow, u32 call_no, u32 *gen_list, unsigned long long *counters)
 {
+    __shared__ u32 sh_gen[LONE_TILES * TPB / 2];
+    __shared__ u32 sh_n, sh_sigs;
+    __shared__ unsigned long long sh_base;
     if (SLOW && *need_slow != call_no) return;
-    const u64 t = (u64)blockIdx.x * TPB + threadIdx.x;
-    const u64 v = t >> 1;
-    const bool in = v < n_vars;
-    LoneClass c{};
-    if (in) c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
-    if (!SLOW) {
-        list_append(in && !c.lone && !(t & 1), (u32)v, gen_list, counters);
-        u32 sigs = in && c.lone && !(t & 1) ? (u32)__popcll(c.mask) : 0;
-        for (int d = 32; d; d >>= 1) sigs += __shfl_xor(sigs, d, 64);
-        if ((threadIdx.x & 63) == 0 && sigs) atomicAdd(counters + 2, (unsigned long long)sigs);
+    if (threadIdx.x == 0) sh_n = sh_sigs = 0;
+    __syncthreads();
+    u32 sigs = 0;
+    for (int tile = 0; tile < LONE_TILES; ++tile) {
+        const u64 t = ((u64)blockIdx.x * LONE_TILES + tile) * TPB + threadIdx.x;
+        const u64 v = t >> 1;
+        if (v >= n_vars) break;
+        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+        if (!SLOW && !(t & 1)) {
+            if (!c.lone) sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
+            else sigs += (u32)__popcll(c.mask);
+        }
+        if (c.lone) iso_cover_body<SLOW>(reference, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
     }
-    if (in && c.lone) iso_cover_body<SLOW>(reference, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
+    if (SLOW) return;
+    for (int d = 32; d; d >>= 1) sigs += __shfl_xor(sigs, d, 64);
+    if ((threadIdx.x & 63) == 0 && sigs) atomicAdd(&sh_sigs, sigs);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sh_base = sh_n ? atomicAdd(counters, (unsigned long long)sh_n) : 0ULL;
+        if (sh_sigs) atomicAdd(counters + 2, (unsigned long long)sh_sigs);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < sh_n; i += TPB) gen_list[sh_base + i] = sh_gen[i];
 }
 // index time: lone records are inserted here (REF key of record v takes insertion row row0 + v), the others listed
 __global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                                const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 row0,
                                                                u8 *overflow, u32 *gen_list, unsigned long long *counters)
 {
-    const u64 v = (u64)blockIdx.x * TPB + threadIdx.x;
-    const bool in = v < n_vars;
-    LoneClass c{};
-    if (in) c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
-    list_append(in && !c.lone, (u32)v, gen_list, counters);
-    if (in && c.lone && c.eligible && !iso_index_body(reference, c.site, c.a0, c.A, c.mask, P.allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
+    __shared__ u32 sh_gen[LONE_TILES * TPB];
+    __shared__ u32 sh_n;
+    __shared__ unsigned long long sh_base;
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    for (int tile = 0; tile < LONE_TILES; ++tile) {
+        const u64 v = ((u64)blockIdx.x * LONE_TILES + tile) * TPB + threadIdx.x;
+        if (v >= n_vars) break;
+        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+        if (!c.lone) sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
+        else if (c.eligible && !iso_index_body(reference, c.site, c.a0, c.A, c.mask, P.allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_base = sh_n ? atomicAdd(counters, (unsigned long long)sh_n) : 0ULL;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < sh_n; i += TPB) gen_list[sh_base + i] = sh_gen[i];
 }
 
 // ---- tier 2 ------------------------------------------------------------------------------------------------------------------
@@ -149,7 +176,9 @@ struct FlatWork {
     u32 comb_cap;
     PickItem *items;
     u32 item_cap;
-    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved
+    PickItem *slides; // items of the sliding kind (a lone allele of k bases or more): a wave each, fw_slide_kernel
+    u32 slide_cap;
+    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved, [2] sliding items
     u8 *fb_flag;                  // [n_vars] the record goes to the workgroup kernel
 };
 
@@ -251,22 +280,30 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
             else W.fb_flag[g] = 1;
         }
     }
-    // room for the wave's descriptors: one atomic
-    const int lane = threadIdx.x & 63;
+    // room for the workgroup's descriptors: one atomic (lanes scan inside the wave, waves through LDS)
+    __shared__ u32 sh_tot[TPB / 64];
+    __shared__ unsigned long long sh_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 incl = n_combs;
     for (int d = 1; d < 64; d <<= 1) {
         const u32 up = __shfl_up(incl, d, 64);
         if (lane >= d) incl += up;
     }
-    const u32 total = __shfl(incl, 63, 64);
+    if (lane == 63) sh_tot[wave] = incl;
+    __syncthreads();
+    u32 before = 0, total = 0;
+    for (int w = 0; w < TPB / 64; ++w) {
+        if (w < wave) before += sh_tot[w];
+        total += sh_tot[w];
+    }
     if (!total) return;
-    unsigned long long base = 0;
-    if (lane == 63) base = atomicAdd(&W.counters[0], (unsigned long long)total);
-    base = __shfl(base, 63, 64);
-    if (base + total > W.comb_cap) { // (an average of FW_COMBS_PER_REC per record of the round was not enough)
+    if (threadIdx.x == 0) sh_base = atomicAdd(&W.counters[0], (unsigned long long)total);
+    __syncthreads();
+    const unsigned long long base = sh_base + before;
+    if (sh_base + total > W.comb_cap) { // (an average of FW_COMBS_PER_REC per record of the round was not enough)
         if (n_combs) W.fb_flag[g] = 1;
         CombDesc none{};                   // what of the reservation lies inside the buffer must not be read as descriptors
-        for (u64 q = base + lane; q < W.comb_cap && q < base + total; q += 64) W.combs[q] = none;
+        for (u64 q = sh_base + threadIdx.x; q < W.comb_cap && q < sh_base + total; q += TPB) W.combs[q] = none;
         return;
     }
     if (!n_combs) return;
@@ -289,6 +326,8 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
 
 // build_alleles_combs + combine_haplotypes (var_block.hpp:709-786) for one chain: the distinct picks of all panel samples
 constexpr int FW_WAVES = TPB / 64;
+constexpr unsigned long long FW_SLIDE = 1ULL << 62; // item code tag: the chain is the variant alone and the allele has k bases or more
+constexpr u32 FW_CHUNK = 512; // items a wave reserves at a time (one returning atomic per chain on ONE counter: 7 ms per 7e5 chains)
 __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
 {
     __shared__ unsigned long long sh_set[FW_WAVES][FW_SET]; // code + 1, 0 = free
@@ -303,6 +342,8 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
     wave_sync();
     const u64 n_combs = min((unsigned long long)W.comb_cap, W.counters[0]);
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    unsigned long long chunk_at = 0; // next free item of the wave's chunk
+    u32 chunk_left = 0;
     for (u64 ci = (u64)blockIdx.x * FW_WAVES + wave; ci < n_combs; ci += n_waves) {
         const CombDesc d = W.combs[ci];
         const int m = d.m;
@@ -348,16 +389,14 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
                     c1 |= (unsigned long long)(gt & 127) << sh_shift[wave][j];
                     c2 |= (unsigned long long)((gt >> 7) & 127) << sh_shift[wave][j];
                 }
-                if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): the workgroup kernel's
+                if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): its own kind of item
                     const u32 a0 = B.var_allele_off[g];
                     const u32 l1 = B.allele_off[a0 + (u32)c1 + 1] - B.allele_off[a0 + (u32)c1], l2 = B.allele_off[a0 + (u32)c2 + 1] - B.allele_off[a0 + (u32)c2];
-                    if ((int)l1 >= B.k || (!B.haploid && (int)l2 >= B.k)) {
-                        fail = true;
-                        break;
-                    }
+                    if ((int)l1 >= B.k) c1 |= FW_SLIDE;
+                    if ((int)l2 >= B.k) c2 |= FW_SLIDE;
                 }
                 if (B.haploid) insert(c1);
-                else if (phased) {
+                else if (phased || m == 1) { // (the mixes of a chain of one are its two alleles)
                     insert(c1);
                     insert(c2);
                 } else if (m > FW_MAXU) {
@@ -380,16 +419,36 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
         const u32 n = sh_n[wave];
         fail = __any(fail) || n > FW_SET * 3 / 4;
         const u32 n_used = n < FW_SET ? n : FW_SET;
-        if (!fail && n) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&W.counters[1], (unsigned long long)n);
-            base = __shfl(base, 0, 64);
-            if (base + n > W.item_cap) {
-                fail = true;
-                for (u64 q = base + lane; q < W.item_cap && q < base + n; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
-            } else
-                for (u32 i = lane; i < n; i += 64) W.items[base + i] = PickItem{(u32)ci, 0u, set[list[i]] - 1};
-        }
+        if (!fail)
+            for (u32 i0 = 0; i0 < n; i0 += 64) { // the set's entries, 64 at a time: ordinary items into the wave's chunk, sliding ones into their own list
+                const u32 i = i0 + lane;
+                const unsigned long long code = i < n ? set[list[i]] - 1 : 0ULL;
+                const bool slide = i < n && (code & FW_SLIDE), norm = i < n && !slide;
+                const u64 nm = __ballot(norm);
+                const u32 cnt = (u32)__popcll(nm);
+                if (cnt > chunk_left) { // a fresh chunk (the rest of the old one is nulled so that it is skipped)
+                    for (u32 q = lane; q < chunk_left; q += 64) W.items[chunk_at + q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&W.counters[1], (unsigned long long)FW_CHUNK);
+                    base = __shfl(base, 0, 64);
+                    if (base + FW_CHUNK > W.item_cap) { // the round's buffer is full
+                        for (u64 q = base + lane; q < W.item_cap; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
+                        chunk_left = 0;
+                        fail = true;
+                        break;
+                    }
+                    chunk_at = base;
+                    chunk_left = FW_CHUNK;
+                }
+                if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{(u32)ci, 0u, code};
+                chunk_at += cnt;
+                chunk_left -= cnt;
+                if (slide) {
+                    const unsigned long long at = atomicAdd(&W.counters[2], 1ULL);
+                    if (at < W.slide_cap) W.slides[at] = PickItem{(u32)ci, 0u, code};
+                    else W.fb_flag[g] = 1;
+                }
+            }
         if (fail && lane == 0) W.fb_flag[g] = 1;
         for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
         if (n > FW_SET) // (the list lost entries: clear the whole set)
@@ -398,6 +457,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
         if (lane == 0) sh_n[wave] = 0;
         wave_sync();
     }
+    for (u32 i = lane; i < chunk_left; i += 64) W.items[chunk_at + i] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
 }
 
 // one signature k-mer: assembly in 2-bit form, canonical, XXH3, then MODE 0 lookup + max into the allele's coverage,
@@ -517,6 +577,93 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
     if (n_evaluated) {
         for (int dd = 32; dd; dd >>= 1) evaluated += __shfl_xor(evaluated, dd, 64);
         if ((threadIdx.x & 63) == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
+    }
+}
+
+// Sliding signatures (var_block.hpp:130-144): the chain is the variant alone and the allele has k bases or more -- every k-mer of
+// the allele, coverage = truncating running mean over those with a weight, in order (main.cpp:162-176).  One WAVE per item:
+// the lanes take the k-mers (assembly, hash, lookup or insert), lane 0 folds their weights in order.
+template <int MODE>
+__global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W, BFView bf, MapView map, u32 *cov_out, unsigned long long *cursor, u32 row0,
+                                                       unsigned long long *n_evaluated)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 n_items = min((unsigned long long)W.slide_cap, W.counters[2]);
+    const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    const int k = B.k;
+    for (u64 it = (u64)blockIdx.x * FW_WAVES + wave; it < n_items; it += n_waves) {
+        const PickItem item = W.slides[it];
+        const u32 g = W.combs[item.comb].g;
+        if (__shfl((int)W.fb_flag[g], 0, 64)) continue;
+        const u32 a0 = B.var_allele_off[g];
+        const u32 a = (u32)(item.code & 127);
+        const u32 canon = B.canon[a0 + a];
+        const u8 *ap = B.pool + B.allele_off[a0 + a];
+        const int al = (int)(B.allele_off[a0 + a + 1] - B.allele_off[a0 + a]);
+        const bool is_ref = canon == 0;
+        const int n_kmers = al - k + 1;
+        // first: is every base ACGT?  (nothing is counted or inserted for a record the workgroup kernel will redo)
+        bool good = k >= 17 && k <= MG_MAX_PACKED_K;
+        for (int x = lane; x < al; x += 64) {
+            bool o;
+            acgt_code(ap[x], &o);
+            good = good && o;
+        }
+        if (!__all(good)) {
+            if (lane == 0) W.fb_flag[g] = 1;
+            continue;
+        }
+        u32 curr = 0;
+        i32 nn = 0;
+        for (int p0 = 0; p0 < n_kmers; p0 += 64) {
+            const int p = p0 + lane;
+            i32 w = 0;
+            if (p < n_kmers) {
+                U128 Lf{0, 0};
+                for (int x = 0; x < k; ++x) {
+                    bool o;
+                    const u64 code = acgt_code(ap[p + x], &o);
+                    if (x < 32) Lf.lo |= code << (2 * x);
+                    else Lf.hi |= code << (2 * (x - 32));
+                }
+                const U128 mk = mask128(2 * k);
+                const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
+                const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+                const U128 key = lt128(Lf, rc) ? Lf : rc;
+                const u64 h = xxh3_packed(key, k);
+                const u64 idx = mod_size(h, bf.mod);
+                if (MODE == 0) {
+                    if (is_ref) {
+                        const long long id = k == (int)map.klen ? map_find_id(map, key, h, idx) : -1;
+                        w = id >= 0 ? (i32)map.vals[id] : 0;
+                    } else {
+                        const long long rank = bucket_rank(map, idx);
+                        w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
+                    }
+                } else if (MODE == 2) {
+                    if (is_ref) map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+                    else {
+                        atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
+                        gate_set(bf, idx);
+                    }
+                }
+            }
+            if (MODE == 0) {
+                const int cnt = min(64, n_kmers - p0);
+                for (int j = 0; j < cnt; ++j) { // in order: the mean truncates at every step
+                    const i32 wj = __shfl(w, j, 64);
+                    if (wj > 0) {
+                        curr = (curr * (u32)nn + (u32)wj) / (u32)(nn + 1);
+                        ++nn;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            if (MODE == 0 && curr) atomicMax(&cov_out[a0 + canon], curr);
+            if (MODE == 1 && is_ref) atomicAdd(cursor, (unsigned long long)n_kmers);
+            if (n_evaluated) atomicAdd(n_evaluated, (unsigned long long)n_kmers);
+        }
     }
 }
 

@@ -1851,7 +1851,7 @@ struct BlocksRun {
     u32 *gen_list, *fb_list;
     u8 *fb_flag;
     CombDesc *combs;
-    PickItem *items;
+    PickItem *items, *slides;
     unsigned long long *round_counters;
     u64 round, n_rounds;
     int cus;
@@ -1870,8 +1870,9 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     TRY(scratch(c, c->s_blk[1], 4 * n, &q[1]));                                                   // fb_list
     TRY(scratch(c, c->s_blk[2], n, &q[2]));                                                       // fb_flag
     TRY(scratch(c, c->s_blk[3], sizeof(CombDesc) * (R.round * FW_COMBS_PER_REC + 64), &q[3]));    // one round's descriptors
-    TRY(scratch(c, c->s_blk[4], sizeof(PickItem) * (R.round * FW_ITEMS_PER_REC + 64), &q[4]));    // one round's items
-    TRY(scratch(c, c->s_blk[5], 16 * R.n_rounds, &q[5]));                                         // per round: descriptors, items reserved
+    TRY(scratch(c, c->s_blk[4], sizeof(PickItem) * (R.round * FW_ITEMS_PER_REC + FW_CHUNK * (u64)(1 << 14)), &q[4])); // one round's items (+ a chunk per wave)
+    TRY(scratch(c, c->s_blk[5], 32 * R.n_rounds, &q[5]));                                         // per round: descriptors, items, sliding items reserved
+    TRY(scratch(c, c->s_blk[6], sizeof(PickItem) * (R.round / 4 + 4096), &q[7]));                 // one round's sliding items
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
         TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
@@ -1896,6 +1897,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     R.P = panel_view(p);
     R.gen_list = (u32 *)q[0]; R.fb_list = (u32 *)q[1]; R.fb_flag = (u8 *)q[2];
     R.combs = (CombDesc *)q[3]; R.items = (PickItem *)q[4]; R.round_counters = (unsigned long long *)q[5];
+    R.slides = (PickItem *)q[7];
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&R.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) R.cus = 256;
@@ -1912,7 +1914,7 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         HIP_TRY(c, hipGetLastError());
         return MG_OK;
     }
-    HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 16 * R.n_rounds, c->stream));
+    HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 32 * R.n_rounds, c->stream));
     for (u64 r = 0; r < R.n_rounds; ++r) {
         FlatWork W{};
         W.gen_list = R.gen_list;
@@ -1922,13 +1924,16 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         W.combs = R.combs;
         W.comb_cap = (u32)(R.round * FW_COMBS_PER_REC);
         W.items = R.items;
-        W.item_cap = (u32)(R.round * FW_ITEMS_PER_REC);
-        W.counters = R.round_counters + 2 * r;
+        W.item_cap = (u32)(R.round * FW_ITEMS_PER_REC + FW_CHUNK * (u64)(1 << 14));
+        W.slides = R.slides;
+        W.slide_cap = (u32)(R.round / 4 + 4096);
+        W.counters = R.round_counters + 4 * r;
         W.fb_flag = R.fb_flag;
         hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
         hipLaunchKernelGGL(fw_picks_kernel, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W);
         hipLaunchKernelGGL(fw_eval_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
                            d_evaluated);
+        hipLaunchKernelGGL(fw_slide_kernel<MODE>, dim3(R.cus * 2), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
         HIP_TRY(c, hipGetLastError());
     }
     return MG_OK;
@@ -2037,9 +2042,9 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     // tier 1: lone and short records (classification fused in); everything else is listed
     u32 *need_slow = (u32 *)(c->d_hit_count + 3);
     if (++c->iso_call_no == 0) c->iso_call_no = 1;
-    hipLaunchKernelGGL(panel_lone_kernel<false>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
+    hipLaunchKernelGGL(panel_lone_kernel<false>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
-    hipLaunchKernelGGL(panel_lone_kernel<true>, dim3(nblocks(2 * n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
+    hipLaunchKernelGGL(panel_lone_kernel<true>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_b[1], c->stream));
@@ -2170,7 +2175,7 @@ MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     HIP_TRY(c, hipMemsetAsync(R.fb_flag, 0, n, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_gen_count, 0, 64, c->stream));
     // tier 1: lone and short records are inserted at once; everything else is listed
-    hipLaunchKernelGGL(panel_lone_index_kernel, dim3(nblocks(n)), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref, (const u8 *)p->pool,
+    hipLaunchKernelGGL(panel_lone_index_kernel, dim3((unsigned)((n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref, (const u8 *)p->pool,
                        (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count);
     HIP_TRY(c, hipGetLastError());
     c->map.rows_total += n;
