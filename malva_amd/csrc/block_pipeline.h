@@ -324,17 +324,23 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
     }
 }
 
-// build_alleles_combs + combine_haplotypes (var_block.hpp:709-786) for one chain: the distinct picks of all panel samples
+// build_alleles_combs + combine_haplotypes (var_block.hpp:709-786): the distinct picks of all panel samples along a chain.
+// A wave takes 64 / G chains at a time, G lanes each (G = the panel's sample count rounded up to a power of two, at most
+// 64: a wave per chain leaves 62 lanes idle on a two-sample panel); lanes stride over the samples.  The picks of all the
+// wave's chains share one LDS set, told apart by the chain's number inside the wave (FW_GRP_SHIFT).
 constexpr int FW_WAVES = TPB / 64;
-constexpr unsigned long long FW_SLIDE = 1ULL << 62; // item code tag: the chain is the variant alone and the allele has k bases or more
+constexpr int FW_CODE_BITS = 55;                     // a pick as a code: bits per member = ceil(log2(alleles)), members left to right
+constexpr unsigned long long FW_SLIDE_IN = 1ULL << 56; // set key: the chain is the variant alone and the allele has k bases or more
+constexpr int FW_GRP_SHIFT = 57;                     // set key: the chain's number inside the wave (6 bits)
+constexpr unsigned long long FW_SLIDE = 1ULL << 62;  // the same tag on an item
 constexpr u32 FW_CHUNK = 512; // items a wave reserves at a time (one returning atomic per chain on ONE counter: 7 ms per 7e5 chains)
-__global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
+__global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W, int G)
 {
-    __shared__ unsigned long long sh_set[FW_WAVES][FW_SET]; // code + 1, 0 = free
+    __shared__ unsigned long long sh_set[FW_WAVES][FW_SET]; // key + 1, 0 = free
     __shared__ unsigned short sh_list[FW_WAVES][FW_SET];    // slots taken, in the order they were taken
     __shared__ u32 sh_n[FW_WAVES];
-    __shared__ u8 sh_bits[FW_WAVES][24], sh_shift[FW_WAVES][24];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / G, sub = lane % G, n_grp = 64 / G;
     unsigned long long *set = sh_set[wave];
     unsigned short *list = sh_list[wave];
     for (int i = lane; i < FW_SET; i += 64) set[i] = 0;
@@ -344,86 +350,99 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
     unsigned long long chunk_at = 0; // next free item of the wave's chunk
     u32 chunk_left = 0;
-    for (u64 ci = (u64)blockIdx.x * FW_WAVES + wave; ci < n_combs; ci += n_waves) {
-        const CombDesc d = W.combs[ci];
+    auto insert = [&](unsigned long long key) {
+        u32 at = (u32)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (FW_SET - 1);
+        for (int tries = 0; tries < FW_SET; ++tries) {
+            const unsigned long long seen = atomicCAS(&set[at], 0ULL, key + 1);
+            if (seen == 0ULL) {
+                const u32 q = atomicAdd(&sh_n[wave], 1u);
+                if (q < FW_SET) list[q] = (unsigned short)at;
+                return;
+            }
+            if (seen == key + 1) return;
+            at = (at + 1) & (FW_SET - 1);
+        }
+    };
+    for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + wave) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) {
+        const u64 ci = c0 + grp;
+        CombDesc d{};
+        if (ci < n_combs) d = W.combs[ci];
         const int m = d.m;
         const u32 g = d.g;
-        if (m == 0 || __shfl((int)W.fb_flag[g], 0, 64)) continue; // (wave-uniform; m == 0: a reservation that did not fit)
-        if (lane < m) {
-            const u32 v = g + d.rel[lane];
-            sh_bits[wave][lane] = (u8)fw_bits(B.var_allele_off[v + 1] - B.var_allele_off[v]);
-        }
-        wave_sync();
-        if (lane == 0) {
-            int sh = 0;
-            for (int j = 0; j < m; ++j) {
-                sh_shift[wave][j] = (u8)(sh > 255 ? 255 : sh);
-                sh += sh_bits[wave][j];
-            }
-            sh_shift[wave][m] = (u8)(sh > 255 ? 255 : sh);
-        }
-        wave_sync();
-        bool fail = sh_shift[wave][m] > 63; // the pick does not fit a 63-bit code
-        auto insert = [&](unsigned long long code) {
-            u32 at = (u32)((code * 0x9E3779B97F4A7C15ULL) >> 40) & (FW_SET - 1);
-            for (int tries = 0; tries < FW_SET; ++tries) {
-                const unsigned long long seen = atomicCAS(&set[at], 0ULL, code + 1);
-                if (seen == 0ULL) {
-                    const u32 q = atomicAdd(&sh_n[wave], 1u);
-                    if (q < FW_SET) list[q] = (unsigned short)at;
-                    return;
-                }
-                if (seen == code + 1) return;
-                at = (at + 1) & (FW_SET - 1);
-            }
-        };
-        if (!fail)
-            for (u32 s = lane; s < B.n_samples; s += 64) {
-                if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break; // too many distinct picks for the set: the workgroup kernel takes the record
+        const bool valid = ci < n_combs && m > 0 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit)
+        bool fail = false;
+        if (valid)
+            for (u32 s = sub; s < B.n_samples && !fail; s += G) {
+                if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break; // too many distinct picks for the set: the workgroup kernel's
                 bool phased = true;
-                unsigned long long c1 = 0, c2 = 0;
+                unsigned long long c1 = 0, c2 = 0, bounds = 1; // bounds: bit set at every member's first code bit, and behind the last
+                int sh = 0;
                 for (int j = 0; j < m; ++j) {
                     const u32 v = g + d.rel[j];
+                    const int bits = fw_bits(B.var_allele_off[v + 1] - B.var_allele_off[v]);
+                    if (sh + bits > FW_CODE_BITS) {
+                        fail = true;
+                        break;
+                    }
                     const u32 gt = B.gt[(u64)v * B.n_samples + s];
                     phased = phased && ((gt >> 14) & 1);
-                    c1 |= (unsigned long long)(gt & 127) << sh_shift[wave][j];
-                    c2 |= (unsigned long long)((gt >> 7) & 127) << sh_shift[wave][j];
+                    c1 |= (unsigned long long)(gt & 127) << sh;
+                    c2 |= (unsigned long long)((gt >> 7) & 127) << sh;
+                    sh += bits;
+                    bounds |= 1ULL << sh;
                 }
+                if (fail) break;
+                const unsigned long long tag = (unsigned long long)grp << FW_GRP_SHIFT;
                 if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): its own kind of item
                     const u32 a0 = B.var_allele_off[g];
                     const u32 l1 = B.allele_off[a0 + (u32)c1 + 1] - B.allele_off[a0 + (u32)c1], l2 = B.allele_off[a0 + (u32)c2 + 1] - B.allele_off[a0 + (u32)c2];
-                    if ((int)l1 >= B.k) c1 |= FW_SLIDE;
-                    if ((int)l2 >= B.k) c2 |= FW_SLIDE;
+                    if ((int)l1 >= B.k) c1 |= FW_SLIDE_IN;
+                    if ((int)l2 >= B.k) c2 |= FW_SLIDE_IN;
                 }
-                if (B.haploid) insert(c1);
+                if (B.haploid) insert(c1 | tag);
                 else if (phased || m == 1) { // (the mixes of a chain of one are its two alleles)
-                    insert(c1);
-                    insert(c2);
-                } else if (m > FW_MAXU) {
-                    fail = true;
-                    break;
-                } else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
+                    insert(c1 | tag);
+                    insert(c2 | tag);
+                } else if (m > FW_MAXU) fail = true;
+                else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
                     const unsigned long long diff = c1 ^ c2;
                     unsigned long long code = c1;
-                    insert(code);
+                    insert(code | tag);
                     for (u32 i = 1; i < (1u << m); ++i) {
                         const int j = __ffs((int)i) - 1;
-                        const unsigned long long fm = ((1ULL << sh_bits[wave][j]) - 1) << sh_shift[wave][j];
+                        unsigned long long t = bounds;
+                        for (int q = 0; q < j; ++q) t &= t - 1;
+                        const int lo = __ffsll((unsigned long long)t) - 1;
+                        t &= t - 1;
+                        const int hi = __ffsll((unsigned long long)t) - 1;
+                        const unsigned long long fm = ((1ULL << (hi - lo)) - 1) << lo;
                         code ^= diff & fm;
-                        if (diff & fm) insert(code);
+                        if (diff & fm) insert(code | tag);
                         if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break;
                     }
                 }
             }
         wave_sync();
         const u32 n = sh_n[wave];
-        fail = __any(fail) || n > FW_SET * 3 / 4;
+        const bool all_fail = n > FW_SET * 3 / 4;
+        // chains (by their number in the wave) whose record goes to the workgroup kernel
+        u64 failed = 0;
+        {
+            const u64 fl = __ballot(fail);
+            for (int q = 0; q < n_grp; ++q) {
+                const u64 qm = (G == 64 ? ~0ULL : ((1ULL << G) - 1)) << (q * G);
+                if (all_fail || (fl & qm)) failed |= 1ULL << q;
+            }
+        }
         const u32 n_used = n < FW_SET ? n : FW_SET;
-        if (!fail)
-            for (u32 i0 = 0; i0 < n; i0 += 64) { // the set's entries, 64 at a time: ordinary items into the wave's chunk, sliding ones into their own list
+        if (!all_fail)
+            for (u32 i0 = 0; i0 < n_used; i0 += 64) { // the set's entries, 64 at a time: ordinary items into the wave's chunk, sliding ones into their own list
                 const u32 i = i0 + lane;
-                const unsigned long long code = i < n ? set[list[i]] - 1 : 0ULL;
-                const bool slide = i < n && (code & FW_SLIDE), norm = i < n && !slide;
+                const unsigned long long key = i < n_used ? set[list[i]] - 1 : 0ULL;
+                const int kg = (int)(key >> FW_GRP_SHIFT) & 63;
+                const bool live = i < n_used && !((failed >> kg) & 1);
+                const bool slide = live && (key & FW_SLIDE_IN), norm = live && !slide;
+                const unsigned long long code = key & ((1ULL << FW_CODE_BITS) - 1);
                 const u64 nm = __ballot(norm);
                 const u32 cnt = (u32)__popcll(nm);
                 if (cnt > chunk_left) { // a fresh chunk (the rest of the old one is nulled so that it is skipped)
@@ -431,25 +450,25 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W)
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(&W.counters[1], (unsigned long long)FW_CHUNK);
                     base = __shfl(base, 0, 64);
-                    if (base + FW_CHUNK > W.item_cap) { // the round's buffer is full
+                    if (base + FW_CHUNK > W.item_cap) { // the round's buffer is full: everything still to be written goes to the workgroup kernel
                         for (u64 q = base + lane; q < W.item_cap; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
                         chunk_left = 0;
-                        fail = true;
+                        failed = ~0ULL; // (records with items already written are redone whole: harmless)
                         break;
                     }
                     chunk_at = base;
                     chunk_left = FW_CHUNK;
                 }
-                if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{(u32)ci, 0u, code};
+                if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{(u32)(c0 + kg), 0u, code};
                 chunk_at += cnt;
                 chunk_left -= cnt;
                 if (slide) {
                     const unsigned long long at = atomicAdd(&W.counters[2], 1ULL);
-                    if (at < W.slide_cap) W.slides[at] = PickItem{(u32)ci, 0u, code};
-                    else W.fb_flag[g] = 1;
+                    if (at < W.slide_cap) W.slides[at] = PickItem{(u32)(c0 + kg), 0u, code | FW_SLIDE};
+                    else W.fb_flag[W.combs[c0 + kg].g] = 1;
                 }
             }
-        if (fail && lane == 0) W.fb_flag[g] = 1;
+        if (valid && sub == 0 && (all_fail || ((failed >> grp) & 1))) W.fb_flag[g] = 1;
         for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
         if (n > FW_SET) // (the list lost entries: clear the whole set)
             for (int i = lane; i < FW_SET; i += 64) set[i] = 0;

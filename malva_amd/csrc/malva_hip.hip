@@ -1930,7 +1930,9 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         W.counters = R.round_counters + 4 * r;
         W.fb_flag = R.fb_flag;
         hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
-        hipLaunchKernelGGL(fw_picks_kernel, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W);
+        int G = 2; // lanes per chain: the samples, rounded up to a power of two
+        while (G < 64 && (u32)G < R.B.n_samples) G *= 2;
+        hipLaunchKernelGGL(fw_picks_kernel, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G);
         hipLaunchKernelGGL(fw_eval_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
                            d_evaluated);
         hipLaunchKernelGGL(fw_slide_kernel<MODE>, dim3(R.cus * 2), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);

@@ -748,35 +748,41 @@ def device_table_flat(panel: FlatPanel, n_rows, k, ref_k, seed, device, plant_re
         genome_t = torch.from_numpy(panel.genome).to(dev)
         cb = panel.contig_base[panel.contig_id[:n_plant]].astype(np.int64)
         ce = cb + panel.contig_len[panel.contig_id[:n_plant]].astype(np.int64)
+        gpos_t = torch.from_numpy(gpos).to(dev)
+        haps = []
         for h in range(2):
             hap = genome_t.clone()
             slot = panel.var_allele_off[:n_plant].astype(np.int64) + panel.donor_gt[:n_plant, h].astype(np.int64)
-            hap[torch.from_numpy(gpos).to(dev)] = torch.from_numpy(panel.pool[panel.allele_off[slot]]).to(dev)
-            for d in offsets:
-                start = gpos - centre + d
-                keep = (start >= cb) & (start + ref_k <= ce)
-                if h == 1:           # a homozygous donor's window is listed once (KMC lists distinct k-mers)... unless a neighbour differs
-                    keep &= True
-                st = torch.from_numpy(start[keep]).to(dev)
-                for a in range(0, st.numel(), chunk):
-                    s_ = st[a:a + chunk]
-                    w = code_t[hap[s_[:, None] + torch.arange(ref_k, device=dev)[None, :]].to(torch.int64)]     # [m, ref_k] codes 0..3 (255: non-ACGT)
-                    good = (w <= 3).all(dim=1)
-                    w = w[good]
-                    hi = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
-                    lo = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
-                    for i in range(ref_k):
-                        sh = 2 * (ref_k - 1 - i)
-                        if sh >= 64:
-                            hi |= w[:, i] << (sh - 64)
-                        else:
-                            lo |= w[:, i] << sh
-                    his.append(hi); los.append(lo)
-            del hap
+            hap[gpos_t] = torch.from_numpy(panel.pool[panel.allele_off[slot]]).to(dev)
+            haps.append(hap)
         del genome_t
+
+        def pack(w):
+            hi = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
+            lo = torch.zeros(w.shape[0], dtype=torch.int64, device=dev)
+            for i in range(ref_k):
+                sh = 2 * (ref_k - 1 - i)
+                if sh >= 64:
+                    hi |= w[:, i] << (sh - 64)
+                else:
+                    lo |= w[:, i] << sh
+            return hi, lo
+        for d in offsets:
+            start = gpos - centre + d
+            keep = (start >= cb) & (start + ref_k <= ce)
+            st = torch.from_numpy(start[keep]).to(dev)
+            for a in range(0, st.numel(), chunk):
+                idx = st[a:a + chunk][:, None] + torch.arange(ref_k, device=dev)[None, :]
+                w0 = code_t[haps[0][idx].to(torch.int64)]                  # [m, ref_k] codes 0..3 (255: non-ACGT)
+                w1 = code_t[haps[1][idx].to(torch.int64)]
+                g0, g1 = (w0 <= 3).all(dim=1), (w1 <= 3).all(dim=1)
+                hi0, lo0 = pack(w0)
+                hi1, lo1 = pack(w1)
+                g1 &= (hi1 != hi0) | (lo1 != lo0) | ~g0                      # the second haplotype's window only where it differs (KMC lists distinct
+                his += [hi0[g0], hi1[g1]]                                    # k-mers; windows shared by neighbouring records of a cluster stay doubled:
+                los += [lo0[g0], lo1[g1]]                                    # torch.unique(dim=0) returns garbage at 1e8 rows on this ROCm build)
+        del haps
         hi_t, lo_t = torch.cat(his), torch.cat(los)
-        pair = torch.unique(torch.stack([hi_t, lo_t], dim=1), dim=0)          # distinct ref_k-mers, as KMC lists them
-        hi_t, lo_t = pair[:, 0].contiguous(), pair[:, 1].contiguous()
     elif n_plant:
         hi, lo = donor_rows(panel, ref_k, n_plant)
         hi_t, lo_t = torch.from_numpy(hi.view(np.int64)).to(dev), torch.from_numpy(lo.view(np.int64)).to(dev)
