@@ -186,7 +186,7 @@ class Job:
                 ctx.bf_insert(BF_ALT, rows[1::2])   # others   -> bf     (main.cpp:139)
             del sig
             ctx.bf_finalize(BF_ALT)
-            ctx.ref_scan(genome)
+            ctx.ref_scan_resident(0, genome.size)    # main.cpp:383-401 on the reference already in HBM
         else:
             from malva_amd.resident import ResidentPanel
             whole = ResidentPanel(self.panel, dev, haploid=haploid)
@@ -197,7 +197,7 @@ class Job:
             del whole
             ctx.bf_finalize(BF_ALT)
             for cb, cl in zip(self.panel.contig_base, self.panel.contig_len):
-                ctx.ref_scan(genome[int(cb):int(cb) + int(cl)])
+                ctx.ref_scan_resident(int(cb), int(cl))
         ctx.bf_finalize(BF_CTX)
         _, n_alt, _ = ctx.bf_info(BF_ALT)
         _, n_ctx, _ = ctx.bf_info(BF_CTX)

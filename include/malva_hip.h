@@ -108,6 +108,9 @@ int mg_map_size(mg_ctx *ctx, uint64_t *n_keys);
 /* One used contig, upper-cased ASCII: for every position, if the centre k-mer
  * of the ref_k window hits `bf`, add the window to `context_bf`. */
 int mg_ref_scan(mg_ctx *ctx, const char *contig, size_t len);
+/* the same for a contig that already lies at [offset, offset + len) of the buffer given to mg_reference_upload (the
+ * reference's index_main holds every contig in memory too, main.cpp:283-295): nothing crosses PCIe, asynchronous */
+int mg_ref_scan_resident(mg_ctx *ctx, uint64_t offset, size_t len);
 
 /* ---- call-time KMC scan  (main.cpp:482-500) ------------------------------ */
 
@@ -321,6 +324,7 @@ int mg_genotype_device(mg_ctx *ctx, const void *d_cov, const void *d_freq, const
  * carries allele a (build_alleles_combs, var_block.hpp:734-786).  probs (optional):
  * normalised likelihood lists at caller-provided var_gt_off, as in mg_genotype. */
 int mg_reference_upload(mg_ctx *ctx, const char *ascii, size_t len);
+int mg_reference_upload_device(mg_ctx *ctx, const void *d_ascii, size_t len); /* from a device buffer (copied) */
 int mg_call_isolated(mg_ctx *ctx, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off,
                      const uint32_t *allele_off, const char *allele_pool, size_t pool_len, const float *freq,
                      const uint64_t *present_mask, const uint8_t *flags, float error_rate, int max_cov, int haploid,

@@ -79,6 +79,8 @@ def lib():
         "mg_map_get_count": [vp, vp, sz, sz, vp],
         "mg_map_size": [vp, vp],
         "mg_ref_scan": [vp, vp, sz],
+        "mg_ref_scan_resident": [vp, u64, sz],
+        "mg_reference_upload_device": [vp, vp, sz],
         "mg_kmc_scan": [vp, vp, vp, vp, sz],
         "mg_kmc_scan_device": [vp, vp, vp, vp, sz],
         "mg_kmc_pack_rows_device": [vp, vp, vp, vp, sz, vp],
@@ -140,7 +142,7 @@ def lib():
 
 EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_synchronize", "mg_bf_insert", "mg_bf_test",
             "mg_bf_finalize", "mg_bf_increment", "mg_bf_get_count", "mg_bf_info", "mg_map_insert", "mg_map_test",
-            "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_kmc_scan", "mg_kmc_scan_device", "mg_kmc_rows_bytes", "mg_kmc_pack_rows_device", "mg_kmc_scan_rows_device",
+            "mg_map_increment", "mg_map_get_count", "mg_map_size", "mg_ref_scan", "mg_ref_scan_resident", "mg_reference_upload_device", "mg_kmc_scan", "mg_kmc_scan_device", "mg_kmc_rows_bytes", "mg_kmc_pack_rows_device", "mg_kmc_scan_rows_device",
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
@@ -389,6 +391,13 @@ class Context:
         """contig: bytes, or a uint8 array (no copy: a whole-genome contig is gigabytes)"""
         buf = np.frombuffer(contig, dtype=np.uint8) if isinstance(contig, (bytes, bytearray, memoryview)) else np.ascontiguousarray(contig, dtype=np.uint8)
         self._ck(self._L.mg_ref_scan(self.h, _p(buf), buf.size))
+
+    def ref_scan_resident(self, offset, length):
+        """the contig at [offset, offset + length) of the uploaded reference (no PCIe)"""
+        self._ck(self._L.mg_ref_scan_resident(self.h, int(offset), int(length)))
+
+    def reference_upload_device(self, d_ptr, length):
+        self._ck(self._L.mg_reference_upload_device(self.h, C.c_void_p(d_ptr), int(length)))
 
     def kmc_scan(self, hi, lo, cnt):
         hi = np.ascontiguousarray(hi, dtype=np.uint64)

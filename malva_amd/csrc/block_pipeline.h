@@ -178,7 +178,8 @@ struct FlatWork {
     u32 item_cap;
     PickItem *slides; // items of the sliding kind (a lone allele of k bases or more): a wave each, fw_slide_kernel
     u32 slide_cap;
-    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved, [2] sliding items
+    u32 *retry;       // chains whose picks outgrew their share of a wave's set: taken again, a wave each (comb_cap entries)
+    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved, [2] sliding items, [3] chains to retry
     u8 *fb_flag;                  // [n_vars] the record goes to the workgroup kernel
 };
 
@@ -334,27 +335,38 @@ constexpr unsigned long long FW_SLIDE_IN = 1ULL << 56; // set key: the chain is 
 constexpr int FW_GRP_SHIFT = 57;                     // set key: the chain's number inside the wave (6 bits)
 constexpr unsigned long long FW_SLIDE = 1ULL << 62;  // the same tag on an item
 constexpr u32 FW_CHUNK = 512; // items a wave reserves at a time (one returning atomic per chain on ONE counter: 7 ms per 7e5 chains)
-__global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W, int G)
+// Whether a chain's picks fit depends on that chain alone -- its share of the set is FW_SET * 3 / 4 / (chains per wave) -- never on
+// which chains happen to share its wave: `index` runs the tiers twice (count, insert) and both passes must send the same
+// records the same way.  A chain that outgrows its share is listed in `retry` and taken again alone (RETRY: G = 64, the whole
+// set); one that outgrows that goes to the workgroup kernel.
+template <bool RETRY>
+__global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W, int G_in, u32 item_cap_eff)
 {
     __shared__ unsigned long long sh_set[FW_WAVES][FW_SET]; // key + 1, 0 = free
     __shared__ unsigned short sh_list[FW_WAVES][FW_SET];    // slots taken, in the order they were taken
     __shared__ u32 sh_n[FW_WAVES];
+    __shared__ u32 sh_cnt[FW_WAVES][32];                    // distinct picks per chain of the wave
+    const int G = RETRY ? 64 : G_in;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane / G, sub = lane % G, n_grp = 64 / G;
     unsigned long long *set = sh_set[wave];
     unsigned short *list = sh_list[wave];
     for (int i = lane; i < FW_SET; i += 64) set[i] = 0;
     if (lane == 0) sh_n[wave] = 0;
+    if (lane < 32) sh_cnt[wave][lane] = 0;
     wave_sync();
-    const u64 n_combs = min((unsigned long long)W.comb_cap, W.counters[0]);
+    const u32 share = (u32)(FW_SET * 3 / 4 / n_grp); // distinct picks a chain may have here
+    const u64 n_combs = RETRY ? min((unsigned long long)W.comb_cap, W.counters[3]) : min((unsigned long long)W.comb_cap, W.counters[0]);
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
     unsigned long long chunk_at = 0; // next free item of the wave's chunk
     u32 chunk_left = 0;
+    volatile u32 *my_cnt = &sh_cnt[wave][grp];
     auto insert = [&](unsigned long long key) {
         u32 at = (u32)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (FW_SET - 1);
         for (int tries = 0; tries < FW_SET; ++tries) {
             const unsigned long long seen = atomicCAS(&set[at], 0ULL, key + 1);
             if (seen == 0ULL) {
+                atomicAdd(&sh_cnt[wave][grp], 1u);
                 const u32 q = atomicAdd(&sh_n[wave], 1u);
                 if (q < FW_SET) list[q] = (unsigned short)at;
                 return;
@@ -364,16 +376,17 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
         }
     };
     for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + wave) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) {
-        const u64 ci = c0 + grp;
+        const u64 cpos = c0 + grp;                            // position in the list of chains this launch walks
+        const u64 ci = cpos < n_combs ? (RETRY ? (u64)W.retry[cpos] : cpos) : 0; // the chain's descriptor
         CombDesc d{};
-        if (ci < n_combs) d = W.combs[ci];
+        if (cpos < n_combs) d = W.combs[ci];
         const int m = d.m;
         const u32 g = d.g;
-        const bool valid = ci < n_combs && m > 0 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit)
-        bool fail = false;
+        const bool valid = cpos < n_combs && m > 0 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit)
+        bool fail = false;  // the record goes to the workgroup kernel
         if (valid)
             for (u32 s = sub; s < B.n_samples && !fail; s += G) {
-                if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break; // too many distinct picks for the set: the workgroup kernel's
+                if (*my_cnt > share) break; // the chain outgrew its share of the set (all its lanes see that sooner or later)
                 bool phased = true;
                 unsigned long long c1 = 0, c2 = 0, bounds = 1; // bounds: bit set at every member's first code bit, and behind the last
                 int sh = 0;
@@ -418,23 +431,32 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
                         const unsigned long long fm = ((1ULL << (hi - lo)) - 1) << lo;
                         code ^= diff & fm;
                         if (diff & fm) insert(code | tag);
-                        if (((volatile u32 *)sh_n)[wave] > FW_SET * 3 / 4) break;
+                        if (*my_cnt > share) break;
                     }
                 }
             }
         wave_sync();
         const u32 n = sh_n[wave];
-        const bool all_fail = n > FW_SET * 3 / 4;
-        // chains (by their number in the wave) whose record goes to the workgroup kernel
+        const bool all_fail = n > FW_SET; // (cannot happen: every chain stops at its share; kept as a guard)
+        const bool grew = valid && sh_cnt[wave][grp] > share; // the chain outgrew its share: again alone, or -- already alone -- the workgroup kernel
+        if (RETRY) fail = fail || grew;
+        else if (grew && sub == 0) {
+            const unsigned long long at = atomicAdd(&W.counters[3], 1ULL);
+            if (at < W.comb_cap) W.retry[at] = (u32)ci;
+            else fail = true;
+        }
+        // chains (by their number in the wave) nothing is written for
         u64 failed = 0;
         {
-            const u64 fl = __ballot(fail);
+            const u64 fl = __ballot(fail || grew);
             for (int q = 0; q < n_grp; ++q) {
                 const u64 qm = (G == 64 ? ~0ULL : ((1ULL << G) - 1)) << (q * G);
                 if (all_fail || (fl & qm)) failed |= 1ULL << q;
             }
         }
+        const u64 to_wg = __ballot(fail); // lanes whose chain's record goes to the workgroup kernel
         const u32 n_used = n < FW_SET ? n : FW_SET;
+        bool buffer_full = false;
         if (!all_fail)
             for (u32 i0 = 0; i0 < n_used; i0 += 64) { // the set's entries, 64 at a time: ordinary items into the wave's chunk, sliding ones into their own list
                 const u32 i = i0 + lane;
@@ -450,26 +472,28 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(&W.counters[1], (unsigned long long)FW_CHUNK);
                     base = __shfl(base, 0, 64);
-                    if (base + FW_CHUNK > W.item_cap) { // the round's buffer is full: everything still to be written goes to the workgroup kernel
-                        for (u64 q = base + lane; q < W.item_cap; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
+                    if (base + FW_CHUNK > item_cap_eff) { // the round's buffer is full: everything still to be written goes to the workgroup kernel
+                        for (u64 q = base + lane; q < W.item_cap && q < base + FW_CHUNK; q += 64) W.items[q] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
                         chunk_left = 0;
-                        failed = ~0ULL; // (records with items already written are redone whole: harmless)
+                        buffer_full = true; // (records with items already written are redone whole: harmless)
                         break;
                     }
                     chunk_at = base;
                     chunk_left = FW_CHUNK;
                 }
-                if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{(u32)(c0 + kg), 0u, code};
+                const u32 kci = RETRY ? (u32)ci : (u32)(c0 + kg); // (alone in the wave, or the kg-th of the wave's run of chains)
+                if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{kci, 0u, code};
                 chunk_at += cnt;
                 chunk_left -= cnt;
                 if (slide) {
                     const unsigned long long at = atomicAdd(&W.counters[2], 1ULL);
-                    if (at < W.slide_cap) W.slides[at] = PickItem{(u32)(c0 + kg), 0u, code | FW_SLIDE};
-                    else W.fb_flag[W.combs[c0 + kg].g] = 1;
+                    if (at < W.slide_cap) W.slides[at] = PickItem{kci, 0u, code | FW_SLIDE};
+                    else W.fb_flag[W.combs[kci].g] = 1;
                 }
             }
-        if (valid && sub == 0 && (all_fail || ((failed >> grp) & 1))) W.fb_flag[g] = 1;
+        if (valid && sub == 0 && (all_fail || buffer_full || ((to_wg >> (grp * G)) & (G == 64 ? ~0ULL : ((1ULL << G) - 1))))) W.fb_flag[g] = 1;
         for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
+        if (lane < 32) sh_cnt[wave][lane] = 0;
         if (n > FW_SET) // (the list lost entries: clear the whole set)
             for (int i = lane; i < FW_SET; i += 64) set[i] = 0;
         wave_sync();
@@ -496,7 +520,6 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
         const u32 g = d.g;
         if (W.fb_flag[g]) continue;
         const int m = d.m, jm = d.jm;
-        const u8 *ref = B.reference + B.contig_base[d.cid];
         const i32 ref_len = (i32)B.contig_len[d.cid];
         // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
         int len_v = 0, mid_pos = 0, mid_len = 0, sh = 0;
@@ -528,9 +551,11 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             if (MODE != 2) overflow[g] = 1; // the reference clips or throws here: the host path's
             continue;
         }
-        // W[x] = Vext[x - mp] for x in [0, k), Vext = V with the reference continuing on both sides
+        // W[x] = Vext[x - mp] for x in [0, k), Vext = V with the reference continuing on both sides.  Reference stretches come
+        // out of the packed reference 32 bases at a time (two loads and a shift each), alleles byte by byte
         U128 Lf{0, 0};
         bool ok = k >= 17 && k <= MG_MAX_PACKED_K;
+        const u64 cbase = B.contig_base[d.cid];
         auto put = [&](int x, u32 byte) {
             bool o;
             const u64 code = acgt_code(byte, &o);
@@ -538,7 +563,19 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             if (x < 32) Lf.lo |= code << (2 * x);
             else Lf.hi |= code << (2 * (x - 32));
         };
-        for (int x = 0; x < mp && x < k; ++x) put(x, ref[first_pos - mp + x]);
+        auto put_ref = [&](int x, int xe, long long from) { // W[x .. xe) = reference[from ..) (positions inside the contig)
+            while (x < xe) {
+                const int n = xe - x < 32 ? xe - x : 32;
+                const u64 at = cbase + (u64)from;
+                ok = ok && !ref_bad(B.refbad, at, n);
+                const U128 sp = shl128(U128{ref_codes(B.ref2, at, n), 0}, 2 * x);
+                Lf.lo |= sp.lo;
+                Lf.hi |= sp.hi;
+                x += n;
+                from += n;
+            }
+        };
+        put_ref(0, mp < k ? (mp > 0 ? mp : 0) : k, (long long)first_pos - mp);
         int vs = 0;
         sh = 0;
         for (int j = 0; j < m; ++j) {
@@ -554,11 +591,15 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             if (j + 1 < m) {
                 const int gs = B.pos[v] + (int)B.ref_size[v];
                 const int gl = B.pos[g + d.rel[j + 1]] - gs;
-                for (int x = max(0, vs + mp), xe = min(k, vs + gl + mp); x < xe; ++x) put(x, ref[gs + (x - mp - vs)]);
+                const int x0 = max(0, vs + mp), xe = min(k, vs + gl + mp);
+                if (x0 < xe) put_ref(x0, xe, (long long)gs + (x0 - mp - vs));
                 vs += gl;
             }
         }
-        for (int x = max(0, len_v + mp); x < k; ++x) put(x, ref[last_end + (x - mp - len_v)]);
+        {
+            const int x0 = max(0, len_v + mp);
+            if (x0 < k) put_ref(x0, k, (long long)last_end + (x0 - mp - len_v));
+        }
         if (!ok) { // a base outside ACGT (or a k the packed form does not hold): the byte-wise path of the workgroup kernel
             W.fb_flag[g] = 1;
             continue;

@@ -83,12 +83,15 @@ struct mg_ctx {
     bool blocks_stats_valid = false;
     int blocks_grid[3] = {0, 0, 0};            // persistent grid of cover_blocks_kernel<MODE> (found at first use)
     int use_flat_tier = 1;                     // 0: every general record takes the workgroup kernel (A/B, tests)
+    int use_packed_ref_scan = 1;               // 0: the byte-wise reference scan for every window (A/B, tests)
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
     float *d_eps = nullptr; // [2 * MG_EPS_TABLE]
     float eps_for = -1.f;
     u8 *d_ref = nullptr;
     size_t ref_len = 0;
+    u64 *d_ref2 = nullptr;   // the same reference as 2-bit codes (ref_pack_kernel) ...
+    u32 *d_refbad = nullptr; // ... and one bit per base: not ACGT
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool stats_valid = false;
     u32 *joined = nullptr; // when set: one allocation holding [bf counters | map counters] (mg_counters_view)
@@ -557,6 +560,8 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipFree(c->d_ln);
     hipFree(c->d_eps);
     hipFree(c->d_ref);
+    hipFree(c->d_ref2);
+    hipFree(c->d_refbad);
     for (auto &e : c->ev)
         if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -592,6 +597,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
+    else if (!strcmp(name, "use_packed_ref_scan")) c->use_packed_ref_scan = value != 0;
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
@@ -635,6 +641,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
     else if (!strcmp(name, "use_partition")) *value = c->use_partition;
     else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
+    else if (!strcmp(name, "use_packed_ref_scan")) *value = c->use_packed_ref_scan;
     else if (!strcmp(name, "gate_log2")) *value = c->gate_log2;
     else if (!strcmp(name, "gate_k")) *value = c->gate_k;
     else if (!strcmp(name, "pregate_log2")) *value = c->pregate_log2;
@@ -898,39 +905,100 @@ MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
 
 // ---- reference scan --------------------------------------------------------------------
 
+namespace {
+int reference_pack(mg_ctx *c, const u8 *d_ascii, size_t len, u64 *ref2, u32 *refbad)
+{
+    const u64 n_words = (len + 31) / 32 + 4; // (+ the padding the span readers may touch)
+    hipLaunchKernelGGL(ref_pack_kernel, dim3(nblocks(n_words)), dim3(TPB), 0, c->stream, d_ascii, (u64)len, ref2, refbad, n_words);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+// the windows [w0, w0 + nw) of a contig whose ASCII bytes from window w0 on are at d_ascii and whose base w0 sits at `at` in
+// the packed arrays: the packed kernel, then the byte-wise one for what it leaves out
+int ref_scan_windows(mg_ctx *c, const u8 *d_ascii, const u64 *ref2, const u32 *refbad, u64 at, u64 w0, u64 nw)
+{
+    const bool packed = c->k >= 1 && c->ref_k <= MG_MAX_PACKED_K && c->use_packed_ref_scan;
+    if (packed) {
+        const unsigned grid = (unsigned)std::min<u64>(nblocks((nw + REF_SCAN_W - 1) / REF_SCAN_W), 1u << 16);
+        // (window numbers are contig-wide only through w == 0 and w < k: the packed kernel is handed the slice's own numbering
+        //  shifted by w0 through `at` -- see its `w` -- so slices after the first never meet the quirk)
+        if (c->k == 35 && c->ref_k == 43)
+            hipLaunchKernelGGL((ref_scan_packed_kernel<35, 43>), dim3(grid), dim3(TPB), 0, c->stream, ref2, refbad, at, w0, nw, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
+        else if (c->k == 35 && c->ref_k == 63)
+            hipLaunchKernelGGL((ref_scan_packed_kernel<35, 63>), dim3(grid), dim3(TPB), 0, c->stream, ref2, refbad, at, w0, nw, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
+        else
+            hipLaunchKernelGGL((ref_scan_packed_kernel<0, 0>), dim3(grid), dim3(TPB), 0, c->stream, ref2, refbad, at, w0, nw, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
+    }
+    hipLaunchKernelGGL(ref_scan_kernel, dim3(nblocks(nw)), dim3(TPB), 0, c->stream, d_ascii, w0, nw, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX),
+                       packed ? refbad : (const u32 *)nullptr, at);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+int ref_scan_checks(mg_ctx *c, size_t len)
+{
+    if (!c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_ref_scan needs `bf` finalised (main.cpp:378 precedes :383)");
+    if (c->bf[MG_BF_CTX].mode) return fail(c, MG_ERR_STATE, "context filter already finalised");
+    const size_t off = (c->ref_k - c->k) / 2;
+    if (off > len) return fail(c, MG_ERR_ARG, "contig shorter than (ref_k-k)/2: the reference throws std::out_of_range here");
+    return MG_OK;
+}
+// main.cpp:386-389 for a contig shorter than ref_k, both strings clipped by std::string(reference, pos, n): one test, no loop
+int ref_scan_short(mg_ctx *c, const char *contig, size_t len)
+{
+    const size_t off = (c->ref_k - c->k) / 2;
+    const size_t kn = len - off < c->k ? len - off : c->k;
+    if (kn == 0) return fail(c, MG_ERR_ARG, "contig of %zu bases has no centre k-mer", len);
+    std::vector<char> r1(MG_MAX_KMER + 8, 0), r2(MG_MAX_KMER + 8, 0);
+    memcpy(r1.data(), contig + off, kn);
+    memcpy(r2.data(), contig, len);
+    uint8_t hit = 0;
+    TRY(mg_bf_test(c, MG_BF_ALT, r1.data(), r1.size(), 1, &hit));
+    if (hit) TRY(mg_bf_insert(c, MG_BF_CTX, r2.data(), r2.size(), 1));
+    return MG_OK;
+}
+} // namespace
+
 MG_EXPORT int mg_ref_scan(mg_ctx *c, const char *contig, size_t len)
 {
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (len && !contig) return fail(c, MG_ERR_ARG, "contig is NULL");
-    if (!c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_ref_scan needs `bf` finalised (main.cpp:378 precedes :383)");
-    if (c->bf[MG_BF_CTX].mode) return fail(c, MG_ERR_STATE, "context filter already finalised");
-    const size_t off = (c->ref_k - c->k) / 2;
-    if (off > len) return fail(c, MG_ERR_ARG, "contig shorter than (ref_k-k)/2: the reference throws std::out_of_range here");
-    if (len < c->ref_k) {
-        // main.cpp:386-389 with both strings clipped by std::string(reference, pos, n): one test, no loop
-        const size_t kn = len - off < c->k ? len - off : c->k;
-        if (kn == 0) return fail(c, MG_ERR_ARG, "contig of %zu bases has no centre k-mer", len);
-        std::vector<char> r1(MG_MAX_KMER + 8, 0), r2(MG_MAX_KMER + 8, 0);
-        memcpy(r1.data(), contig + off, kn);
-        memcpy(r2.data(), contig, len);
-        uint8_t hit = 0;
-        TRY(mg_bf_test(c, MG_BF_ALT, r1.data(), r1.size(), 1, &hit));
-        if (hit) TRY(mg_bf_insert(c, MG_BF_CTX, r2.data(), r2.size(), 1));
-        return MG_OK;
-    }
+    TRY(ref_scan_checks(c, len));
+    if (len < c->ref_k) return ref_scan_short(c, contig, len);
     const u64 n_windows = len - c->ref_k + 1;
-    // stream the contig through the device in slices (a human chromosome is a few hundred MB)
+    // stream the contig through the device in slices (a human chromosome is a few hundred MB): bytes up, packed, scanned
     const size_t slice = 256u << 20;
     for (u64 w0 = 0; w0 < n_windows; w0 += slice) {
         const u64 nw = n_windows - w0 < slice ? n_windows - w0 : slice;
-        void *d;
-        TRY(upload(c, c->s_rows, contig + w0, nw + c->ref_k - 1, &d));
-        hipLaunchKernelGGL(ref_scan_kernel, dim3(nblocks(nw)), dim3(TPB), 0, c->stream, (const u8 *)d, w0, nw, (int)c->k,
-                           (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX));
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const size_t nbytes = nw + c->ref_k - 1;
+        void *d, *p2, *pb;
+        TRY(scratch(c, c->s_rows, (nbytes + 63) / 64 * 64 + 256, &d));
+        TRY(scratch(c, c->s_aux, ((nbytes + 31) / 32 + 4) * 8, &p2));
+        TRY(scratch(c, c->s_out, ((nbytes + 31) / 32 + 4) * 4, &pb));
+        HIP_TRY(c, hipMemsetAsync((u8 *)d + nbytes / 64 * 64, 0, (nbytes + 63) / 64 * 64 + 256 - nbytes / 64 * 64, c->stream)); // (the tail the pack kernel reads past the bytes)
+        HIP_TRY(c, hipMemcpyAsync(d, contig + w0, nbytes, hipMemcpyHostToDevice, c->stream));
+        TRY(reference_pack(c, (const u8 *)d, nbytes, (u64 *)p2, (u32 *)pb));
+        TRY(ref_scan_windows(c, (const u8 *)d, (const u64 *)p2, (const u32 *)pb, 0, w0, nw));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // (the scratch is reused by the next slice; the caller may reuse its buffer)
     }
+    return MG_OK;
+}
+
+// the same for a contig that lies at [offset, offset + len) of the buffer given to mg_reference_upload: nothing crosses PCIe
+MG_EXPORT int mg_ref_scan_resident(mg_ctx *c, uint64_t offset, size_t len)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
+    if (offset + len > c->ref_len) return fail(c, MG_ERR_ARG, "contig lies outside the uploaded reference");
+    TRY(ref_scan_checks(c, len));
+    if (len < c->ref_k) { // (the short-contig case goes through the row kernels: fetch its bytes)
+        std::vector<char> h(len + 1, 0);
+        if (len) HIP_TRY(c, hipMemcpy(h.data(), c->d_ref + offset, len, hipMemcpyDeviceToHost));
+        return ref_scan_short(c, h.data(), len);
+    }
+    const u64 n_windows = len - c->ref_k + 1;
+    TRY(ref_scan_windows(c, c->d_ref + offset, c->d_ref2, c->d_refbad, offset, 0, n_windows));
     return MG_OK;
 }
 
@@ -1852,6 +1920,7 @@ struct BlocksRun {
     u8 *fb_flag;
     CombDesc *combs;
     PickItem *items, *slides;
+    u32 *retry;
     unsigned long long *round_counters;
     u64 round, n_rounds;
     int cus;
@@ -1873,6 +1942,8 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     TRY(scratch(c, c->s_blk[4], sizeof(PickItem) * (R.round * FW_ITEMS_PER_REC + FW_CHUNK * (u64)(1 << 14)), &q[4])); // one round's items (+ a chunk per wave)
     TRY(scratch(c, c->s_blk[5], 32 * R.n_rounds, &q[5]));                                         // per round: descriptors, items, sliding items reserved
     TRY(scratch(c, c->s_blk[6], sizeof(PickItem) * (R.round / 4 + 4096), &q[7]));                 // one round's sliding items
+    void *q_retry;
+    TRY(scratch(c, c->s_blk[7], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_retry));                // one round's chains to retry
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
         TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
@@ -1887,6 +1958,8 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 64));
     BlockBatch B{};
     B.reference = c->d_ref;
+    B.ref2 = c->d_ref2;
+    B.refbad = c->d_refbad;
     B.contig_base = p->contig_base; B.contig_len = p->contig_len; B.contig_id = p->contig_id;
     B.blk_var_off = d_blk_var_off; B.var_block = d_var_block;
     B.pos = p->pos; B.ref_size = p->ref_size; B.min_size = p->min_size; B.present = p->present; B.var_allele_off = p->var_allele_off;
@@ -1898,6 +1971,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     R.gen_list = (u32 *)q[0]; R.fb_list = (u32 *)q[1]; R.fb_flag = (u8 *)q[2];
     R.combs = (CombDesc *)q[3]; R.items = (PickItem *)q[4]; R.round_counters = (unsigned long long *)q[5];
     R.slides = (PickItem *)q[7];
+    R.retry = (u32 *)q_retry;
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&R.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) R.cus = 256;
@@ -1927,12 +2001,16 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         W.item_cap = (u32)(R.round * FW_ITEMS_PER_REC + FW_CHUNK * (u64)(1 << 14));
         W.slides = R.slides;
         W.slide_cap = (u32)(R.round / 4 + 4096);
+        W.retry = R.retry;
         W.counters = R.round_counters + 4 * r;
         W.fb_flag = R.fb_flag;
         hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
         int G = 2; // lanes per chain: the samples, rounded up to a power of two
         while (G < 64 && (u32)G < R.B.n_samples) G *= 2;
-        hipLaunchKernelGGL(fw_picks_kernel, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G);
+        // the counting pass of `index` leaves a margin in the item buffer: the insert pass packs its chunks in another order
+        const u32 cap_eff = MODE == 1 ? W.item_cap / 8 * 7 : W.item_cap;
+        hipLaunchKernelGGL(fw_picks_kernel<false>, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G, cap_eff);
+        if (G < 64) hipLaunchKernelGGL(fw_picks_kernel<true>, dim3(R.cus * 4), dim3(TPB), 0, c->stream, R.B, W, 64, cap_eff);
         hipLaunchKernelGGL(fw_eval_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
                            d_evaluated);
         hipLaunchKernelGGL(fw_slide_kernel<MODE>, dim3(R.cus * 2), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
@@ -2263,16 +2341,45 @@ MG_EXPORT int mg_index_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, c
     return MG_OK;
 }
 
+namespace {
+int reference_alloc(mg_ctx *c, size_t len)
+{
+    for (void *q : {(void *)c->d_ref, (void *)c->d_ref2, (void *)c->d_refbad})
+        if (q) hipFree(q);
+    c->d_ref = nullptr;
+    c->d_ref2 = nullptr;
+    c->d_refbad = nullptr;
+    c->ref_len = 0;
+    const size_t padded = (len + 63) / 64 * 64 + 256; // the pack kernel reads whole 32-byte groups, pack_span whole dwords around a window
+    const u64 n_words = (len + 31) / 32 + 4;
+    HIP_TRY(c, hipMalloc(&c->d_ref, padded));
+    HIP_TRY(c, hipMalloc(&c->d_ref2, n_words * 8));
+    HIP_TRY(c, hipMalloc(&c->d_refbad, n_words * 4));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref, 0, padded, c->stream));
+    return MG_OK;
+}
+} // namespace
+
 MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 {
     const DeviceGuard on_device(c);
     if (!c || (len && !ascii)) return MG_ERR_ARG;
-    if (c->d_ref) hipFree(c->d_ref);
-    c->d_ref = nullptr;
-    c->ref_len = 0;
-    HIP_TRY(c, hipMalloc(&c->d_ref, len + 64)); // padded: pack_span reads whole aligned dwords around a window
-    HIP_TRY(c, hipMemset(c->d_ref, 0, len + 64));
-    if (len) HIP_TRY(c, hipMemcpy(c->d_ref, ascii, len, hipMemcpyHostToDevice));
+    TRY(reference_alloc(c, len));
+    if (len) HIP_TRY(c, hipMemcpyAsync(c->d_ref, ascii, len, hipMemcpyHostToDevice, c->stream));
+    TRY(reference_pack(c, c->d_ref, len, c->d_ref2, c->d_refbad));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ref_len = len;
+    return MG_OK;
+}
+// the same from a buffer already on the device (a copy is kept: the caller's buffer may go)
+MG_EXPORT int mg_reference_upload_device(mg_ctx *c, const void *d_ascii, size_t len)
+{
+    const DeviceGuard on_device(c);
+    if (!c || (len && !d_ascii)) return MG_ERR_ARG;
+    TRY(reference_alloc(c, len));
+    if (len) HIP_TRY(c, hipMemcpyAsync(c->d_ref, d_ascii, len, hipMemcpyDeviceToDevice, c->stream));
+    TRY(reference_pack(c, c->d_ref, len, c->d_ref2, c->d_refbad));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_len = len;
     return MG_OK;
 }

@@ -11,6 +11,19 @@ struct LdsIn {
     const u8 *p;
     __device__ __forceinline__ u32 operator()(int i) const { return p[i]; }
 };
+// is window w of a contig (its first base at `at` in the packed reference) one the packed kernel leaves to the byte-wise one?
+__device__ __forceinline__ bool ref_window_slow_any(const u32 *__restrict__ refbad, u64 at, u64 w, int k, int ref_k)
+{
+    if (((ref_k - k) & 1) && w >= 1 && w < (u64)k) return true;
+    for (int done = 0; done < ref_k; done += 32) {
+        const int n = ref_k - done < 32 ? ref_k - done : 32;
+        const u64 s = at + done, wd = s >> 5;
+        const int o = (int)(s & 31);
+        const u64 b = ((u64)refbad[wd] | ((u64)refbad[wd + 1] << 32)) >> o;
+        if (b & (n >= 32 ? 0xFFFFFFFFULL : ((1ULL << n) - 1))) return true;
+    }
+    return false;
+}
 // The reference slides its centre k-mer by appending reference[p - (ref_k-k)/2]
 // (main.cpp:395-397).  When ref_k - k is odd that append runs one base ahead of a
 // true slide: window w >= 1 reads the centre at offset (ref_k-k) - (ref_k-k)/2,
@@ -22,16 +35,27 @@ struct CentreIn {
     int off_first, off_slide, keep; // keep = bytes still taken at the first window's offset
     __device__ __forceinline__ u32 operator()(int i) const { return p[(i < keep ? off_first : off_slide) + i]; }
 };
+// refbad != NULL: only the windows ref_scan_packed_kernel leaves out (`slow_base` = offset of window w0 in the packed arrays)
 __global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0, u64 n_windows, int k, int ref_k, BFView bf,
-                                                       BFView ctx)
+                                                       BFView ctx, const u32 *__restrict__ refbad, u64 slow_base)
 {
     __shared__ u8 sh[TPB + MG_MAX_KMER];
+    __shared__ int sh_any;
     const u64 p0 = (u64)blockIdx.x * TPB;
     const u64 avail = n_windows - p0 < TPB ? n_windows - p0 : TPB;
     const int nbytes = (int)avail + ref_k - 1;
+    bool mine = threadIdx.x < avail;
+    if (refbad) { // (a workgroup with nothing to do does not even stage its bytes)
+        if (threadIdx.x == 0) sh_any = 0;
+        __syncthreads();
+        mine = mine && ref_window_slow_any(refbad, slow_base + p0 + threadIdx.x, w0 + p0 + threadIdx.x, k, ref_k);
+        if (mine) sh_any = 1;
+        __syncthreads();
+        if (!sh_any) return;
+    }
     for (int i = threadIdx.x; i < nbytes; i += TPB) sh[i] = contig[p0 + i];
     __syncthreads();
-    if (threadIdx.x >= avail) return;
+    if (!mine) return;
     const u64 w = w0 + p0 + threadIdx.x; // window index inside the contig
     const int off = (ref_k - k) / 2;
     const int keep = w < (u64)k ? k - (int)w : 0;
@@ -41,6 +65,119 @@ __global__ void __launch_bounds__(TPB) ref_scan_kernel(const u8 *contig, u64 w0,
     CanonBytes<LdsIn> cc(LdsIn{sh + threadIdx.x}, ref_k);
     const u64 cidx = mod_size(xxh3_bytes(cc, ref_k), ctx.mod);
     atomicOr((unsigned long long *)&ctx.words[cidx >> 6], 1ULL << (cidx & 63));
+}
+
+// ---- the reference in 2-bit form ------------------------------------------------------------------------------------------
+// Beside the upper-cased ASCII text the context keeps the reference packed: ref2 holds base i as a 2-bit code (A0 C1 G2 T3) at
+// bits 2 (i % 32) of word i / 32 -- the L-form's order, so a span comes out as the L-form of its bases with two loads and a
+// shift -- and refbad one bit per base, set where the byte is not one of ACGT (N, IUPAC, a lower-case letter that escaped
+// the caller's toupper).  Both arrays are padded with two zero words.  One thread packs 32 bases from eight aligned dwords.
+__global__ void __launch_bounds__(TPB) ref_pack_kernel(const u8 *__restrict__ ascii, u64 n, u64 *__restrict__ ref2, u32 *__restrict__ refbad, u64 n_words)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= n_words) return;
+    u64 codes = 0;
+    u32 bad = 0;
+    const u32 *q = (const u32 *)(ascii + 32 * w); // (the buffer is padded to a multiple of 64 bytes)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 at = 32 * w + 4 * (u64)j;
+        const u32 d = at < n ? q[j] : 0u;
+        u32 t = (d >> 1) & 0x03030303u; // per byte: A0 C1 G3 T2
+        t ^= (t >> 1) & 0x01010101u;    //           A0 C1 G2 T3
+        const u32 c8 = (t * 0x01041040u) >> 24;
+        const u32 x = expand4(c8) ^ d; // non-zero bytes: not ACGT
+        u32 b4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (((x >> (8 * i)) & 0xFF) && at + i < n) b4 |= 1u << i;
+        codes |= (u64)c8 << (8 * j);
+        bad |= b4 << (4 * j);
+    }
+    ref2[w] = codes;
+    refbad[w] = bad;
+}
+// n <= 32 bases from position `start` as an L-form (base i of the span at bits 2i)
+__device__ __forceinline__ u64 ref_codes(const u64 *__restrict__ ref2, u64 start, int n)
+{
+    const u64 w = start >> 5;
+    const int o = (int)(start & 31) * 2;
+    u64 v = ref2[w] >> o;
+    if (o) v |= ref2[w + 1] << (64 - o);
+    return n >= 32 ? v : v & ((1ULL << (2 * n)) - 1);
+}
+// is any of the n <= 32 bases from `start` outside ACGT?
+__device__ __forceinline__ bool ref_bad(const u32 *__restrict__ refbad, u64 start, int n)
+{
+    const u64 w = start >> 5;
+    const int o = (int)(start & 31);
+    const u64 b = ((u64)refbad[w] | ((u64)refbad[w + 1] << 32)) >> o;
+    return (b & (n >= 32 ? 0xFFFFFFFFULL : ((1ULL << n) - 1))) != 0;
+}
+
+// H11 on the packed reference: one thread takes REF_SCAN_W consecutive windows of a contig that lies at `base` in the packed
+// arrays (three code words and the bad bits loaded once, the windows slid out of registers): centre k-mer -> canonical -> XXH3
+// -> gate -> `bf` bit; on a hit the ref_k-mer -> canonical -> XXH3 -> context_bf bit.  Exactly scan_filter's arithmetic, on
+// L-forms cut from the reference instead of M-forms read from a table.  Windows it cannot take -- a base outside ACGT
+// inside the window, or the first k windows of a contig when ref_k - k is odd (the reference's sliding quirk, above) -- are
+// left to ref_scan_kernel, which is launched over the same range with `only_slow` set and returns at once elsewhere.
+constexpr int REF_SCAN_W = 8;
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) ref_scan_packed_kernel(const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, u64 base, u64 first_window, u64 n_windows,
+                                                              int k_rt, int r_rt, BFView bf, BFView ctx)
+{
+    __shared__ u32 sh_lut[256];
+    ascii_lut_fill(sh_lut);
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2, off_slide = (r - k) - off;
+    const U128 mk = mask128(2 * k), mr = mask128(2 * r);
+    const u64 n_threads = (u64)gridDim.x * TPB;
+    for (u64 t = (u64)blockIdx.x * TPB + threadIdx.x; t * REF_SCAN_W < n_windows; t += n_threads) {
+        const u64 w0 = t * REF_SCAN_W;
+        const u64 at0 = base + w0;
+        // the 2-bit codes of [at0, at0 + W + r - 1): at most 71 bases behind an offset of up to 31 -> four words
+        const u64 wi = at0 >> 5;
+        const int o = (int)(at0 & 31) * 2;
+        u64 q0 = ref2[wi], q1 = ref2[wi + 1], q2 = ref2[wi + 2], q3 = ref2[wi + 3];
+        if (o) {
+            q0 = (q0 >> o) | (q1 << (64 - o));
+            q1 = (q1 >> o) | (q2 << (64 - o));
+            q2 = (q2 >> o) | (q3 << (64 - o));
+        }
+        // bad bits of the same span (up to 71 + 31 bits: four 32-bit words)
+        const u64 b01 = (u64)refbad[wi] | ((u64)refbad[wi + 1] << 32), b23 = (u64)refbad[wi + 2] | ((u64)refbad[wi + 3] << 32);
+        const int ob = (int)(at0 & 31);
+        const u64 blo = ob ? (b01 >> ob) | (b23 << (64 - ob)) : b01, bhi = b23 >> ob; // bit i: base at0 + i is not ACGT
+        for (int j = 0; j < REF_SCAN_W; ++j) {
+            if (w0 + j >= n_windows) break;
+            const u64 w = first_window + w0 + j; // the window's number inside its contig (`base` is where window first_window starts)
+            // any bad base in [j, j + r)?
+            const U128 bw = shr128(U128{blo, bhi}, j);
+            const u64 bm_lo = r >= 64 ? ~0ULL : ((1ULL << r) - 1);
+            bool slow = (bw.lo & bm_lo) != 0;
+            if (((r - k) & 1) && w >= 1 && w < (u64)k) slow = true;
+            if (slow) continue;
+            U128 L = shr128(U128{q0, q1}, 2 * j); // bases [j, j + 64 - j) ...
+            if (j) L.hi |= q2 << (64 - 2 * j);   // ... and the rest of the second word
+            L.lo &= mr.lo;
+            L.hi &= mr.hi;
+            const int coff = w == 0 ? off : off_slide;
+            U128 f = shr128(L, 2 * coff);
+            f.lo &= mk.lo;
+            f.hi &= mk.hi;
+            const U128 fm = shr128(U128{pairrev64(f.hi), pairrev64(f.lo)}, 2 * (64 - k)); // M-form of the centre k-mer
+            const U128 frc{~fm.lo & mk.lo, ~fm.hi & mk.hi};
+            const U128 key = lt128(f, frc) ? f : frc;
+            const u64 idx = mod_size(xxh3_packed_k<KC>(key, k, sh_lut), bf.mod);
+            if (!gate_open(bf, idx) || !bf_bit(bf, idx)) continue;
+            const U128 Lm = shr128(U128{pairrev64(L.hi), pairrev64(L.lo)}, 2 * (64 - r));
+            const U128 Lrc{~Lm.lo & mr.lo, ~Lm.hi & mr.hi};
+            const U128 ckey = lt128(L, Lrc) ? L : Lrc;
+            const u64 cidx = mod_size(xxh3_packed_k<RC>(ckey, r, sh_lut), ctx.mod);
+            atomicOr((unsigned long long *)&ctx.words[cidx >> 6], 1ULL << (cidx & 63));
+        }
+    }
 }
 
 // ---- H10: KMC scan (main.cpp:482-500) -----------------------------------------

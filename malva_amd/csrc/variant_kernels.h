@@ -324,6 +324,8 @@ __global__ void __launch_bounds__(TPB) iso_index_kernel(const u8 *reference, u64
 // `overflow` and its block is redone by the host enumerator + mg_lookup_cover / mg_*_insert, so results never depend on them.
 struct BlockBatch {
     const u8 *reference;      // concatenated contigs (mg_reference_upload)
+    const u64 *ref2;          // the same as 2-bit codes, and one bit per base: not ACGT (ref_pack_kernel)
+    const u32 *refbad;
     const u64 *contig_base;   // per sequence: its offset in `reference`
     const u32 *contig_len;    //               and its length
     const u32 *contig_id;     // [n_vars] sequence of each record; a block is evaluated against the sequence of its FIRST record

@@ -42,7 +42,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general):
         assert ovf.sum() == 0, "%d records handed back at index time" % int(ovf.sum())
         ctx.bf_finalize(BF_ALT)
         for b, l in zip(panel.contig_base, panel.contig_len):
-            ctx.ref_scan(panel.genome[int(b):int(b) + int(l)])
+            ctx.ref_scan_resident(int(b), int(l))         # main.cpp:383-401 on the reference already in HBM
         ctx.bf_finalize(BF_CTX)
         assert np.array_equal(ctx.bf_export_sparse(BF_ALT)[2], obf.set_positions())
         assert np.array_equal(ctx.bf_export_sparse(BF_CTX)[2], octx.set_positions())
@@ -96,6 +96,26 @@ def test_c4_recipe_clustered_snps_beyond_2_to_the_25():
     assert panel.pos.max() > (1 << 25)
     stats = run_recipe(panel, k, ref_k, False, 1 << 30, n_rows=3_000_000, plant=20_000, min_general=30_000)
     assert stats["signatures"] > 2 * panel.n
+
+
+def test_index_on_the_device_is_repeatable():
+    """`index` runs the tiers twice (count the exact map's rows, then insert): both passes must deal every record to the same
+    tier whatever order the waves run in.  Five indexes of the same C5 panel on fresh contexts: same bits, same keys."""
+    panel = synth.indel_panel(20_000, seed=77)
+    k, bits = 35, 1 << 26
+    args = oracle_blocks(panel, k)
+    obf, omap = ocapi.BF(bits), ocapi.KMAP()
+    ocapi.index_blocks(obf, omap, panel.genome, **args, haploid=False, k=k)
+    obf.switch_mode()
+    want_bits, want_keys = obf.set_positions(), sorted(k_ for k_, _ in omap.items())
+    for _ in range(5):
+        with Context(k, 63, bits) as ctx:
+            ctx.reference_upload(panel.genome)
+            rp = ResidentPanel(panel, 0, haploid=False)
+            assert rp.index(ctx).sum() == 0
+            ctx.bf_finalize(BF_ALT)
+            assert np.array_equal(ctx.bf_export_sparse(BF_ALT)[2], want_bits)
+            assert sorted(ctx.map_export()[0]) == want_keys
 
 
 @pytest.mark.parametrize("haploid", [False, True])

@@ -285,3 +285,44 @@ def test_scan_in_many_chunks(form, chunk_log2):
             assert ctx.get_option("scan_tickets") >= 2
         if form == "partition":
             assert ctx.get_option("scan_bins") >= 2
+
+
+@pytest.mark.parametrize("k,ref_k", [(35, 43), (35, 63), (31, 42), (21, 29), (64, 64), (17, 18), (33, 64)])
+def test_ref_scan_dense_hits_packed_resident_and_bytewise(k, ref_k):
+    """H11 (main.cpp:383-401) with MANY hits, so that the context insert is exercised as much as the centre test: `bf` holds
+    every 7th k-mer of the reference itself.  Three ways -- the host contig (packed on the fly), the contig inside the
+    resident reference at a non-zero, unaligned offset (mg_ref_scan_resident), and the byte-wise kernel for every window
+    (use_packed_ref_scan = 0) -- against the oracle: N runs, IUPAC codes, odd ref_k - k (the reference's sliding quirk in the
+    first k windows), a contig end."""
+    bits = (1 << 22) + 5
+    rng = np.random.default_rng(k * 100 + ref_k)
+    g = synth.random_genome(260_000, 99 + k).copy()
+    g[1000:1400] = ord("N")
+    for p in rng.integers(2000, len(g) - 2000, size=400):
+        g[p] = rng.choice(np.frombuffer(b"NWMRYK", dtype=np.uint8))
+    g[-5:] = ord("N")
+    text = g.tobytes()
+    rows = np.zeros((len(range(0, len(g) - k, 7)), 72), dtype=np.uint8)
+    for i, p in enumerate(range(0, len(g) - k, 7)):
+        rows[i, :k] = g[p:p + k]
+    obf, octx = ocapi.BF(bits), ocapi.BF(bits)
+    ocapi.add_kmers(obf, ocapi.KMAP(), rows, np.zeros(rows.shape[0], dtype=np.uint8))
+    obf.switch_mode()
+    ocapi.ref_scan(obf, octx, text, k, ref_k)
+    want = octx.set_positions()
+    assert len(want) > 20_000
+    prefix = synth.random_genome(12_345, 5).tobytes()          # another sequence in front: the contig starts at an odd offset
+    for mode in ("host", "resident", "bytewise"):
+        with Context(k, ref_k, bits) as ctx:
+            if mode == "bytewise":
+                ctx.set_option("use_packed_ref_scan", 0)
+            ctx.bf_insert(BF_ALT, rows)
+            ctx.bf_finalize(BF_ALT)
+            if mode == "resident":
+                ctx.reference_upload(prefix + text)
+                ctx.ref_scan_resident(len(prefix), len(text))
+            else:
+                ctx.ref_scan(text)
+            ctx.bf_finalize(BF_CTX)
+            got = ctx.bf_export_sparse(BF_CTX)[2]
+            assert np.array_equal(got, want), mode
