@@ -615,7 +615,11 @@ int index_main(const Options &o)
         auto it = refs.seqs.find(name);
         static const std::string empty;
         const std::string &seq = it == refs.seqs.end() ? empty : it->second;
-        dev.check(mg_ref_scan(dev.ctx, seq.data(), seq.size()), "mg_ref_scan");
+        auto cb = contig_base.find(name);
+        if (cb != contig_base.end()) // the contig is already in HBM (mg_reference_upload above): nothing crosses PCIe again
+            dev.check(mg_ref_scan_resident(dev.ctx, cb->second, seq.size()), "mg_ref_scan_resident");
+        else
+            dev.check(mg_ref_scan(dev.ctx, seq.data(), seq.size()), "mg_ref_scan");
     }
     pelapsed("Reference BF creation complete");
     dev.check(mg_bf_finalize(dev.ctx, MG_BF_CTX), "mg_bf_finalize(context_bf)"); // main.cpp:404

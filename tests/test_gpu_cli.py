@@ -2,6 +2,7 @@
 (bin/malva-geno over libmalva_hip.so) against the reference's golden VCF and against the oracle
 pipeline on clustered synthetic panels."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -57,7 +58,7 @@ def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref
     run_cli(["index"] + args)
     got = run_cli(["call"] + args)
     assert got.count("\n") == want.count("\n")
-    strip = lambda s: "\n".join(";".join(p for p in l.split(";") if not p.startswith("GTS=")) if "GTS=" in l else l for l in s.split("\n"))
+    strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)         # (the likelihood list only: COVS before it and GT:GQ behind it stay)
     assert strip(got) == strip(want)                 # header, records, COVS, GT, GQ: identical
     if got != want:                                   # GTS holds printf("%f") of doubles that may differ in the last bit of exp()
         for a, b in zip(got.split("\n"), want.split("\n")):
@@ -266,3 +267,56 @@ def test_bcf_panel_gives_the_same_records_as_the_vcf(tmp_path, golden_dir):
     recs = lambda s: [l for l in s.split("\n") if l and not l.startswith("##")]
     want = open(os.path.join(golden_dir, "haploid.malva.vcf")).read()        # the reference's own golden
     assert recs(out) == recs(want) and len(recs(out)) == 419
+
+
+@pytest.mark.parametrize("what", ["samples", "uniform", "error_cov", "freq_key", "all"])
+def test_cli_options_match_oracle(tmp_path, what):
+    """The options of argument_parser.hpp:86-159 no other test passes, each against oracle/pipeline.py byte for byte:
+    -s <file>  a subset of the panel's samples, kept in VCF order whatever the file's order (main.cpp:264-272, 434-440: the
+               index AND the call see only those samples' genotypes, so other alleles carry signatures);
+    -u         uniform allele frequencies (variant.hpp:148-152; no record is then 'not present' through its frequencies);
+    -e / -c    error rate and the coverage cap of VB::genotype (var_block.hpp:236-248: over-covered alleles -> 0/0:0);
+    -f EUR_AF  another INFO key than AF (BASELINE config C2's flag) on a panel that carries both with different values."""
+    seed, k, ref_k = 91, 35, 43
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=False, k=k, n_clusters=60, vcf_strip_chr=True, n_samples=7, second_freq_key="EUR_AF")
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, ref_k, seed, table + ".txt")
+    opt = pipeline.Options(haploid=False, verbose=True, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
+    args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p", "-v"]
+    if what in ("samples", "all"):
+        sfile = str(tmp_path / "keep.txt")
+        with open(sfile, "w") as fh:
+            fh.write("S5\nS1\n\nS2\n")                                # not the VCF's order, a blank line
+        opt.samples = sfile
+        args += ["-s", sfile]
+    if what in ("uniform", "all"):
+        opt.uniform = True
+        args += ["-u"]
+    if what in ("error_cov", "all"):
+        opt.error_rate, opt.max_coverage = 0.01, 8
+        args += ["-e", "0.01", "-c", "8"]
+    if what in ("freq_key", "all"):
+        opt.freq_key = "EUR_AF"
+        args += ["-f", "EUR_AF"]
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+    want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+    args += [prefix + ".fa", prefix + ".vcf", table]
+    run_cli(["index"] + args)
+    got = run_cli(["call"] + args)
+    strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)         # (the likelihood list only: COVS before it and GT:GQ behind it stay)
+    assert strip(got) == strip(want)                 # header, records, COVS, GT, GQ: identical
+    for a, b in zip(got.split("\n"), want.split("\n")):   # GTS: printf("%f") of doubles, within the contract's 1e-6
+        if a != b:
+            fa = [float(x.split(":")[1]) for x in a.split("GTS=")[1].split("\t")[0].split(",")]
+            fb = [float(x.split(":")[1]) for x in b.split("GTS=")[1].split("\t")[0].split(",")]
+            assert all(abs(x - y) <= 1.000001e-6 or (x != x and y != y) for x, y in zip(fa, fb)), (a, b)
+    recs = [l for l in got.split("\n") if l and not l.startswith("#")]
+    assert sum(1 for l in recs if not l.endswith(":0")) > 20
+    if what == "error_cov":
+        assert any(l.endswith("\t0/0:0") and "COVS=" in l and max(int(x) for x in l.split("COVS=")[1].split(";")[0].split(",")) > 8 for l in recs), "no record exercised the coverage cap"
+    # and the option really changes the result (the test would pass vacuously if the flag were ignored by both sides)
+    base_opt = pipeline.Options(haploid=False, verbose=True, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
+    base = pipeline.call(prefix + ".fa", prefix + ".vcf", pipeline.index(prefix + ".fa", prefix + ".vcf", base_opt), kmers, base_opt)
+    assert strip(base) != strip(want)

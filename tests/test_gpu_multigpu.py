@@ -203,3 +203,25 @@ def test_context_before_torch_import_then_shared_stream(tmp_path):
     script.write_text(_ORDER_SCRIPT)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ORDER_OK" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("workload,extra", [("c3", ["--kmers", "2e6", "--variants", "2e4"]), ("c5", ["--kmers", "1e6", "--clusters", "3e3"])])
+def test_bench_self_launch_two_ranks_on_one_gpu(workload, extra):
+    """plain `python bench.py --gpus 2` (no launcher): the ranks are started by bench.py itself; on a one-GPU box they share
+    the device and reduce over gloo (--rehearse-on-one-gpu).  ONE JSON line comes out, for two ranks, with the table rows and
+    the record loop split between them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", workload, "--steps", "2",
+                        "--warmup", "1", "--cpu-sample", "0", "--sustained-s", "0.2"] + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["config"]["kmers_total"] == 2 * d["config"]["kmers_per_gpu"]
+    assert d["config"]["variants_genotyped_per_gpu"] < d["config"]["panel_variants"]
+    assert d["overflow_records"] == 0

@@ -4,7 +4,9 @@ genotypes, a non-present record, records near contig ends, two contigs, N/IUPAC 
 import numpy as np
 
 
-def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False, dense=False):
+def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35, vcf_strip_chr=False, dense=False, second_freq_key=None):
+    """second_freq_key: INFO carries AF and a second key (e.g. EUR_AF, BASELINE config C2's `-f EUR_AF`) with OTHER values,
+    sometimes zero where AF is not (so is_present differs between the keys) and sometimes before AF in the INFO column"""
     rng = np.random.default_rng(seed)
     contigs = {}
     scale = max(1, n_clusters // 40)
@@ -41,8 +43,9 @@ def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35
                 records.append((name, pos, ref, alts))
     records.sort(key=lambda r: (list(contigs).index(r[0]), r[1]))
     samples = ["S%d" % i for i in range(n_samples)]
-    lines = ["##fileformat=VCFv4.2", '##INFO=<ID=AF,Number=A,Type=Float,Description="af">',
-             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">'] + \
+    lines = ["##fileformat=VCFv4.2", '##INFO=<ID=AF,Number=A,Type=Float,Description="af">'] + \
+            (['##INFO=<ID=%s,Number=A,Type=Float,Description="second af">' % second_freq_key] if second_freq_key else []) + \
+            ['##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">'] + \
             ["##contig=<ID=%s,length=%d>" % (n, len(s)) for n, s in contigs.items()]
     lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples))
     for i, (name, pos, ref, alts) in enumerate(records):
@@ -63,8 +66,14 @@ def make_case(path_prefix, seed, n_clusters=40, haploid=False, n_samples=5, k=35
         qual = "." if i % 3 else "%d" % (10 + i % 90)
         if vcf_strip_chr and name.startswith("chr"):
             name = name[3:]                     # matches the FASTA id only under -p/--strip-chr
-        lines.append("%s\t%d\t%s\t%s\t%s\t%s\t.\tAF=%s\tGT\t%s" % (name, pos + 1, "." if i % 4 else "rs%d" % i, ref, ",".join(alts), qual,
-                                                                  ",".join("%g" % x for x in af), "\t".join(gts)))
+        info = "AF=%s" % ",".join("%g" % x for x in af)
+        if second_freq_key:
+            w2 = rng.dirichlet(np.ones(len(alts) + 1))[1:]
+            af2 = [0.0] * len(alts) if i % 17 == 3 else [round(float(x), 4) for x in w2]
+            second = "%s=%s" % (second_freq_key, ",".join("%g" % x for x in af2))
+            info = second + ";" + info if i % 2 else info + ";DP=%d;" % (i % 50) + second
+        lines.append("%s\t%d\t%s\t%s\t%s\t%s\t.\t%s\tGT\t%s" % (name, pos + 1, "." if i % 4 else "rs%d" % i, ref, ",".join(alts), qual,
+                                                               info, "\t".join(gts)))
     with open(path_prefix + ".vcf", "w") as fh:
         fh.write("\n".join(lines) + "\n")
     with open(path_prefix + ".fa", "w") as fh:
