@@ -1291,6 +1291,19 @@ int pipeline_ready(mg_ctx *c)
 constexpr size_t HOST_PIECE = 1u << 24; // rows per staged piece: 320 MB of SoA rows per slot
 } // namespace
 
+namespace {
+// Host-fed scans leave DMA from the caller's buffers in flight on copy_stream: whatever way the call ends, both streams are
+// drained before the caller (who may free or unmap the source on an error) sees the result.
+struct StreamsDrained {
+    mg_ctx *c;
+    ~StreamsDrained()
+    {
+        if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+        hipStreamSynchronize(c->stream);
+    }
+};
+} // namespace
+
 MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n)
 {
     const DeviceGuard on_device(c);
@@ -1299,6 +1312,7 @@ MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, con
     if (!hi || !lo || !cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     TRY(pipeline_ready(c));
+    const StreamsDrained drained{c};
     const size_t cap = n < HOST_PIECE ? n : HOST_PIECE;
     void *d[2][3];
     for (int sl = 0; sl < 2; ++sl)
@@ -1374,6 +1388,7 @@ MG_EXPORT int mg_kmc_scan_records(mg_ctx *c, const void *records, size_t n, uint
     if (!c->d_kmc_lut) return fail(c, MG_ERR_STATE, "mg_kmc_set_lut first");
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     TRY(pipeline_ready(c));
+    const StreamsDrained drained{c};
     const size_t rs = c->kmc_suffix_bytes + c->kmc_counter_bytes;
     const size_t cap = n < HOST_PIECE ? n : HOST_PIECE;
     void *d[2][3], *raw[2];
@@ -1687,7 +1702,10 @@ MG_EXPORT int mg_comm_init_all(mg_ctx **ctxs, int n)
         const ncclResult_t ge = R->GroupEnd();
         if (prev >= 0) hipSetDevice(prev);
         if (bad != ncclSuccess || ge != ncclSuccess) {
-            for (int i = 0; i < n; ++i) ctxs[i]->comm = nullptr;
+            for (int i = 0; i < n; ++i) { // communicators the group did create are destroyed, not dropped
+                if (ctxs[i]->comm) R->CommDestroy(ctxs[i]->comm);
+                ctxs[i]->comm = nullptr;
+            }
             return fail(ctxs[0], MG_ERR_COMM, "ncclCommInitRank x%d: %s", n, R->GetErrorString(bad != ncclSuccess ? bad : ge));
         }
         for (int i = 0; i < n; ++i) {

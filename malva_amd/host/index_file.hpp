@@ -42,10 +42,22 @@ struct IndexPayload {
 };
 
 // ---- reference container -----------------------------------------------------------------------------------------
+// The image carries libzstd's runtime system-wide and its header only under /opt/conda (Makefile): the two may be different
+// releases.  The streaming calls used here (ZSTD_compressStream2, ZSTD_CCtx_setParameter, ZSTD_decompressStream) are stable
+// since 1.4.0 with an unchanged ABI inside major version 1; anything else is refused at the first use instead of
+// misbehaving somewhere inside a frame.
+inline void zstd_check()
+{
+    const unsigned rt = ZSTD_versionNumber();
+    if (rt / 10000 != ZSTD_VERSION_MAJOR || rt < 10400)
+        throw std::runtime_error("libzstd " + std::string(ZSTD_versionString()) + " at run time, header " + std::to_string(ZSTD_VERSION_MAJOR) + "." +
+                                 std::to_string(ZSTD_VERSION_MINOR) + "." + std::to_string(ZSTD_VERSION_RELEASE) + ": need the same major version, 1.4.0 or later");
+}
 class ZstdWriter {
   public:
     explicit ZstdWriter(const std::string &path) : out_(ZSTD_CStreamOutSize())
     {
+        zstd_check();
         f_ = fopen(path.c_str(), "wb");
         if (!f_) throw std::runtime_error("cannot write " + path);
         c_ = ZSTD_createCCtx();
@@ -91,6 +103,7 @@ class ZstdReader { // like zstd::ifstream, a file that is not a zstd frame is re
   public:
     explicit ZstdReader(const std::string &path) : in_(ZSTD_DStreamInSize()), out_(ZSTD_DStreamOutSize() * 8)
     {
+        zstd_check();
         f_ = fopen(path.c_str(), "rb");
         if (!f_) throw std::runtime_error("cannot open index " + path);
         d_ = ZSTD_createDCtx();

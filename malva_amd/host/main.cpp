@@ -51,7 +51,8 @@ const char *USAGE =
     "      -v, --verbose                     output COVS and GTS in INFO column (default: false)\n"
     "      -1, --haploid                     run MALVA in haploid mode (default: false)\n"
     "      -d, --device                      first GPU to run on (default:0)                     [this build]\n"
-    "      -g, --gpus                        GPUs to use, devices -d .. -d+N-1 (default:1)       [this build]\n"
+    "      -g, --gpus                        GPUs to use, devices -d .. -d+N-1 (default:1)       [this build; N > 1 has run\n"
+    "                                        only with all contexts on ONE device: untested on multi-GPU hardware]\n"
     "                                        call: the k-mer table is sharded over them, the per-allele counters\n"
     "                                        are all-reduced over RCCL, the variants are split between them\n"
     "\n"
@@ -337,13 +338,21 @@ void save_index(Device &dev, const Options &o)
     p.vals.resize(nkeys);
     if (nkeys) dev.check(mg_map_export(dev.ctx, p.rows.data(), STRIDE, p.vals.data()), "mg_map_export");
     const char *fmt = getenv("MALVA_GENO_INDEX_FORMAT");
-    if (fmt && std::string(fmt) == "hipz") {
-        save_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size);
-        unlink(index_path(o, ".zst").c_str()); // `call` prefers .zst: do not leave a stale one beside the new index
-    } else {
-        save_index_zst(index_path(o, ".zst"), p, o.bf_size);
-        unlink(index_path(o, ".hipz").c_str());
+    // written under a temporary name and renamed: a run that dies mid-write leaves no truncated index for `call` to prefer
+    const bool hipz = fmt && std::string(fmt) == "hipz";
+    const std::string final_path = index_path(o, hipz ? ".hipz" : ".zst"), tmp_path = final_path + ".tmp." + std::to_string((long)getpid());
+    try {
+        if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size);
+        else save_index_zst(tmp_path, p, o.bf_size);
+    } catch (...) {
+        unlink(tmp_path.c_str());
+        throw;
     }
+    if (rename(tmp_path.c_str(), final_path.c_str()) != 0) {
+        unlink(tmp_path.c_str());
+        throw std::runtime_error("cannot write " + final_path);
+    }
+    unlink(index_path(o, hipz ? ".zst" : ".hipz").c_str()); // (`call` prefers .zst: no stale index of the other kind beside the new one)
 }
 
 // every device of a multi-GPU call holds the whole index (the read-only structures are replicated):
