@@ -112,8 +112,9 @@ constexpr int LONE_TILES = 8; // tiles of TPB / 2 records a workgroup of panel_l
                               // a returning atomic per wave on ONE counter serialises at ~10 ns each -- 3 ms per 5e6 records)
 template <bool SLOW>
 __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
-                                                         const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 *cov_out,
-                                                         u32 *need_slow, u32 call_no, u32 *gen_list, unsigned long long *counters)
+                                                         const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, const u8 *pool, int k,
+                                                         int haploid, BFView bf, MapView map, u32 *cov_out, u32 *need_slow, u32 call_no, u32 *gen_list,
+                                                         unsigned long long *counters)
 {
     __shared__ u32 sh_gen[LONE_TILES * TPB / 2];
     __shared__ u32 sh_n, sh_sigs;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars
             if (!c.lone) sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
             else sigs += (u32)__popcll(c.mask);
         }
-        if (c.lone) iso_cover_body<SLOW>(reference, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
+        if (c.lone) iso_cover_body<SLOW>(reference, ref2, refbad, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
     }
     if (SLOW) return;
     for (int d = 32; d; d >>= 1) sigs += __shfl_xor(sigs, d, 64);

@@ -201,6 +201,11 @@ struct BFView {
     // the coarse gate pay the (HBM / Infinity Cache) line of the fine one.
     u64 *pregate;
     u64 *pregate_fill; // the same array whenever it is allocated: inserts always fill it, `pregate` says whether probes use it
+    // `context_bf` only, call time: the positions of its set bits as an open-addressing set (position + 1, 0 = free).  A
+    // whole-genome context filter is 16 GiB of bits of which a few million are set: the scan's hit kernel asks the set
+    // (tens of MB: no page of it ever leaves the TLBs) instead of a random word of the bit array (a page walk per row)
+    const u64 *pos_set;
+    u32 pos_set_log2;
     ModDesc mod;
     u32 gate_shift;
     u32 gate_k;   // bits per entry, 1..4
@@ -209,6 +214,19 @@ struct BFView {
     u32 use_gate;
 };
 __device__ __forceinline__ bool bf_bit(const BFView &b, u64 idx) { return (b.words[idx >> 6] >> (idx & 63)) & 1; }
+// the same answer from the set of set positions, where the view carries one
+__device__ __forceinline__ bool bf_bit_via_set(const BFView &b, u64 idx)
+{
+    if (!b.pos_set) return bf_bit(b, idx);
+    const u64 mask = (1ULL << b.pos_set_log2) - 1;
+    u64 s = (idx * 0x9E3779B97F4A7C15ULL) >> (64 - b.pos_set_log2);
+    for (;;) {
+        const u64 v = b.pos_set[s];
+        if (v == idx + 1) return true;
+        if (v == 0) return false;
+        s = (s + 1) & mask;
+    }
+}
 // low 32 bits of the product of the low 24 bits of a and c (full rate; the compiler keeps v_mul_lo_u32 for
 // __umul24 when it cannot see the operand's width)
 __device__ __forceinline__ u32 mul24(u32 a, u32 c)
@@ -348,6 +366,101 @@ __device__ __forceinline__ long long bucket_rank(const MapView &m, u64 idx)
         if (b1 == want) return (long long)b.w;
         if (b0 == 0 || b1 == 0) return -1;
         s = (s + 1) & mask;
+    }
+}
+// A wave's 64 home records, fetched by ROUNDS of four lanes per record (16 bytes each, three of the four) instead of three
+// 16-byte loads per lane: 4 wave-wide load instructions touching 16 records each, against 3 touching 64.  At whole-genome
+// scale the record table is 17-34 GB, every lane of a wave lands on another page, and each load instruction of each lane
+// costs a translation request that misses the per-CU TLB (profiles/r03_pmc_c4share_before.txt: UTCL1 miss rate 0.65, UTCL2 busy
+// 93 % of scan_probe_kernel's time -- the kernel was bound by address translation, not by HBM).  Every lane of the wave must
+// call this; `s` = the lane's record, ignored where !active.  Returns the record's first 48 bytes.
+__device__ __forceinline__ uint4 shfl_u4(uint4 v, int src)
+{
+    return uint4{(u32)__shfl((int)v.x, src, 64), (u32)__shfl((int)v.y, src, 64), (u32)__shfl((int)v.z, src, 64), (u32)__shfl((int)v.w, src, 64)};
+}
+__device__ __forceinline__ void records_load_coop(const MapView &m, u64 s, bool active, uint4 *a, uint4 *b, uint4 *c)
+{
+    const int lane = threadIdx.x & 63;
+    const int part = lane & 3, q = lane >> 2;
+    uint4 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { // all four rounds' loads are requested before any is used
+        const int src = 16 * t + q; // the lane whose record this lane helps fetch in round t
+        const u32 lo = (u32)__shfl((int)(u32)s, src, 64), hi = (u32)__shfl((int)(u32)(s >> 32), src, 64);
+        const bool act = __shfl((int)active, src, 64) != 0;
+        v[t] = uint4{0u, 0u, 0u, 0u};
+        if (act && part < 3) v[t] = reinterpret_cast<const uint4 *>(&m.slots[(u64)lo | ((u64)hi << 32)])[part];
+    }
+    uint4 ra{0u, 0u, 0u, 0u}, rb = ra, rc = ra;
+    const int mine = 4 * (lane & 15); // as an owner: my record's parts sit in lanes mine .. mine + 2 of round lane / 16
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint4 p0 = shfl_u4(v[t], mine), p1 = shfl_u4(v[t], mine + 1), p2 = shfl_u4(v[t], mine + 2);
+        if ((lane >> 4) == t) {
+            ra = p0;
+            rb = p1;
+            rc = p2;
+        }
+    }
+    *a = ra;
+    *b = rb;
+    *c = rc;
+}
+// bucket_probe with the home records fetched cooperatively (every lane of the wave calls it; `active` = the lane has a row)
+__device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u64 h, u64 idx, bool active, long long *map_id, long long *rank)
+{
+    const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
+    u64 s = map_home(m, idx);
+    const u32 tag = map_tag(h);
+    bool map_open = active, bf_open = active;
+    *map_id = -1;
+    *rank = -1;
+    uint4 a, b, c;
+    records_load_coop(m, s, active, &a, &b, &c);
+    for (;;) {
+        if (map_open) {
+            if (a.x == 0) map_open = false;
+            else if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) {
+                *map_id = (long long)a.y;
+                map_open = false;
+            }
+        }
+        if (bf_open) {
+            const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+            if (b0 == want) {
+                *rank = (long long)b.z;
+                bf_open = false;
+            } else if (b1 == want) {
+                *rank = (long long)b.w;
+                bf_open = false;
+            } else if (b0 == 0 || b1 == 0)
+                bf_open = false;
+        }
+        if (!map_open && !bf_open) return;
+        s = (s + 1) & mask; // (one lane in five goes on to the next record: nearly always the same page)
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        a = p[0];
+        b = p[1];
+        c = p[2];
+    }
+}
+// bucket_rank likewise
+__device__ __forceinline__ long long bucket_rank_coop(const MapView &m, u64 idx, bool active)
+{
+    const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
+    u64 s = map_home(m, idx);
+    uint4 a, b, c;
+    records_load_coop(m, s, active, &a, &b, &c);
+    if (!active) return -1;
+    for (;;) {
+        const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+        if (b0 == want) return (long long)b.z;
+        if (b1 == want) return (long long)b.w;
+        if (b0 == 0 || b1 == 0) return -1;
+        s = (s + 1) & mask;
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        b = p[1];
+        c = p[2];
     }
 }
 // Both questions of the scan's probe in one walk (the two chains share their records).

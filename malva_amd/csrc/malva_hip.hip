@@ -52,6 +52,9 @@ struct BFState {
     u64 *gate = nullptr; // only `bf` (MG_BF_ALT) owns one
     u64 n_gate_bits = 0;
     u32 gate_shift = 6;
+    u64 *pos_set = nullptr; // `context_bf`, call time: its set positions as a hash set (BFView::pos_set); built at the first scan
+    u32 pos_set_log2 = 0;
+    bool pos_set_valid = false;
     u64 *pregate = nullptr; // coarse L2-sized gate in front of a gate that outgrew L2
     u32 pre_shift = 6;
     int mode = 0;
@@ -83,6 +86,8 @@ struct mg_ctx {
     bool blocks_stats_valid = false;
     int blocks_grid[3] = {0, 0, 0};            // persistent grid of cover_blocks_kernel<MODE> (found at first use)
     int use_flat_tier = 1;                     // 0: every general record takes the workgroup kernel (A/B, tests)
+    int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
+    int use_ctx_set = 1;                       // 1: large context filters answer the scan's hit kernel from the set of their set positions (A/B)
     int use_packed_ref_scan = 1;               // 0: the byte-wise reference scan for every window (A/B, tests)
     unsigned long long *d_hit_count = nullptr;
     double *d_ln = nullptr;
@@ -229,6 +234,8 @@ BFView view(const mg_ctx *c, int which)
     v.pre_shift = b.pre_shift;
     v.pre_k = (u32)c->pre_k;
     v.use_gate = (c->use_summary && b.gate) ? 1 : 0;
+    v.pos_set = b.pos_set_valid ? b.pos_set : nullptr;
+    v.pos_set_log2 = b.pos_set_log2;
     return v;
 }
 MapView view(const mg_ctx *c)
@@ -339,6 +346,14 @@ int map_reserve(mg_ctx *c, u64 extra)
     const u64 dir_entries = alt.mode ? alt.nset : 0;
     u32 want = 10;
     while ((1ULL << want) < need_rows * 4 || (1ULL << want) < dir_entries * 2) ++want;
+    if (want > 26 && c->map_dense) {
+        // Beyond 2^26 records (4 GB) what a probe costs is the PAGE it lands on, not the length of its walk: at whole-genome scale
+        // scan_probe_kernel spent its time in address translation (UTCL2 busy 93 %, profiles/r03_pmc_c4share_before.txt), and the next
+        // record of a walk is nearly always on the same page.  Half the table: key load <= 1/2, directory load <= 1/2.
+        u32 w2 = 26;
+        while ((1ULL << w2) < need_rows * 2 || (1ULL << w2) < dir_entries) ++w2;
+        if (w2 < want) want = w2;
+    }
     if (!m.slots) {
         TRY(map_alloc(c, m, want));
         return build_bf_entries(c);
@@ -542,6 +557,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
         hipFree(b.counts);
         hipFree(b.gate);
         hipFree(b.pregate);
+        hipFree(b.pos_set);
     }
     map_free_table(c->map);
     hipFree(c->map.vals);
@@ -597,6 +613,11 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_pregate")) c->use_pregate = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
+    else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
+    else if (!strcmp(name, "use_ctx_set")) {
+        c->use_ctx_set = (int)value; // (2: whatever the filter's size -- tests)
+        c->bf[MG_BF_CTX].pos_set_valid = false;
+    }
     else if (!strcmp(name, "use_packed_ref_scan")) c->use_packed_ref_scan = value != 0;
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
@@ -641,6 +662,9 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
     else if (!strcmp(name, "use_partition")) *value = c->use_partition;
     else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
+    else if (!strcmp(name, "map_dense")) *value = c->map_dense;
+    else if (!strcmp(name, "use_ctx_set")) *value = c->use_ctx_set;
+    else if (!strcmp(name, "ctx_set_log2")) *value = c->bf[MG_BF_CTX].pos_set_valid ? c->bf[MG_BF_CTX].pos_set_log2 : 0;
     else if (!strcmp(name, "use_packed_ref_scan")) *value = c->use_packed_ref_scan;
     else if (!strcmp(name, "gate_log2")) *value = c->gate_log2;
     else if (!strcmp(name, "gate_k")) *value = c->gate_k;
@@ -666,6 +690,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
 
 MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride, size_t n)
 {
+    if (c && (which == MG_BF_ALT || which == MG_BF_CTX)) c->bf[which].pos_set_valid = false; // (the bits are about to change)
     const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
@@ -693,6 +718,7 @@ MG_EXPORT int mg_debug_bf_index(mg_ctx *c, int which, const char *rows, size_t s
 
 MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
 {
+    if (c && (which == MG_BF_ALT || which == MG_BF_CTX)) c->bf[which].pos_set_valid = false;
     const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
@@ -936,6 +962,7 @@ int ref_scan_windows(mg_ctx *c, const u8 *d_ascii, const u64 *ref2, const u32 *r
 }
 int ref_scan_checks(mg_ctx *c, size_t len)
 {
+    c->bf[MG_BF_CTX].pos_set_valid = false;
     if (!c->bf[MG_BF_ALT].mode) return fail(c, MG_ERR_STATE, "mg_ref_scan needs `bf` finalised (main.cpp:378 precedes :383)");
     if (c->bf[MG_BF_CTX].mode) return fail(c, MG_ERR_STATE, "context filter already finalised");
     const size_t off = (c->ref_k - c->k) / 2;
@@ -1005,6 +1032,26 @@ MG_EXPORT int mg_ref_scan_resident(mg_ctx *c, uint64_t offset, size_t len)
 // ---- KMC scan ----------------------------------------------------------------------------
 
 namespace {
+// `context_bf` for the hit kernel: its set positions as a hash set, (re)built at the first scan after the bits changed
+int ctx_set_ready(mg_ctx *c)
+{
+    BFState &b = c->bf[MG_BF_CTX];
+    if (b.pos_set_valid) return MG_OK;
+    // worth it where the bit array is far larger than the set: filters of 2^31 bits and more (256 MB) holding few bits
+    u32 log2 = 10;
+    while ((1ULL << log2) < 2 * b.nset + 16) ++log2;
+    const bool want = c->use_ctx_set == 2 || (c->use_ctx_set == 1 && b.size >= (1ULL << 31) && (8ULL << log2) * 4 <= b.size / 8);
+    if (!want) return MG_OK;
+    if (b.pos_set) hipFree(b.pos_set);
+    b.pos_set = nullptr;
+    HIP_TRY(c, hipMalloc(&b.pos_set, 8ULL << log2));
+    HIP_TRY(c, hipMemsetAsync(b.pos_set, 0, 8ULL << log2, c->stream));
+    hipLaunchKernelGGL(pos_set_build_kernel, dim3(nblocks(b.nwords)), dim3(TPB), 0, c->stream, (const u64 *)b.words, b.nwords, b.pos_set, log2);
+    HIP_TRY(c, hipGetLastError());
+    b.pos_set_log2 = log2;
+    b.pos_set_valid = true;
+    return MG_OK;
+}
 // ---- the ticket form's host side ---------------------------------------------------------------------------------------
 u64 ticket_slices(mg_ctx *c) // slices of half the L2-resident size (2 MiB) the fine gate splits into
 {
@@ -1129,6 +1176,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     if (n == 0) return MG_OK;
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.slots) TRY(map_reserve(c, 0));
+    TRY(ctx_set_ready(c));
     // large index: tickets by gate slice (takes precedence over the row-moving partition below)
     const BFState &alt = c->bf[MG_BF_ALT];
     const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6); // slices of half the L2-resident size: 2 MiB
@@ -1246,6 +1294,7 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     if (n == 0) return MG_OK;
     if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(c, MG_ERR_ARG, "packed rows must be 16-byte aligned");
     if (!c->map.slots) TRY(map_reserve(c, 0));
+    TRY(ctx_set_ready(c));
     u32 row_bits = 27;
     const bool tickets = ticket_form(c, &row_bits);
     const u64 chunk = std::max<u64>(4, 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2)); // (a multiple of 4 rows: chunks start on whole quads)
@@ -2141,9 +2190,11 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     u32 *need_slow = (u32 *)(c->d_hit_count + 3);
     if (++c->iso_call_no == 0) c->iso_call_no = 1;
     hipLaunchKernelGGL(panel_lone_kernel<false>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
-                       (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
+                       (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
+                       c->iso_call_no, R.gen_list, c->d_gen_count);
     hipLaunchKernelGGL(panel_lone_kernel<true>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
-                       (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow, c->iso_call_no, R.gen_list, c->d_gen_count);
+                       (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
+                       c->iso_call_no, R.gen_list, c->d_gen_count);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_b[1], c->stream));
     TRY(blocks_tier2<0>(R, (u32 *)d_cov_out, (u8 *)d_overflow_out, nullptr, 0u, c->d_gen_count + 3));
@@ -2418,11 +2469,11 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
     TRY(fill_geno_params(c, error_rate, max_cov, haploid, &p));
     u32 *need_slow = (u32 *)(c->d_hit_count + 3); // a spare word of the scan's counter block, compared with a call number
     if (++c->iso_call_no == 0) c->iso_call_no = 1;  // (never 0: the scan clears the block) so that nothing has to reset it
-    hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
+    hipLaunchKernelGGL(iso_cover_kernel<false>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
                        (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
                        c->iso_call_no);
-    hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (u64)n_vars,
+    hipLaunchKernelGGL(iso_cover_kernel<true>, dim3(nblocks(2 * (u64)n_vars)), dim3(TPB), 0, c->stream, (const u8 *)c->d_ref, (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (u64)n_vars,
                        (const u64 *)d_pos, (const u32 *)d_var_allele_off, (const u32 *)d_allele_off, (const u8 *)d_allele_pool,
                        (const u64 *)d_present_mask, (const u8 *)d_flags, (int)c->k, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
                        c->iso_call_no);
@@ -2520,6 +2571,7 @@ MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *
 MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *words, const uint16_t *counts,
                            uint64_t n_counts)
 {
+    if (c && (which == MG_BF_ALT || which == MG_BF_CTX)) c->bf[which].pos_set_valid = false;
     const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
@@ -2575,6 +2627,7 @@ MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out,
 MG_EXPORT int mg_bf_import_sparse(mg_ctx *c, int which, int mode, uint64_t size_bits, const uint64_t *positions,
                                   const uint16_t *counts, uint64_t n)
 {
+    if (c && (which == MG_BF_ALT || which == MG_BF_CTX)) c->bf[which].pos_set_valid = false;
     const DeviceGuard on_device(c);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];

@@ -106,6 +106,14 @@ __device__ __forceinline__ u64 ref_codes(const u64 *__restrict__ ref2, u64 start
     if (o) v |= ref2[w + 1] << (64 - o);
     return n >= 32 ? v : v & ((1ULL << (2 * n)) - 1);
 }
+// bit i set: base start + i (i < n <= 32) is outside ACGT
+__device__ __forceinline__ u64 ref_badbits(const u32 *__restrict__ refbad, u64 start, int n)
+{
+    const u64 w = start >> 5;
+    const int o = (int)(start & 31);
+    const u64 b = ((u64)refbad[w] | ((u64)refbad[w + 1] << 32)) >> o;
+    return b & (n >= 32 ? 0xFFFFFFFFULL : ((1ULL << n) - 1));
+}
 // is any of the n <= 32 bases from `start` outside ACGT?
 __device__ __forceinline__ bool ref_bad(const u32 *__restrict__ refbad, u64 start, int n)
 {
@@ -978,8 +986,9 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         if (j < n_open) {
             count = open.cnt[j];
             if (rows12) { // ticket form over compact rows: the list holds row numbers, a row is 12 contiguous bytes (one line, now and then two)
-                const u32 *w = rows12 + 3 * (u64)count;
-                const u32 w0 = __builtin_nontemporal_load(w), w1 = __builtin_nontemporal_load(w + 1), w2 = __builtin_nontemporal_load(w + 2);
+                typedef u32 __attribute__((ext_vector_type(3), aligned(4))) row12_t; // ONE load instruction (global_load_dwordx3): one translation per row
+                const row12_t wv = __builtin_nontemporal_load((const row12_t *)(rows12 + 3 * (u64)count));
+                const u32 w0 = wv.x, w1 = wv.y, w2 = wv.z;
                 const u32 kbits_hi = (u32)(2 * r - 64) & 31; // (33 <= ref_k <= 44 here)
                 m = U128{w0 | (u64)w1 << 32, (u64)(w2 & ((1u << kbits_hi) - 1))};
                 count = w2 >> kbits_hi;
@@ -990,11 +999,14 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
                 m = U128{open.lo[j], open.hi[j]};
                 if (cnt_table) count = __builtin_nontemporal_load(cnt_table + count); // the filter kernel listed the row's index (requested beside the record below)
             }
+        }
+        {
+            const bool live = j < n_open;
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
             long long id, rank; // one record answers both: exact-map key?  bit idx of bf set?
-            bucket_probe(map, c, h, idx, &id, &rank);
+            bucket_probe_coop(map, c, h, idx, live, &id, &rank); // (whole waves: the records are fetched four lanes to a record)
             if (id >= 0) atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
             hit = rank >= 0;
         }
@@ -1012,17 +1024,19 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
     const int off = (r - k) / 2;
     const u64 nh = counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[2] += nh;
-    for (u64 j = (u64)blockIdx.x * TPB + threadIdx.x; j < nh; j += (u64)gridDim.x * TPB) {
-        const U128 m{hits.lo[j], hits.hi[j]};
+    for (u64 base = (u64)blockIdx.x * TPB; base < nh; base += (u64)gridDim.x * TPB) { // (whole waves stay together: the records are fetched cooperatively)
+        const u64 j = base + threadIdx.x;
+        const bool live = j < nh;
+        const U128 m{live ? hits.lo[j] : 0ULL, live ? hits.hi[j] : 0ULL};
         const U128 l = mform_to_lform(m, r);
         const U128 cc = canon_sub(m, l, r, 0, r);
         const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
-        // (the centre k-mer's slot and its block are computed and requested before the context bit is looked at:
+        // (the centre k-mer's slot and its record are computed and requested before the context bit is looked at:
         // both random reads are in flight together)
         const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
-        const long long rank = bucket_rank(map, idx);                     // set for every row of this list
-        if (bf_bit(ctx, cidx)) continue;                                  // context_bf.test_key (main.cpp:496)
-        if (rank >= 0) atomicAdd(&bf.counts[rank], hits.cnt[j]);          // bf.increment (main.cpp:498)
+        const bool in_ctx = live && bf_bit_via_set(ctx, cidx);            // context_bf.test_key (main.cpp:496)
+        const long long rank = bucket_rank_coop(map, idx, live);          // set for every row of this list
+        if (!in_ctx && rank >= 0) atomicAdd(&bf.counts[rank], hits.cnt[j]); // bf.increment (main.cpp:498)
     }
 }
 

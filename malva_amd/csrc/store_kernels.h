@@ -211,6 +211,21 @@ __global__ void __launch_bounds__(TPB) map_dump_kernel(MapView m, u64 *klo, u64 
     ids[j] = m.slots[s].id;
 }
 
+// positions of a filter's set bits into an open-addressing set (BFView::pos_set); `set` zeroed, capacity 2^log2 >= 2 x the bits
+__global__ void __launch_bounds__(TPB) pos_set_build_kernel(const u64 *__restrict__ words, u64 nwords, u64 *set, u32 log2)
+{
+    const u64 w = (u64)blockIdx.x * TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u64 x = words[w];
+    const u64 mask = (1ULL << log2) - 1;
+    while (x) {
+        const u64 pos = w * 64 + (u64)(__ffsll((unsigned long long)x) - 1);
+        x &= x - 1;
+        u64 s = (pos * 0x9E3779B97F4A7C15ULL) >> (64 - log2);
+        while (atomicCAS((unsigned long long *)&set[s], 0ULL, (unsigned long long)(pos + 1)) != 0ULL) s = (s + 1) & mask;
+    }
+}
+
 // ---- finalize: rank directory, counters, summary ---------------------------
 
 // per 512-bit block popcount, exclusive scan inside a tile of TPB blocks

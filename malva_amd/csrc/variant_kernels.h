@@ -132,9 +132,12 @@ __device__ __forceinline__ void span_pack(const SpanWords &s, int n, u64 *codes,
 constexpr u32 ISO_SLOW = 0xFFFFFFFFu; // never a coverage: those are float-rounded counts below 2^31
 // one thread's share (alleles of parity `par`) of a lone variant: `site` = its offset in the uploaded reference,
 // pm = mask of the alleles some panel haplotype carries, live = eligible (var_block.hpp:104)
+// ref2 / refbad: the packed reference (scan_kernels.h); the flanks come out of it in two loads and a shift each, and a
+// 128-byte line of it holds 512 bases (five SNPs of a whole-genome panel share one, against one line of text each)
 template <bool SLOW>
-__device__ __forceinline__ void iso_cover_body(const u8 *reference, u64 site_off, u32 a0, u32 A, bool live, u64 pm_in, u32 par, const u32 *allele_off,
-                                               const u8 *pool, int k, const BFView &bf, const MapView &map, u32 *cov_out, u32 *need_slow, u32 call_no)
+__device__ __forceinline__ void iso_cover_body(const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, u64 site_off, u32 a0, u32 A, bool live,
+                                               u64 pm_in, u32 par, const u32 *allele_off, const u8 *pool, int k, const BFView &bf, const MapView &map, u32 *cov_out,
+                                               u32 *need_slow, u32 call_no)
 {
     const u32 ref_size = allele_off[a0 + 1] - allele_off[a0];
     u32 *cov = cov_out + a0;
@@ -144,10 +147,17 @@ __device__ __forceinline__ void iso_cover_body(const u8 *reference, u64 site_off
     const bool packed_ok = k >= 17 && k <= MG_MAX_PACKED_K;
     // flanks as L-forms: left = ref[pos-lmax, pos), right = ref[pos+ref_size, +rmax)  (<= 32 bases each)
     u64 lf = 0, rf = 0, lbad = 0, rbad = 0;
-    if (!SLOW && packed_ok && live) { // both flanks' dwords requested before either is consumed
-        const SpanWords ls = span_load(site - lmax, lmax), rs = span_load(site + ref_size, rmax);
-        span_pack(ls, lmax, &lf, &lbad);
-        span_pack(rs, rmax, &rf, &rbad);
+    if (!SLOW && packed_ok && live) {
+        if (ref2) { // (bad masks: one bit per base here, four per dword below; both are used as "any bad base in the part taken")
+            lf = ref_codes(ref2, site_off - lmax, lmax);
+            rf = ref_codes(ref2, site_off + ref_size, rmax);
+            lbad = ref_badbits(refbad, site_off - lmax, lmax);
+            rbad = ref_badbits(refbad, site_off + ref_size, rmax);
+        } else { // both flanks' dwords requested before either is consumed
+            const SpanWords ls = span_load(site - lmax, lmax), rs = span_load(site + ref_size, rmax);
+            span_pack(ls, lmax, &lf, &lbad);
+            span_pack(rs, rmax, &rf, &rbad);
+        }
     }
     for (u32 a = par; a < A; a += 2) {
         if (SLOW) {
@@ -207,8 +217,8 @@ __device__ __forceinline__ void iso_cover_body(const u8 *reference, u64 site_off
     }
 }
 template <bool SLOW>
-__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64 n_vars, const u64 *pos, const u32 *var_allele_off,
-                                                        const u32 *allele_off, const u8 *pool, const u64 *present_mask,
+__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, u64 n_vars, const u64 *pos,
+                                                        const u32 *var_allele_off, const u32 *allele_off, const u8 *pool, const u64 *present_mask,
                                                         const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow,
                                                         u32 call_no)
 {
@@ -218,7 +228,7 @@ __global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, u64
     if (v >= n_vars) return;
     const u32 a0 = var_allele_off[v], A = var_allele_off[v + 1] - a0;
     const bool live = flags[v] & 1;
-    iso_cover_body<SLOW>(reference, pos[v], a0, A, live, live ? present_mask[v] : 0, (u32)(t & 1), allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
+    iso_cover_body<SLOW>(reference, ref2, refbad, pos[v], a0, A, live, live ? present_mask[v] : 0, (u32)(t & 1), allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
 }
 
 __global__ void __launch_bounds__(TPB) iso_genotype_kernel(u64 n_vars, const u32 *var_allele_off, const float *freq, GenoParams p,

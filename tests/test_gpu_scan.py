@@ -326,3 +326,32 @@ def test_ref_scan_dense_hits_packed_resident_and_bytewise(k, ref_k):
             ctx.bf_finalize(BF_CTX)
             got = ctx.bf_export_sparse(BF_CTX)[2]
             assert np.array_equal(got, want), mode
+
+
+@pytest.mark.parametrize("use_set", [0, 2])
+def test_context_filter_blocks_rows_with_and_without_the_position_set(use_set):
+    """main.cpp:496-498: a row whose ref_k-mer is in context_bf does NOT increment `bf`.  The table here is made of exactly
+    such rows -- every reference window whose context the index put into context_bf (its centre k-mer hits `bf`: with a
+    small filter, mostly Bloom false positives) -- beside donor windows and random rows, so the hit kernel's context test
+    decides hundreds of rows.  use_ctx_set = 2 answers it from the hash set of context_bf's set positions (what a
+    whole-genome filter does by itself), 0 from the bit array: counters equal the oracle's either way."""
+    k, ref_k, bits = 35, 43, (1 << 20) + 7
+    panel = synth.snp_panel(3000, 5)
+    with Context(k, ref_k, bits) as ctx:
+        ctx.set_option("use_ctx_set", use_set)
+        obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
+        g = panel.genome
+        blocked = [p for p in range(0, len(g) - ref_k + 1) if octx.test_key(g[p:p + ref_k].tobytes())]
+        assert len(blocked) > 300
+        whi, wlo = synth.pack_ascii(synth.windows(g, np.array(blocked), ref_k))
+        hi, lo, cnt = synth.kmer_table(panel, 60000, k, ref_k, seed=9)
+        hi = np.concatenate([hi, whi]); lo = np.concatenate([lo, wlo]); cnt = np.concatenate([cnt, np.full(len(blocked), 7, dtype=np.uint32)])
+        ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        ctx.kmc_scan(hi, lo, cnt)
+        assert (ctx.get_option("ctx_set_log2") > 0) == (use_set == 2)
+        assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
+        assert map_values_by_key(ctx) == dict(omap.items())
+        # the blocked rows alone, on fresh counters: nothing may reach `bf` through them
+        ctx.counters_reset()
+        ctx.kmc_scan(whi, wlo, np.full(len(blocked), 7, dtype=np.uint32))
+        assert not ctx.bf_export(BF_ALT)[3].any()
