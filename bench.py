@@ -79,6 +79,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the sustained leg (back-to-back steps after the timed region; 0 = skip)")
     ap.add_argument("--no-strong-c4", action="store_true", help="N > 1, default workload: skip the strong_c4 leg")
+    ap.add_argument("--no-c5-leg", action="store_true", help="N = 1, default workload: skip the reduced C5 leg (general_blocks_c5 in the JSON line)")
+    ap.add_argument("--c5-leg-clusters", type=float, default=6e4, help="clusters of the reduced C5 leg (6e4 ~ 2.1e5 records)")
+    ap.add_argument("--c5-leg-kmers", type=float, default=2e7)
+    ap.add_argument("--plant-records", type=float, default=None, help="c5: records whose donor windows are planted in the table (host loop; default: 20 %% of the rows' worth)")
     ap.add_argument("--strong-c4-kmers", type=float, default=3e9)
     ap.add_argument("--strong-c4-variants", type=float, default=8e7)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
@@ -127,7 +131,8 @@ def log(rank, *a):
 class Job:
     """One workload on this rank: context, index, resident table and panel, and `step()`."""
 
-    def __init__(self, workload, args, rank, world, local, torch, dist, haploid=False, kmers=None, variants=None, b=None, strong=None):
+    def __init__(self, workload, args, rank, world, local, torch, dist, haploid=False, kmers=None, variants=None, b=None, strong=None, clusters=None,
+                 plant_records=None):
         from malva_amd import BF_ALT, BF_CTX, Context, synth
         from malva_amd.dist import alias_int32, shard_range
         self.workload, self.args, self.rank, self.world, self.torch, self.dist = workload, args, rank, world, torch, dist
@@ -157,7 +162,7 @@ class Job:
             self.n_vars_total = self.panel.n
             genome = self.panel.genome
         else:
-            self.panel = synth.indel_panel(int(args.clusters), seed=20261005, k=K)
+            self.panel = synth.indel_panel(int(args.clusters if clusters is None else clusters), seed=20261005, k=K)
             self.n_vars_total = self.panel.n
             genome = self.panel.genome
         log(rank, "%s panel: %d records on a %.3g-base genome (%.1fs)" % (workload, self.n_vars_total, genome.size, time.time() - t0))
@@ -249,6 +254,10 @@ class Job:
             self.rp = ResidentPanel(sub, dev, haploid=haploid)
             self.n_genotypes = self.rp.n_gt
             plant = max(1, min(self.n_vars, int(self.n_rows * 0.2 / 7.5)))
+            if plant_records is None and args.plant_records is not None:
+                plant_records = args.plant_records
+            if plant_records is not None:
+                plant = max(1, min(plant, int(plant_records)))
             tb = synth.device_table_flat(sub, self.n_rows, K, R, 777 + rank, dev, plant_records=plant)
             self.d_hi, self.d_lo, self.d_cnt = tb["d_hi"], tb["d_lo"], tb["d_cnt"]
             log(rank, "table: %d of the rows are the donor's windows around %d records" % (tb["n_site"], plant))
@@ -697,6 +706,23 @@ def main():
         if rank == 0:
             out["haploid"] = {k_: hout[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "kernels_ms", "roofline", "roofline_blocks", "sustained",
                                                       "calls", "cpu_baseline", "parity_sample", "index_build_s")}
+    if world == 1 and args.workload == "c3" and not args.no_c5_leg and not args.scan_ablate:
+        # BASELINE config C5's shape at a fifth of its bench size, so that the default line carries the general-block path too
+        # (`--workload c5` is the full measurement): diploid and haploid, parity of everything against the oracle
+        leg = {}
+        for hap in (False, True):
+            lj = Job("c5", args, rank, world, local, torch, dist, haploid=hap, kmers=args.c5_leg_kmers, b=8, strong=False, clusters=args.c5_leg_clusters,
+                     plant_records=5e4)
+            el = lj.timed(args.steps, args.warmup)
+            lkt = lj.kernel_times(3)
+            _, _, _, n_ovf = lj.results()
+            rec = record(lj, el, args.steps, args.warmup, lkt, None)
+            cpu, par = cpu_leg(lj, rank) if args.cpu_sample > 0 else (None, None)
+            leg["haploid" if hap else "diploid"] = {
+                "ms_per_step": rec["ms_per_step"], "variants_per_s": rec["variants_per_s"], "value": rec["value"], "kernels_ms": lkt, "roofline_blocks": rec["roofline_blocks"],
+                "overflow_records": n_ovf, "parity_sample": par, "cpu_variants_per_s": cpu and cpu["variants_per_s"], "config": rec["config"]["workload"]}
+            lj.close()
+        out["general_blocks_c5"] = leg
     if world > 1 and args.workload == "c3" and not args.no_strong_c4 and not args.rehearse_on_one_gpu:
         # north_star's whole-genome claim on the same ranks: the 3e9-row table cut N ways against the 8e7-SNP index
         ref1 = None
@@ -705,20 +731,24 @@ def main():
             p1 = os.path.join(ROOT, "profiles", "r02_bench_c4_whole_1gpu.json")
         if os.path.exists(p1):
             ref1 = json.load(open(p1))
-        sj = Job("c4", args, rank, world, local, torch, dist, kmers=args.strong_c4_kmers, variants=args.strong_c4_variants, b=16, strong=True)
-        el = sj.timed(max(2, min(args.steps, 5)), 1)
-        skt = sj.kernel_times(3)
-        _, _, _, n_ovf = sj.results()
-        if rank == 0:
-            st = max(2, min(args.steps, 5))
-            srec = record(sj, el, st, 1, skt, None)
-            out["strong_c4"] = {k_: srec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_blocks")}
-            out["strong_c4"]["overflow_records"] = n_ovf
-            if ref1:
-                out["strong_c4"]["one_gpu_reference"] = {"file": os.path.relpath(p1, ROOT), "ms_per_step": ref1["ms_per_step"],
-                                                         "same_panel_recipe": "r03" in os.path.basename(p1)}
-                out["strong_c4"]["speedup_vs_one_gpu"] = ref1["ms_per_step"] / srec["ms_per_step"]
-        sj.close()
+        try:    # (a failure every rank meets alike -- memory, a refused size -- must not cost the line already measured)
+            sj = Job("c4", args, rank, world, local, torch, dist, kmers=args.strong_c4_kmers, variants=args.strong_c4_variants, b=16, strong=True)
+            el = sj.timed(max(2, min(args.steps, 5)), 1)
+            skt = sj.kernel_times(3)
+            _, _, _, n_ovf = sj.results()
+            if rank == 0:
+                st = max(2, min(args.steps, 5))
+                srec = record(sj, el, st, 1, skt, None)
+                out["strong_c4"] = {k_: srec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_blocks")}
+                out["strong_c4"]["overflow_records"] = n_ovf
+                if ref1:
+                    out["strong_c4"]["one_gpu_reference"] = {"file": os.path.relpath(p1, ROOT), "ms_per_step": ref1["ms_per_step"],
+                                                             "same_panel_recipe": "r03" in os.path.basename(p1)}
+                    out["strong_c4"]["speedup_vs_one_gpu"] = ref1["ms_per_step"] / srec["ms_per_step"]
+            sj.close()
+        except Exception as e:      # noqa: BLE001 -- reported in the line, never silent
+            if rank == 0:
+                out["strong_c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
