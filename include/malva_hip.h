@@ -260,7 +260,16 @@ typedef struct mg_panel_dev {
     const uint32_t *allele_off;      /* [slots + 1] */
     const char *pool;
     const uint8_t *canon;            /* [slots] */
-    const uint16_t *gt;              /* [n_vars][n_samples] */
+    const uint16_t *gt;              /* [n_vars][n_samples] -- or NULL with the sparse form below */
+    /* sparse genotypes (a panel of tens of thousands of samples is nearly all 0|0): record v's entries are
+     * [sp_off[v], sp_off[v + 1]) of sp_sample (ascending sample numbers) / sp_gt (their genotype words); every sample
+     * without an entry carries the word sp_default (1 << 14 = 0|0 phased for a phased panel, 0 = 0/0 for an unphased one:
+     * the phase bit of a homozygous genotype still decides how its sample's OTHER genotypes along a chain combine,
+     * var_block.hpp:758-782, so it is part of the word).  Given (non-NULL sp_off), `gt` is ignored. */
+    const uint32_t *sp_off;          /* [n_vars + 1] or NULL */
+    const uint32_t *sp_sample;
+    const uint16_t *sp_gt;
+    uint32_t sp_default;
 } mg_panel_dev;
 /* The cut (main.cpp:341, 547) of all n_vars records: d_blk_var_off_out ([n_vars + 1] u32), d_n_blocks_out (one u64), and
  * -- optional, NULL to skip -- d_var_block_out ([n_vars] u32: the block of every record, which the two calls below
@@ -279,6 +288,22 @@ int mg_cover_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d
  * twice on eight bytes: the exact map is sized from a counting pass before the insert pass runs. */
 int mg_index_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d_blk_var_off, const void *d_var_block /* or NULL */,
                            const void *d_n_blocks, int haploid, void *d_overflow_out);
+
+/* mg_cover_blocks / mg_index_blocks with the panel's genotypes in the sparse form of mg_panel_dev (sp_off, sp_sample, sp_gt:
+ * only the samples whose genotype word is not sp_default).  What crosses PCIe for a 27,934-sample panel drops from 56 KB per
+ * record to a few bytes per non-reference genotype. */
+int mg_cover_blocks_sparse(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                           const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                           const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                           const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                           const uint32_t *sp_off, const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default,
+                           uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out);
+int mg_index_blocks_sparse(mg_ctx *ctx, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
+                           const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
+                           const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                           const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                           const uint32_t *sp_off, const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default,
+                           uint32_t n_samples, int haploid, uint8_t *overflow_out);
 
 /* Result codes of mg_genotype / mg_call_isolated per variant */
 #define MG_GT_NORMAL 0   /* likelihood list computed                              */

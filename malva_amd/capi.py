@@ -105,6 +105,8 @@ def lib():
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
+        "mg_cover_blocks_sparse": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint16, u32, it, vp, vp],
+        "mg_index_blocks_sparse": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint16, u32, it, vp],
         "mg_cut_blocks": [vp, sz, vp, vp, vp, vp, vp, vp],
         "mg_cut_blocks_device": [vp, vp, vp, vp, vp],
         "mg_cover_blocks_device": [vp, vp, vp, vp, vp, it, vp, vp],
@@ -148,7 +150,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
             "mg_counters_allreduce_all", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
             "mg_index_isolated",
-            "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
+            "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_cover_blocks_sparse", "mg_index_blocks_sparse", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
             "mg_debug_packed_index", "mg_scan_stats", "mg_blocks_stats", "mg_set_option", "mg_get_option"]
 
@@ -161,7 +163,18 @@ class PanelDev(C.Structure):
     """mg_panel_dev: a panel resident in HBM (every pointer a device pointer)"""
     _fields_ = [("n_vars", C.c_uint64), ("n_contigs", C.c_uint32), ("n_samples", C.c_uint32), ("contig_base", C.c_void_p), ("contig_len", C.c_void_p),
                 ("contig_id", C.c_void_p), ("pos", C.c_void_p), ("ref_size", C.c_void_p), ("min_size", C.c_void_p), ("present", C.c_void_p),
-                ("var_allele_off", C.c_void_p), ("allele_off", C.c_void_p), ("pool", C.c_void_p), ("canon", C.c_void_p), ("gt", C.c_void_p)]
+                ("var_allele_off", C.c_void_p), ("allele_off", C.c_void_p), ("pool", C.c_void_p), ("canon", C.c_void_p), ("gt", C.c_void_p),
+                ("sp_off", C.c_void_p), ("sp_sample", C.c_void_p), ("sp_gt", C.c_void_p), ("sp_default", C.c_uint32)]
+
+
+def sparse_genotypes(gt, n_samples, default=1 << 14):
+    """dense [n_vars, n_samples] genotype words -> (sp_off, sp_sample, sp_gt): the entries other than `default` (0|0 phased)"""
+    gt = np.ascontiguousarray(gt, dtype=np.uint16).reshape(-1, max(int(n_samples), 1)) if n_samples else np.zeros((len(gt), 0), np.uint16)
+    keep = gt != np.uint16(default)
+    off = np.zeros(gt.shape[0] + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(keep.sum(axis=1))
+    rows, cols = np.nonzero(keep)
+    return off, cols.astype(np.uint32), gt[rows, cols].astype(np.uint16)
 
 
 def host_alloc(n_bytes):
@@ -504,7 +517,8 @@ class Context:
         return cov
 
     def cover_blocks(self, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off,
-                     allele_off, pool, canon, gt, n_samples, haploid):
+                     allele_off, pool, canon, gt, n_samples, haploid, sparse=False, sp_default=1 << 14):
+        """sparse: hand the genotypes over as the entries other than the word sp_default (mg_cover_blocks_sparse)"""
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
         bb, bl, bo = a(blk_ref_base, np.uint64), a(blk_ref_len, np.uint32), a(blk_var_off, np.uint32)
         pos, rs, ms, pr = a(pos, np.int32), a(ref_size, np.uint32), a(min_size, np.uint32), a(present, np.uint8)
@@ -512,6 +526,11 @@ class Context:
         n = len(pos)
         cov = np.zeros(int(vo[-1]), dtype=np.uint32)
         ovf = np.zeros(n, dtype=np.uint8)
+        if sparse:
+            so, ss, sg = sparse_genotypes(gt.reshape(n, -1) if n else gt, n_samples, sp_default)
+            self._ck(self._L.mg_cover_blocks_sparse(self.h, len(bb), _p(bb), _p(bl), _p(bo), n, _p(pos), _p(rs), _p(ms), _p(pr), _p(vo), _p(ao),
+                                                    _p(pool), pool.size, _p(canon), _p(so), _p(ss), _p(sg), sp_default, n_samples, int(haploid), _p(cov), _p(ovf)))
+            return cov, ovf
         self._ck(self._L.mg_cover_blocks(self.h, len(bb), _p(bb), _p(bl), _p(bo), n, _p(pos), _p(rs), _p(ms), _p(pr), _p(vo), _p(ao),
                                          _p(pool), pool.size, _p(canon), _p(gt), n_samples, int(haploid), _p(cov), _p(ovf)))
         return cov, ovf
@@ -554,13 +573,18 @@ class Context:
                                             v(d_g1), v(d_g2), v(d_gq), v(d_st), v(d_probs), v(d_gt_off)))
 
     def index_blocks(self, blk_ref_base, blk_ref_len, blk_var_off, pos, ref_size, min_size, present, var_allele_off,
-                     allele_off, pool, canon, gt, n_samples, haploid):
+                     allele_off, pool, canon, gt, n_samples, haploid, sparse=False, sp_default=1 << 14):
         a = lambda x, t: np.ascontiguousarray(x, dtype=t)
         bb, bl, bo = a(blk_ref_base, np.uint64), a(blk_ref_len, np.uint32), a(blk_var_off, np.uint32)
         pos, rs, ms, pr = a(pos, np.int32), a(ref_size, np.uint32), a(min_size, np.uint32), a(present, np.uint8)
         vo, ao, pool, canon, gt = a(var_allele_off, np.uint32), a(allele_off, np.uint32), a(pool, np.uint8), a(canon, np.uint8), a(gt, np.uint16)
         n = len(pos)
         ovf = np.zeros(n, dtype=np.uint8)
+        if sparse:
+            so, ss, sg = sparse_genotypes(gt.reshape(n, -1) if n else gt, n_samples, sp_default)
+            self._ck(self._L.mg_index_blocks_sparse(self.h, len(bb), _p(bb), _p(bl), _p(bo), n, _p(pos), _p(rs), _p(ms), _p(pr), _p(vo), _p(ao),
+                                                    _p(pool), pool.size, _p(canon), _p(so), _p(ss), _p(sg), sp_default, n_samples, int(haploid), _p(ovf)))
+            return ovf
         self._ck(self._L.mg_index_blocks(self.h, len(bb), _p(bb), _p(bl), _p(bo), n, _p(pos), _p(rs), _p(ms), _p(pr), _p(vo), _p(ao),
                                          _p(pool), pool.size, _p(canon), _p(gt), n_samples, int(haploid), _p(ovf)))
         return ovf

@@ -87,12 +87,25 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
     if (!lone) return c;
     c.eligible = P.present[v] && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
     u64 mask = 0;
-    if (c.eligible) // build_alleles_combs on a chain of one (var_block.hpp:734-786): the alleles some panel haplotype carries
-        for (u32 s = 0; s < P.n_samples; ++s) {
-            const u32 g = P.gt[v * P.n_samples + s];
-            mask |= 1ULL << P.canon[c.a0 + (g & 127)];
-            if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
-        }
+    if (c.eligible) { // build_alleles_combs on a chain of one (var_block.hpp:734-786): the alleles some panel haplotype carries
+        if (P.sp_off) { // sparse genotypes: the entries, and allele 0 for the samples that have none
+            const u32 e0 = P.sp_off[v], e1 = P.sp_off[v + 1];
+            for (u32 e = e0; e < e1; ++e) {
+                const u32 g = P.sp_gt[e];
+                mask |= 1ULL << P.canon[c.a0 + (g & 127)];
+                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
+            }
+            if (e1 - e0 < P.n_samples) { // the samples without an entry carry the default word
+                mask |= 1ULL << P.canon[c.a0 + (P.sp_default & 127)];
+                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((P.sp_default >> 7) & 127)];
+            }
+        } else
+            for (u32 s = 0; s < P.n_samples; ++s) {
+                const u32 g = P.gt[v * P.n_samples + s];
+                mask |= 1ULL << P.canon[c.a0 + (g & 127)];
+                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
+            }
+    }
     c.mask = mask;
     c.site = cbase + (u64)p;
     return c;
@@ -398,7 +411,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
                         fail = true;
                         break;
                     }
-                    const u32 gt = B.gt[(u64)v * B.n_samples + s];
+                    const u32 gt = gt_at(B, v, s);
                     phased = phased && ((gt >> 14) & 1);
                     c1 |= (unsigned long long)(gt & 127) << sh;
                     c2 |= (unsigned long long)((gt >> 7) & 127) << sh;

@@ -1963,7 +1963,8 @@ int check_panel(mg_ctx *c, const mg_panel_dev *p, bool need_gt)
     if (p->n_vars >= 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "fewer than 2^32 records per batch");
     if (p->n_vars == 0) return MG_OK;
     if (!p->contig_id || !p->pos || !p->ref_size || !p->min_size) return fail(c, MG_ERR_ARG, "NULL panel array");
-    if (need_gt && (!p->contig_base || !p->contig_len || !p->present || !p->var_allele_off || !p->allele_off || !p->pool || !p->canon || (p->n_samples && !p->gt)))
+    if (need_gt && (!p->contig_base || !p->contig_len || !p->present || !p->var_allele_off || !p->allele_off || !p->pool || !p->canon ||
+                    (p->n_samples && !p->gt && !p->sp_off) || (p->sp_off && (!p->sp_sample || !p->sp_gt))))
         return fail(c, MG_ERR_ARG, "NULL panel array");
     return MG_OK;
 }
@@ -1973,6 +1974,7 @@ PanelView panel_view(const mg_panel_dev *p)
     P.contig_base = p->contig_base; P.contig_len = p->contig_len; P.contig_id = p->contig_id; P.pos = p->pos;
     P.ref_size = p->ref_size; P.min_size = p->min_size; P.present = p->present; P.var_allele_off = p->var_allele_off;
     P.allele_off = p->allele_off; P.canon = p->canon; P.gt = p->gt; P.n_samples = p->n_samples;
+    P.sp_off = p->sp_off; P.sp_sample = p->sp_sample; P.sp_gt = p->sp_gt; P.sp_default = p->sp_default;
     return P;
 }
 // The tiers of block_pipeline.h over one resident panel.  Counts stay on the device; c->d_gen_count holds
@@ -2031,6 +2033,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.blk_var_off = d_blk_var_off; B.var_block = d_var_block;
     B.pos = p->pos; B.ref_size = p->ref_size; B.min_size = p->min_size; B.present = p->present; B.var_allele_off = p->var_allele_off;
     B.allele_off = p->allele_off; B.pool = (const u8 *)p->pool; B.canon = p->canon; B.gt = p->gt;
+    B.sp_off = p->sp_off; B.sp_sample = p->sp_sample; B.sp_gt = p->sp_gt; B.sp_default = p->sp_default;
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
     R.B = B;
@@ -2230,11 +2233,19 @@ namespace {
 int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
                   const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
                   const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, uint32_t n_samples,
-                  mg_panel_dev *out, void **d_blk_var_off, void **d_var_block, void **d_n_blocks)
+                  mg_panel_dev *out, void **d_blk_var_off, void **d_var_block, void **d_n_blocks, const uint32_t *sp_off = nullptr,
+                  const uint32_t *sp_sample = nullptr, const uint16_t *sp_gt = nullptr)
 {
     if (!blk_ref_base || !blk_ref_len || !blk_var_off || !pos || !ref_size || !min_size || !present || !var_allele_off || !allele_off || !pool || !canon ||
-        (n_samples && !gt))
+        (n_samples && !gt && !sp_off) || (sp_off && (!sp_sample || !sp_gt)))
         return fail(c, MG_ERR_ARG, "NULL argument");
+    if (sp_off)
+        for (size_t v = 0; v < n_vars; ++v) {
+            if (sp_off[v + 1] < sp_off[v] || sp_off[v + 1] - sp_off[v] > n_samples) return fail(c, MG_ERR_ARG, "sparse genotype offsets of record %zu", v);
+            for (u32 e = sp_off[v]; e < sp_off[v + 1]; ++e)
+                if (sp_sample[e] >= n_samples || (e > sp_off[v] && sp_sample[e] <= sp_sample[e - 1]))
+                    return fail(c, MG_ERR_ARG, "sparse genotypes of record %zu: samples must ascend below n_samples", v);
+        }
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
     if (blk_var_off[n_blocks] != n_vars) return fail(c, MG_ERR_ARG, "block offsets do not close");
     const size_t na = var_allele_off[n_vars];
@@ -2257,7 +2268,15 @@ int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, cons
     TRY(upload(c, c->s_aux, allele_off, 4 * (na + 1), &d[9]));
     TRY(upload(c, c->s_open[0], pool, pool_len, &d[10]));
     TRY(upload(c, c->s_open[1], canon, na, &d[11]));
-    TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
+    void *d_sp[3] = {nullptr, nullptr, nullptr};
+    if (sp_off) {
+        const size_t ne = sp_off[n_vars];
+        TRY(upload(c, c->s_open[2], sp_off, 4 * (n_vars + 1), &d_sp[0]));
+        TRY(upload(c, c->s_hit[0], sp_sample, 4 * ne, &d_sp[1]));
+        TRY(upload(c, c->s_hit[1], sp_gt, 2 * ne, &d_sp[2]));
+        d[12] = nullptr;
+    } else
+        TRY(upload(c, c->s_open[2], gt, 2 * (size_t)n_vars * n_samples, &d[12]));
     if (!c->d_gen_count) HIP_TRY(c, hipMalloc(&c->d_gen_count, 64));
     const unsigned long long nb = n_blocks;
     HIP_TRY(c, hipMemcpyAsync(c->d_gen_count + 1, &nb, 8, hipMemcpyHostToDevice, c->stream));
@@ -2269,6 +2288,7 @@ int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, cons
     p.pos = (const int32_t *)d[4]; p.ref_size = (const uint32_t *)d[5]; p.min_size = (const uint32_t *)d[6]; p.present = (const uint8_t *)d[7];
     p.var_allele_off = (const uint32_t *)d[8]; p.allele_off = (const uint32_t *)d[9]; p.pool = (const char *)d[10]; p.canon = (const uint8_t *)d[11];
     p.gt = (const uint16_t *)d[12]; p.n_samples = n_samples;
+    p.sp_off = (const uint32_t *)d_sp[0]; p.sp_sample = (const uint32_t *)d_sp[1]; p.sp_gt = (const uint16_t *)d_sp[2];
     *out = p;
     *d_blk_var_off = d[2];
     *d_var_block = d[3];
@@ -2277,11 +2297,52 @@ int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, cons
 }
 } // namespace
 
+namespace {
+int cover_blocks_host(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                      const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                      const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, const uint32_t *sp_off,
+                      const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out);
+int index_blocks_host(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                      const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                      const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, const uint32_t *sp_off,
+                      const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid, uint8_t *overflow_out);
+} // namespace
+
 MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len,
                               const uint32_t *blk_var_off, size_t n_vars, const int32_t *pos, const uint32_t *ref_size,
                               const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
                               const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
                               uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
+{
+    return cover_blocks_host(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                             canon, gt, nullptr, nullptr, nullptr, 0, n_samples, haploid, cov_out, overflow_out);
+}
+MG_EXPORT int mg_cover_blocks_sparse(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off,
+                                     size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present,
+                                     const uint32_t *var_allele_off, const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                                     const uint32_t *sp_off, const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid,
+                                     uint32_t *cov_out, uint8_t *overflow_out)
+{
+    if (c && !sp_off) return fail(c, MG_ERR_ARG, "NULL argument");
+    return cover_blocks_host(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                             canon, nullptr, sp_off, sp_sample, sp_gt, sp_default, n_samples, haploid, cov_out, overflow_out);
+}
+MG_EXPORT int mg_index_blocks_sparse(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off,
+                                     size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present,
+                                     const uint32_t *var_allele_off, const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon,
+                                     const uint32_t *sp_off, const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid,
+                                     uint8_t *overflow_out)
+{
+    if (c && !sp_off) return fail(c, MG_ERR_ARG, "NULL argument");
+    return index_blocks_host(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                             canon, nullptr, sp_off, sp_sample, sp_gt, sp_default, n_samples, haploid, overflow_out);
+}
+
+namespace {
+int cover_blocks_host(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                      const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                      const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, const uint32_t *sp_off,
+                      const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
 {
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
@@ -2291,7 +2352,8 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     mg_panel_dev p{};
     void *d_bo, *d_vb, *d_nb;
     TRY(upload_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
-                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb));
+                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb, sp_off, sp_sample, sp_gt));
+    p.sp_default = sp_default;
     const size_t na = var_allele_off[n_vars];
     void *d_cov, *d_ovf;
     TRY(scratch(c, c->s_out, 4 * na, &d_cov));
@@ -2302,6 +2364,7 @@ MG_EXPORT int mg_cover_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }
+} // namespace
 
 // index time: VB::extract_kmers + add_kmers_to_bf (main.cpp:349-350, 122-144) for every block of a resident panel.  Synchronises
 // once on eight bytes: the exact map is sized from the counting pass before the insert pass runs.
@@ -2353,6 +2416,15 @@ MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
                               const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt,
                               uint32_t n_samples, int haploid, uint8_t *overflow_out)
 {
+    return index_blocks_host(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
+                             canon, gt, nullptr, nullptr, nullptr, 0, n_samples, haploid, overflow_out);
+}
+namespace {
+int index_blocks_host(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, const uint32_t *blk_ref_len, const uint32_t *blk_var_off, size_t n_vars,
+                      const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint8_t *present, const uint32_t *var_allele_off,
+                      const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, const uint32_t *sp_off,
+                      const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid, uint8_t *overflow_out)
+{
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
@@ -2361,7 +2433,8 @@ MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     mg_panel_dev p{};
     void *d_bo, *d_vb, *d_nb;
     TRY(upload_blocks(c, n_blocks, blk_ref_base, blk_ref_len, blk_var_off, n_vars, pos, ref_size, min_size, present, var_allele_off, allele_off, pool, pool_len,
-                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb));
+                      canon, gt, n_samples, &p, &d_bo, &d_vb, &d_nb, sp_off, sp_sample, sp_gt));
+    p.sp_default = sp_default;
     void *d_ovf;
     TRY(scratch(c, c->s_irr, n_vars, &d_ovf));
     HIP_TRY(c, hipMemsetAsync(d_ovf, 0, n_vars, c->stream));
@@ -2369,6 +2442,7 @@ MG_EXPORT int mg_index_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_re
     HIP_TRY(c, hipMemcpy(overflow_out, d_ovf, n_vars, hipMemcpyDeviceToHost));
     return MG_OK;
 }
+} // namespace
 
 // index time: blocks of one variant whose alleles are all shorter than k (nearly every block of a SNP panel), on the device
 MG_EXPORT int mg_index_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, const uint32_t *var_allele_off, const uint32_t *allele_off,

@@ -349,11 +349,34 @@ struct BlockBatch {
     const u32 *allele_off;     // [n_slots + 1] into pool
     const u8 *pool;
     const u8 *canon;           // [n_slots] first allele index of the variant with the same text
-    const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14
+    const uint16_t *gt;        // [n_vars][n_samples]: a1 | a2 << 7 | phased << 14 -- or, when sp_off is given, the SPARSE form:
+    const u32 *sp_off;         // [n_vars + 1] record v's entries are [sp_off[v], sp_off[v + 1]) of ...
+    const u32 *sp_sample;      // ... the samples (ascending) whose genotype is anything but 0|0 phased ...
+    const uint16_t *sp_gt;     // ... and that genotype.  A panel of tens of thousands of samples is nearly all 0|0.
+    u32 sp_default;            // the genotype word of every sample WITHOUT an entry (0|0 phased, or 0/0 for an unphased panel)
     u32 n_samples;
     int haploid, k;
     u32 set_limit; // distinct picks per chain held in the LDS set (<= BK_SET_CAP / 2; tests shrink it to reach the direct form)
 };
+// entry of sample s in record v's sparse genotypes, or -1
+__device__ __forceinline__ long long sp_find(const u32 *sp_off, const u32 *sp_sample, u32 v, u32 s)
+{
+    u32 lo = sp_off[v];
+    const u32 end = sp_off[v + 1];
+    u32 hi = end;
+    while (lo < hi) {
+        const u32 mid = lo + (hi - lo) / 2;
+        if (sp_sample[mid] < s) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < end && sp_sample[lo] == s ? (long long)lo : -1;
+}
+__device__ __forceinline__ u32 gt_at(const BlockBatch &B, u32 v, u32 s)
+{
+    if (!B.sp_off) return B.gt[(u64)v * B.n_samples + s];
+    const long long e = sp_find(B.sp_off, B.sp_sample, v, s);
+    return e >= 0 ? (u32)B.sp_gt[e] : B.sp_default;
+}
 constexpr int BK_MAXC = 16;  // chains per side
 constexpr int BK_MAXL = 32;  // members per chain side (a combined chain: left + the variant + right <= 65 members)
 constexpr int BK_MAXU = 14;  // unphased chain length (2^14 haplotype mixes per sample)
@@ -451,6 +474,9 @@ struct PanelView {
     const u32 *var_allele_off, *allele_off;
     const u8 *canon;
     const uint16_t *gt;
+    const u32 *sp_off, *sp_sample; // sparse genotypes (see BlockBatch), or NULL
+    const uint16_t *sp_gt;
+    u32 sp_default;
     u32 n_samples;
 };
 
@@ -757,20 +783,23 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
         int code_bits = 0;
         for (int j = 0; j < m; ++j) code_bits += bits_of(j);
         const bool coded = code_bits <= BK_CODE_BITS;
-        // every sample's picks: into the set (collect) or straight to evaluate()
+        // every sample's picks: into the set (collect) or straight to evaluate().  Dense genotypes: the threads stride over the
+        // samples.  Sparse genotypes: over the ENTRIES of the chain's members -- a sample is taken at the first member it has
+        // an entry in -- plus once the sample with no entry anywhere (all 0|0; there is one whenever the entries are fewer
+        // than the samples); a chain with as many entries as samples walks the samples and looks each genotype up.
         auto walk_samples = [&](bool collect) {
-            for (u32 s = threadIdx.x; s < B.n_samples; s += TPB) {
+            auto one_sample = [&](auto gt_of) -> bool { // gt_of(j): member j's genotype word; false: the set overflowed, stop
                 bool phased = true;
                 if (!B.haploid)
-                    for (int j = 0; j < m; ++j) phased = phased && ((B.gt[(u64)comb[j] * B.n_samples + s] >> 14) & 1);
+                    for (int j = 0; j < m; ++j) phased = phased && ((gt_of(j) >> 14) & 1);
                 const u32 npick = B.haploid ? 1u : phased ? 2u : (1u << m);
                 if (!B.haploid && !phased && m > BK_MAXU) {
                     bad = true;
-                    continue;
+                    return true;
                 }
                 for (u32 pick = 0; pick < npick; ++pick) {
                     auto allele_of = [&](int j) -> u32 { // allele of member j under this pick
-                        const u32 gt = B.gt[(u64)comb[j] * B.n_samples + s];
+                        const u32 gt = gt_of(j);
                         const u32 a1 = gt & 127, a2 = (gt >> 7) & 127;
                         if (B.haploid) return a1;
                         if (phased) return pick ? a2 : a1;
@@ -796,9 +825,34 @@ __global__ void __launch_bounds__(TPB) cover_blocks_kernel(BlockBatch B, const u
                         if (seen == code + 1) break;
                         at = (at + 1) & (BK_SET_CAP - 1);
                     }
-                    if (sh_set_n > B.set_limit) return; // too many distinct picks: this chain is redone directly
+                    if (sh_set_n > B.set_limit) return false; // too many distinct picks: this chain is redone directly
                 }
+                return true;
+            };
+            u32 entries = 0;
+            if (B.sp_off)
+                for (int j = 0; j < m; ++j) entries += B.sp_off[comb[j] + 1] - B.sp_off[comb[j]];
+            if (!B.sp_off || entries >= B.n_samples) {
+                for (u32 s = threadIdx.x; s < B.n_samples; s += TPB)
+                    if (!one_sample([&](int j) -> u32 { return gt_at(B, (u32)comb[j], s); })) return;
+                return;
             }
+            for (u32 idx = threadIdx.x; idx < entries; idx += TPB) {
+                u32 rem = idx;
+                int j = 0;
+                for (; j < m; ++j) {
+                    const u32 cnt = B.sp_off[comb[j] + 1] - B.sp_off[comb[j]];
+                    if (rem < cnt) break;
+                    rem -= cnt;
+                }
+                const u32 e = B.sp_off[comb[j]] + rem, smp = B.sp_sample[e];
+                bool first = true;
+                for (int q = 0; q < j && first; ++q) first = sp_find(B.sp_off, B.sp_sample, (u32)comb[q], smp) < 0;
+                if (!first) continue;
+                if (!one_sample([&](int q) -> u32 { return q == j ? (u32)B.sp_gt[e] : gt_at(B, (u32)comb[q], smp); })) return;
+            }
+            // (every member default: one pick if the default is homozygous, whatever its phase bit says -- the mixes of equal alleles are equal)
+            if (threadIdx.x == 0) one_sample([&](int) -> u32 { return (B.sp_default & 127) == ((B.sp_default >> 7) & 127) ? B.sp_default | (1u << 14) : B.sp_default; });
         };
         if (coded) {
             for (u32 w = threadIdx.x; w < BK_SET_CAP; w += TPB) sh_set[w] = 0;

@@ -317,6 +317,64 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
     return i;
 }
 
+// ---- the panel genotypes of a batch of blocks, as the device takes them ---------------------------------------------------
+// Dense: one [variant][sample] matrix of a1 | a2 << 7 | phased << 14.  Sparse (panels of more than SPARSE_GT_SAMPLES samples:
+// nearly every genotype of such a panel is 0|0): per variant only the samples that carry anything else, in sample order --
+// what crosses PCIe for the 27,934-sample SARS-CoV-2 panel drops from 56 KB per record to a few bytes per carrier.
+constexpr uint32_t SPARSE_GT_SAMPLES = 64;
+struct PanelGenotypes {
+    bool sparse = false;
+    std::vector<uint16_t> gt;                 // dense
+    std::vector<uint32_t> sp_off{0}, sp_sample; // sparse
+    std::vector<uint16_t> sp_gt;
+    uint16_t sp_default = (uint16_t)(1u << 14);
+    size_t bytes() const { return sparse ? 4 * sp_off.size() + 6 * sp_sample.size() : 2 * gt.size(); }
+};
+inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_vars, uint32_t n_samples, bool haploid)
+{
+    PanelGenotypes g;
+    g.sparse = n_samples > SPARSE_GT_SAMPLES;
+    if (!g.sparse) g.gt.assign(n_vars * n_samples, 0);
+    // haploid mode reads the first allele only (var_block.hpp:751): the word is reduced to it, so that a ploidy-1 panel --
+    // whose second "allele" is whatever htslib's layout puts behind the first -- is as sparse as it looks
+    auto word = [&](const Variant &v, size_t s_) -> uint16_t {
+        const auto &p2 = v.genotypes[s_];
+        if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
+            throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
+                                     " (the reference reads out of bounds here)");
+        if (haploid) return (uint16_t)(p2.first | (1u << 14));
+        return (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
+    };
+    if (g.sparse) { // the default word: 0|0 phased or 0/0 unphased, whichever the batch holds more of (a sample of it decides)
+        size_t phased0 = 0, unphased0 = 0, seen = 0;
+        for (const Block &b : blocks) {
+            for (const Variant &v : b.vars)
+                for (size_t s_ = 0; s_ < v.genotypes.size() && seen < 200000; s_ += 7, ++seen) {
+                    const uint16_t w = word(v, s_);
+                    phased0 += w == (1u << 14);
+                    unphased0 += w == 0;
+                }
+            if (seen >= 200000) break;
+        }
+        g.sp_default = unphased0 > phased0 ? 0 : (uint16_t)(1u << 14);
+    }
+    size_t row = 0;
+    for (const Block &b : blocks)
+        for (const Variant &v : b.vars) {
+            for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
+                const uint16_t w = word(v, s_);
+                if (!g.sparse) g.gt[row * n_samples + s_] = w;
+                else if (w != g.sp_default) {
+                    g.sp_sample.push_back((uint32_t)s_);
+                    g.sp_gt.push_back(w);
+                }
+            }
+            if (g.sparse) g.sp_off.push_back((uint32_t)g.sp_sample.size());
+            ++row;
+        }
+    return g;
+}
+
 // ---- index file (index_file.hpp): payload out of / into the contexts ---------------------------------------------------
 void save_index(Device &dev, const Options &o)
 {
@@ -474,23 +532,16 @@ int index_main(const Options &o)
             }
             const size_t nv = ipos.size();
             const uint32_t n_samples = (uint32_t)vcf.keep.size();
-            std::vector<uint16_t> gt(nv * n_samples, 0);
-            size_t g = 0;
-            for (const Block &b : waiting)
-                for (const Variant &v : b.vars) {
-                    for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
-                        const auto &p2 = v.genotypes[s_];
-                        if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
-                            throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
-                                                     " (the reference reads out of bounds here)");
-                        gt[g * n_samples + s_] = (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
-                    }
-                    ++g;
-                }
+            const PanelGenotypes pg = pack_genotypes(waiting, nv, n_samples, o.haploid);
             std::vector<uint8_t> overflow(nv, 1);
-            if (device_ok)
+            if (device_ok && pg.sparse)
+                dev.check(mg_index_blocks_sparse(dev.ctx, nb, blk_base.data(), blk_len.data(), blk_var_off.data(), nv, ipos.data(), ref_size.data(), min_size.data(),
+                                                 is_present.data(), var_allele_off.data(), allele_off.data(), pool.data(), pool.size(), canon.data(), pg.sp_off.data(),
+                                                 pg.sp_sample.data(), pg.sp_gt.data(), pg.sp_default, n_samples, o.haploid, overflow.data()),
+                          "mg_index_blocks_sparse");
+            else if (device_ok)
                 dev.check(mg_index_blocks(dev.ctx, nb, blk_base.data(), blk_len.data(), blk_var_off.data(), nv, ipos.data(), ref_size.data(), min_size.data(),
-                                          is_present.data(), var_allele_off.data(), allele_off.data(), pool.data(), pool.size(), canon.data(), gt.data(),
+                                          is_present.data(), var_allele_off.data(), allele_off.data(), pool.data(), pool.size(), canon.data(), pg.gt.data(),
                                           n_samples, o.haploid, overflow.data()),
                           "mg_index_blocks");
             for (size_t b = 0; b < nb; ++b)
@@ -997,6 +1048,7 @@ int call_main(const Options &o)
     const size_t batch_records = getenv("MALVA_GENO_BATCH") ? (size_t)std::max(1L, atol(getenv("MALVA_GENO_BATCH"))) : 200000;
     std::vector<Rec> recs;
     Batch iso, gen;
+    std::atomic<size_t> gt_bytes_uploaded{0}; // panel genotypes handed to mg_cover_blocks[_sparse], all batches
     const std::string best_default = o.haploid ? "0" : "0/0";
     auto n_gt = [&](uint64_t A) { return o.haploid ? A : A * (A + 1) / 2; };
 
@@ -1028,28 +1080,23 @@ int call_main(const Options &o)
             gen.probs.resize(o.verbose ? gen.var_gt_off.back() : 0);
             // panel genotypes of the batch as one [variant][sample] matrix of a1 | a2 << 7 | phased << 14
             const uint32_t n_samples = (uint32_t)vcf.keep.size();
-            std::vector<uint16_t> gt((size_t)n * n_samples, 0);
             std::vector<uint8_t> overflow(n, 0);
             bool device_ok = o.k <= MG_MAX_PACKED_K && !getenv("MALVA_GENO_HOST_ENUM"); // the variable forces the host enumerator (tests)
-            {
-                size_t g = 0;
-                for (const Block &b : gen.blocks)
-                    for (const Variant &v : b.vars) {
-                        if (v.n_alleles() > 127) device_ok = false;
-                        for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
-                            const auto &p2 = v.genotypes[s_];
-                            if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
-                                throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
-                                                         " (the reference reads out of bounds here)");
-                            gt[g * n_samples + s_] = (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
-                        }
-                        ++g;
-                    }
-            }
-            if (device_ok)
+            for (const Block &b : gen.blocks)
+                for (const Variant &v : b.vars)
+                    if (v.n_alleles() > 127) device_ok = false;
+            const PanelGenotypes pg = pack_genotypes(gen.blocks, n, n_samples, o.haploid);
+            gt_bytes_uploaded += pg.bytes();
+            if (device_ok && pg.sparse)
+                dev.check(mg_cover_blocks_sparse(dev.ctx, gen.blocks.size(), gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
+                                                 gen.ref_size.data(), gen.min_size.data(), gen.is_present.data(), gen.var_allele_off.data(),
+                                                 gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), pg.sp_off.data(), pg.sp_sample.data(),
+                                                 pg.sp_gt.data(), pg.sp_default, n_samples, o.haploid, gen.cov.data(), overflow.data()),
+                          "mg_cover_blocks_sparse"); // extract_kmers + set_coverages, main.cpp:556-557
+            else if (device_ok)
                 dev.check(mg_cover_blocks(dev.ctx, gen.blocks.size(), gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
                                           gen.ref_size.data(), gen.min_size.data(), gen.is_present.data(), gen.var_allele_off.data(),
-                                          gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), gt.data(), n_samples, o.haploid,
+                                          gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), pg.gt.data(), n_samples, o.haploid,
                                           gen.cov.data(), overflow.data()),
                           "mg_cover_blocks"); // extract_kmers + set_coverages, main.cpp:556-557
             else
@@ -1228,6 +1275,7 @@ int call_main(const Options &o)
     run_and_print();
     drain(0);
     std::cout.flush();
+    if (gt_bytes_uploaded) std::cerr << "[malva-geno] panel genotypes of the general blocks: " << gt_bytes_uploaded.load() << " bytes uploaded" << std::endl;
     pelapsed("Processed " + std::to_string(n) + " variants");
     pelapsed("Execution completed");
     return 0;

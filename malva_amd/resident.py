@@ -4,13 +4,14 @@ PyTorch is the allocator here (device tensors keep the arrays alive and give the
 computed is computed by libmalva_hip.so.  Used by bench.py and the -m gpu tests."""
 import numpy as np
 
-from .capi import PanelDev
+from .capi import PanelDev, sparse_genotypes
 
 
 class ResidentPanel:
     """The arrays of malva_amd.synth.FlatPanel uploaded once; `.dev` is the mg_panel_dev to hand to the library."""
 
-    def __init__(self, panel, device, haploid=False):
+    def __init__(self, panel, device, haploid=False, sparse=False, sp_default=1 << 14):
+        """sparse: the genotypes go up as the entries other than 0|0 phased (mg_panel_dev.sp_*) instead of the dense matrix"""
         import torch
         self.torch = torch
         self.dev_t = torch.device("cuda", device) if isinstance(device, int) else device
@@ -40,6 +41,12 @@ class ResidentPanel:
         d.n_vars, d.n_contigs, d.n_samples = self.n, len(panel.contig_len), self.n_samples
         for name in ("contig_base", "contig_len", "contig_id", "pos", "ref_size", "min_size", "present", "var_allele_off", "allele_off", "pool", "canon", "gt"):
             setattr(d, name, self.t[name].data_ptr())
+        if sparse:
+            so, ss, sg = sparse_genotypes(panel.gt, self.n_samples, sp_default)
+            d.sp_default = sp_default
+            self.t["sp_off"], self.t["sp_sample"], self.t["sp_gt"] = up(so, np.uint32), up(ss, np.uint32), up(sg, np.uint16)
+            d.gt = None
+            d.sp_off, d.sp_sample, d.sp_gt = (self.t[x].data_ptr() for x in ("sp_off", "sp_sample", "sp_gt"))
         self.dev = d
 
     def _up(self, a, dt):

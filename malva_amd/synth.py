@@ -514,7 +514,7 @@ def clustered_snp_panel(n_vars, seed, n_contigs=24, mean_spacing=38, cluster_fra
                      canon=np.tile(np.array([0, 1], dtype=np.uint8), n_vars), freq=freq, gt=gt, n_samples=n_samples, donor_gt=donor)
 
 
-def indel_panel(n_clusters, seed, k=35, n_samples=8, n_contigs=2, unphased_frac=0.5, max_cluster=6, cluster_gap=400):
+def indel_panel(n_clusters, seed, k=35, n_samples=8, n_contigs=2, unphased_frac=0.5, max_cluster=6, cluster_gap=400, hom_ref=0.45):
     """BASELINE config C5's panel: clusters of 1..max_cluster records mixing SNPs, MNPs, 1-30 nt deletions and
     1-60 nt insertions (some of k bases and more: the sliding-signature path), up to 3 ALTs, a few records overlapping the
     deletion before them, `n_samples` samples of which `unphased_frac` of the genotypes are unphased; clusters `cluster_gap`
@@ -606,9 +606,9 @@ def indel_panel(n_clusters, seed, k=35, n_samples=8, n_contigs=2, unphased_frac=
     # genotypes
     a1 = (rng.random((n, n_samples)) * A[:, None]).astype(np.uint16)
     a2 = (rng.random((n, n_samples)) * A[:, None]).astype(np.uint16)
-    hom_ref = rng.random((n, n_samples)) < 0.45
-    a1[hom_ref] = 0
-    a2[hom_ref & (rng.random((n, n_samples)) < 0.8)] = 0
+    is_hom_ref = rng.random((n, n_samples)) < hom_ref          # (hom_ref near 1: a large panel, nearly all 0|0)
+    a1[is_hom_ref] = 0
+    a2[is_hom_ref & (rng.random((n, n_samples)) < (0.8 if hom_ref < 0.9 else 1.0))] = 0
     carried = (a1 > 0).any(axis=1)
     a1[~carried, 0] = 1                                                           # every record carries an ALT in some first haplotype
     phased = rng.random((n, n_samples)) >= unphased_frac

@@ -38,7 +38,19 @@ def test_direct_evaluation_when_the_pick_set_overflows(tmp_path, seed, haploid, 
     _run_case(tmp_path, seed, haploid, 35, 43, dense=dense, set_limit=limit, flat=0)
 
 
-def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None, flat=1):
+@pytest.mark.parametrize("flat", [1, 0])
+@pytest.mark.parametrize("sp_default", [1 << 14, 0, 1 | (1 << 14)])
+@pytest.mark.parametrize("seed,haploid,dense", [(37, False, False), (38, True, False), (44, False, True)])
+def test_sparse_genotype_layout(tmp_path, seed, haploid, dense, flat, sp_default):
+    """the panel's genotypes handed over as the entries other than one default word (mg_cover_blocks_sparse): same
+    coverages, whether the default is 0|0 phased, 0/0 unphased (an unphased panel: the phase bit of a homozygous
+    genotype still decides how the sample's other genotypes along a chain combine) or any other word (1|0 here).
+    flat = 0 sends every record through the workgroup kernel, whose sample walk then runs over the ENTRIES of a chain's
+    members (and once over the sample that has none)."""
+    _run_case(tmp_path, seed, haploid, 35, 43, dense=dense, flat=flat, sparse=True, sp_default=sp_default)
+
+
+def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None, flat=1, sparse=False, sp_default=1 << 14):
     prefix = str(tmp_path / "case")
     contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=k, n_clusters=40 if dense else 120, vcf_strip_chr=True,
                                            dense=dense, n_samples=4 if dense else 5)
@@ -81,7 +93,7 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None, flat=1):
         want.append(ocapi.set_coverages(w, so, ao))
     want = np.concatenate(want)
     args = pack_blocks(blocks, base, {n: len(refs[n]) for n in names})
-    cov, ovf = ctx.cover_blocks(**args, haploid=haploid)
+    cov, ovf = ctx.cover_blocks(**args, haploid=haploid, sparse=sparse, sp_default=sp_default)
     ok = np.repeat(ovf == 0, np.diff(np.array(args["var_allele_off"])))
     assert ok.mean() > (0.6 if dense else 0.9), "too many variants fell back: %.2f" % (1 - ok.mean())
     assert np.array_equal(cov[ok], want[ok])

@@ -24,7 +24,7 @@ def oracle_blocks(panel, k):
                 canon=panel.canon, gt=panel.gt, n_samples=panel.n_samples)
 
 
-def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general):
+def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, sparse=False):
     args = oracle_blocks(panel, k)
     sizes = np.diff(args["blk_var_off"].astype(np.int64))
     assert (sizes > 1).sum() >= min_general, "the recipe drew too few general blocks: %d" % (sizes > 1).sum()
@@ -37,7 +37,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general):
     octx.switch_mode()
     with Context(k, ref_k, bits) as ctx:
         ctx.reference_upload(panel.genome)
-        rp = ResidentPanel(panel, 0, haploid=haploid)
+        rp = ResidentPanel(panel, 0, haploid=haploid, sparse=sparse)
         ovf = rp.index(ctx)
         assert ovf.sum() == 0, "%d records handed back at index time" % int(ovf.sum())
         ctx.bf_finalize(BF_ALT)
@@ -124,3 +124,16 @@ def test_c5_recipe_indel_mnp_clusters_r63(haploid):
     unphased; k35 r63"""
     panel = synth.indel_panel(60_000, seed=52 + int(haploid))
     run_recipe(panel, 35, 63, haploid, 1 << 28, n_rows=2_000_000, plant=15_000, min_general=30_000)
+
+
+@pytest.mark.parametrize("haploid", [False, True])
+def test_large_panel_sparse_genotypes_through_the_workgroup_tier(haploid):
+    """700 samples (beyond the flat tier's 512: every general record takes the workgroup kernel), 97 % of the genotypes 0|0
+    phased, handed over SPARSE (mg_panel_dev.sp_*: 3 % of the dense matrix): the lone tier gathers its presence masks from the
+    entries, the workgroup kernel walks the entries of a chain's members plus the one all-reference sample.  Index, counters,
+    cuts, coverages, GT and GQ equal the oracle's (which reads the dense matrix)."""
+    panel = synth.indel_panel(4_000, seed=61 + int(haploid), n_samples=700, hom_ref=0.97, unphased_frac=0.02)
+    from malva_amd.capi import sparse_genotypes
+    off, _, _ = sparse_genotypes(panel.gt, panel.n_samples)
+    assert off[-1] < 0.06 * panel.gt.size
+    run_recipe(panel, 35, 63, haploid, 1 << 26, n_rows=400_000, plant=3_000, min_general=2_000, sparse=True)
