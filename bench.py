@@ -274,8 +274,12 @@ class Job:
             e1.record()
             e1.synchronize()
             self.pack_ms = e0.elapsed_time(e1)
-        cptr, self.n_bf, self.n_map = ctx.counters_view()                 # [bf counters | map counters], one allocation inside the context
-        self.d_counters = alias_int32(cptr, self.n_bf + self.n_map, dev)  # reduced in place: no export/import copies
+        self.d_counters = None
+        if world > 1:                                                         # (a context whose vector has been handed out keeps its counters there alone:
+            cptr, self.n_bf, self.n_map = ctx.counters_view()                 #  one GPU does not ask for it, and its lookups read the records' own copies)
+            self.d_counters = alias_int32(cptr, self.n_bf + self.n_map, dev)  # [bf counters | map counters], reduced in place: no export/import copies
+        else:
+            self.n_bf, self.n_map = ctx.counters_size()
         self.exchange = "none"
         self.native = False
         self.packed_steps = []

@@ -67,44 +67,83 @@ struct LoneClass {
     u64 site, mask;
     u32 a0, A;
 };
+// The loads are arranged in three LEVELS of mutually independent requests (what a thread of this kernel does is wait for
+// loads: the first form, a chain of fifteen dependent ones -- block, block ends, its sequence, the sequence's base; genotype
+// word, canonical allele, next genotype word ... -- ran at a quarter of the rate its 2.5 lines of HBM traffic per record allow):
+//   1  addressed by v alone: block number, sequence, position, sizes, allele range, presence flag, genotype words / entry range
+//   2  addressed by those: the block's ends, the sequence's base and length, allele offsets, canonical alleles, genotype entries
+//   3  the flanks and allele bytes (iso_cover_body), then the records
+// The genotype words give a mask of RAW allele numbers; the canonical numbers (variant.hpp:228-240) are applied to the mask
+// afterwards, so their loads wait for nothing but the allele range.
 __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32 *blk_var_off, const u32 *var_block, u64 v, int k, int haploid)
 {
     LoneClass c{};
+    // level 1
     const u32 blk = var_block[v];
-    const u32 b0 = blk_var_off[blk], b1 = blk_var_off[blk + 1];
-    const u32 cid = P.contig_id[b0];
-    const u64 cbase = P.contig_base[cid];
-    const u32 clen = P.contig_len[cid];
+    const u32 cid = P.contig_id[v]; // (of the block's first record in general; a lone record IS its block's first)
     const i32 p = P.pos[v];
     const u32 rs = P.ref_size[v];
     c.a0 = P.var_allele_off[v];
     c.A = P.var_allele_off[v + 1] - c.a0;
+    const bool present = P.present[v] != 0;
+    u64 raw = 0; // raw allele numbers some panel haplotype carries (numbers of 64 and more fold back: such a record is not lone)
+    u32 e0 = 0, e1 = 0;
+    if (P.sp_off) {
+        e0 = P.sp_off[v];
+        e1 = P.sp_off[v + 1];
+    } else {
+        const uint16_t *g = P.gt + v * P.n_samples;
+        for (u32 s = 0; s < P.n_samples; s += 4) { // four words requested together
+            u32 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = s + j < P.n_samples ? (u32)g[s + j] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w[j] != 0xFFFFFFFFu) {
+                    raw |= 1ULL << (w[j] & 63);
+                    if (!haploid) raw |= 1ULL << ((w[j] >> 7) & 63);
+                }
+        }
+    }
+    // level 2
+    const u32 b0 = blk_var_off[blk], b1 = blk_var_off[blk + 1];
+    const u64 cbase = P.contig_base[cid];
+    const u32 clen = P.contig_len[cid];
+    u32 ao[5];
+    u8 cn[4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) ao[a] = a <= (int)c.A ? P.allele_off[c.a0 + a] : 0u;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cn[a] = a < (int)c.A ? P.canon[c.a0 + a] : (u8)0;
+    if (P.sp_off) { // sparse genotypes: the entries, and the default word for the samples that have none
+        for (u32 e = e0; e < e1; ++e) {
+            const u32 g = P.sp_gt[e];
+            raw |= 1ULL << (g & 63);
+            if (!haploid) raw |= 1ULL << ((g >> 7) & 63);
+        }
+        if (e1 - e0 < P.n_samples) {
+            raw |= 1ULL << (P.sp_default & 63);
+            if (!haploid) raw |= 1ULL << ((P.sp_default >> 7) & 63);
+        }
+    }
     // a block of one variant, alleles all shorter than k (at most 64 of them: the presence mask), flanks inside the sequence
     bool lone = b1 - b0 == 1 && c.A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
-    if (lone)
-        for (u32 a = 0; a < c.A; ++a) lone = lone && (int)(P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a]) < k;
+    if (lone) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < (int)c.A) lone = lone && (int)(ao[a + 1] - ao[a]) < k;
+        for (u32 a = 4; a < c.A; ++a) lone = lone && (int)(P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a]) < k;
+    }
     c.lone = lone;
     if (!lone) return c;
-    c.eligible = P.present[v] && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
+    c.eligible = present && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
     u64 mask = 0;
     if (c.eligible) { // build_alleles_combs on a chain of one (var_block.hpp:734-786): the alleles some panel haplotype carries
-        if (P.sp_off) { // sparse genotypes: the entries, and allele 0 for the samples that have none
-            const u32 e0 = P.sp_off[v], e1 = P.sp_off[v + 1];
-            for (u32 e = e0; e < e1; ++e) {
-                const u32 g = P.sp_gt[e];
-                mask |= 1ULL << P.canon[c.a0 + (g & 127)];
-                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
-            }
-            if (e1 - e0 < P.n_samples) { // the samples without an entry carry the default word
-                mask |= 1ULL << P.canon[c.a0 + (P.sp_default & 127)];
-                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((P.sp_default >> 7) & 127)];
-            }
-        } else
-            for (u32 s = 0; s < P.n_samples; ++s) {
-                const u32 g = P.gt[v * P.n_samples + s];
-                mask |= 1ULL << P.canon[c.a0 + (g & 127)];
-                if (!haploid) mask |= 1ULL << P.canon[c.a0 + ((g >> 7) & 127)];
-            }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < (int)c.A && ((raw >> a) & 1)) mask |= 1ULL << cn[a];
+        for (u32 a = 4; a < c.A; ++a)
+            if ((raw >> a) & 1) mask |= 1ULL << P.canon[c.a0 + a];
     }
     c.mask = mask;
     c.site = cbase + (u64)p;
@@ -628,13 +667,8 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
         const bool is_ref = mid_canon == 0;
         if (MODE == 0) {
             i32 w;
-            if (is_ref) {
-                const long long id = k == (int)map.klen ? map_find_id(map, key, h, idx) : -1;
-                w = id >= 0 ? (i32)map.vals[id] : 0;
-            } else {
-                const long long rank = bucket_rank(map, idx);
-                w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
-            }
+            if (is_ref) w = k == (int)map.klen ? map_value(map, key, h, idx) : 0;
+            else w = (i32)bucket_count(map, bf.counts, idx);
             if (w > 0) atomicMax(&cov_out[a0 + mid_canon], (u32)w);
         } else if (is_ref) {
             if (MODE == 1) ++ref_rows;
@@ -707,13 +741,8 @@ __global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W,
                 const u64 h = xxh3_packed(key, k);
                 const u64 idx = mod_size(h, bf.mod);
                 if (MODE == 0) {
-                    if (is_ref) {
-                        const long long id = k == (int)map.klen ? map_find_id(map, key, h, idx) : -1;
-                        w = id >= 0 ? (i32)map.vals[id] : 0;
-                    } else {
-                        const long long rank = bucket_rank(map, idx);
-                        w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
-                    }
+                    if (is_ref) w = k == (int)map.klen ? map_value(map, key, h, idx) : 0;
+                    else w = (i32)bucket_count(map, bf.counts, idx);
                 } else if (MODE == 2) {
                     if (is_ref) map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
                     else {

@@ -322,21 +322,60 @@ struct __attribute__((aligned(64))) MapSlot {
     u64 klo, khi;
     u32 brank[2]; // filter entries (written once `bf` is finalised): counter index of set bit bidx[j] - 1
     u64 bidx[2];  // 0 = free, else position of a set bit of `bf` + 1; slot 0 fills before slot 1
-    u64 pad;
+    // The record's own copy of its three counters, so that a call-time lookup ends on the line it started on (key ->
+    // vals[id] and bit -> counts[rank] are each a second random line: four per biallelic SNP, two with the copies).
+    // Each word carries the EPOCH it was last written in; a word of another epoch reads as zero, so resetting the
+    // counters (every sample starts from zero) is one increment of the context's epoch, not a pass over the table.
+    // vals[] / counts[] stay the counters of record (exchange between GPUs, export, the per-k-mer calls); the scan's
+    // probe and hit kernels, which hold the record's line anyway, keep the copies equal to them (MapView::epoch != 0).
+    unsigned long long cval; // epoch << 32 | the key's counter (wrapping u32, kmap.hpp:114-122)
+    unsigned long long cbf;  // epoch << 32 | filter entry 1's counter << 16 | entry 0's (wrapping u16 each, bloom_filter.hpp:100-113)
 };
 static_assert(sizeof(MapSlot) == 64, "one record per 64 bytes");
 struct MapView {
     MapSlot *slots;
     u32 *vals;
     u32 cap_log2;
-    u32 klen; // every key held here is exactly this long (other lengths live in the host overflow list)
+    u32 klen;  // every key held here is exactly this long (other lengths live in the host overflow list)
+    u32 epoch; // != 0: the records' counter copies of this epoch are current (single GPU, every increment since the reset made by the scan)
+    u64 home_mul; // see map_home
 };
+// the scan's side of the copies: add `c` to the record's counter of the current epoch (a word of an older epoch restarts at zero)
+__device__ __forceinline__ void rec_add_val(MapSlot *rec, u32 epoch, u32 c)
+{
+    unsigned long long old = rec->cval;
+    for (;;) {
+        const u32 cur = (u32)(old >> 32) == epoch ? (u32)old : 0u;
+        const unsigned long long nw = (unsigned long long)epoch << 32 | (u32)(cur + c);
+        const unsigned long long prev = atomicCAS(&rec->cval, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+__device__ __forceinline__ void rec_add_bf(MapSlot *rec, int j, u32 epoch, u32 c)
+{
+    unsigned long long old = rec->cbf;
+    for (;;) {
+        const u32 cur = (u32)(old >> 32) == epoch ? (u32)old : 0u;
+        const u32 half = ((cur >> (16 * j)) + c) & 0xFFFFu;
+        const unsigned long long nw = (unsigned long long)epoch << 32 | ((cur & ~(0xFFFFu << (16 * j))) | half << (16 * j));
+        const unsigned long long prev = atomicCAS(&rec->cbf, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
 // The table is addressed with the same XXH3 value the Bloom filter uses for the
 // k-mer (one hash per table row serves both stores): home record from the filter slot
 // idx = h % size (so that a bit of the filter, which knows only idx, lands in the same
 // record as the keys that hash to it), tag from the middle of h.
 __device__ __forceinline__ u32 map_tag(u64 h) { return (u32)(h >> 8) | 0x80000000u; }
-__device__ __forceinline__ u64 map_home(const MapView &m, u64 idx) { return (idx * 0x9E3779B97F4A7C15ULL) >> (64 - m.cap_log2); }
+// home_mul = floor((2^64 - 1) / size): the home record is idx scaled onto the table, so records lie IN ORDER OF THE FILTER SLOT.
+// idx is already an XXH3 value reduced mod size -- as uniform as a second hash of it -- and the order buys locality where it
+// decides everything: the ticket form of the scan files its rows by gate slice, i.e. by ranges of idx, so the rows a wave of
+// the probe kernel holds land in one 1/128th of a 17-34 GB table (tens of pages) instead of on 64 pages of 16 thousand, and
+// the kernel stops waiting for address translation (profiles/r03_pmc_c4share_before.txt).  (The multiplicative hash it
+// replaces, home_mul = 0x9E3779B97F4A7C15, stays available as option map_ordered = 0.)
+__device__ __forceinline__ u64 map_home(const MapView &m, u64 idx) { return (idx * m.home_mul) >> (64 - m.cap_log2); }
 // Counter id of a published key (index into vals[]), or -1.  Read side only (every insert has completed: the host
 // orders the kernels), so a record is read whole -- 16-byte loads issued together, one round trip -- instead of
 // tag, then key low, then key high, then id, each waiting for the one before on the same line.
@@ -365,6 +404,46 @@ __device__ __forceinline__ long long bucket_rank(const MapView &m, u64 idx)
         if (b0 == want) return (long long)b.z;
         if (b1 == want) return (long long)b.w;
         if (b0 == 0 || b1 == 0) return -1;
+        s = (s + 1) & mask;
+    }
+}
+// KMAP::get_count of a key (kmap.hpp:124-131): 0 when absent.  With the records' copies current the answer sits in the
+// record (its fourth 16 bytes, requested with the first two); otherwise vals[id], a second random line.
+__device__ __forceinline__ i32 map_value(const MapView &m, U128 key, u64 h, u64 idx)
+{
+    if (!m.epoch) {
+        const long long id = map_find_id(m, key, h, idx);
+        return id >= 0 ? (i32)m.vals[id] : 0;
+    }
+    const u64 mask = (1ULL << m.cap_log2) - 1;
+    u64 s = map_home(m, idx);
+    const u32 tag = map_tag(h);
+    for (;;) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 a = p[0], b = p[1], d = p[3]; // {tag, id, klo}, {khi, brank}, {cval, cbf}
+        if (a.x == 0) return 0;
+        if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32))
+            return d.y == m.epoch ? (i32)d.x : 0;
+        s = (s + 1) & mask;
+    }
+}
+// BF::get_count of filter slot idx as the genotyping reads it (bloom_filter.hpp:115-125: the u16 cell, 0 when the bit is clear)
+__device__ __forceinline__ u32 bucket_count(const MapView &m, const u32 *counts, u64 idx)
+{
+    if (!m.epoch) {
+        const long long rank = bucket_rank(m, idx);
+        return rank >= 0 ? (u32)(uint16_t)counts[rank] : 0u;
+    }
+    const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
+    u64 s = map_home(m, idx);
+    for (;;) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 c = p[2], d = p[3]; // {bidx0, bidx1}, {cval, cbf}
+        const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+        const u32 both = d.w == m.epoch ? d.z : 0u;
+        if (b0 == want) return both & 0xFFFFu;
+        if (b1 == want) return both >> 16;
+        if (b0 == 0 || b1 == 0) return 0u;
         s = (s + 1) & mask;
     }
 }
@@ -407,7 +486,9 @@ __device__ __forceinline__ void records_load_coop(const MapView &m, u64 s, bool 
     *c = rc;
 }
 // bucket_probe with the home records fetched cooperatively (every lane of the wave calls it; `active` = the lane has a row)
-__device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u64 h, u64 idx, bool active, long long *map_id, long long *rank)
+// map_slot / bf_ent (may be NULL): the record that held the key, and record * 2 + entry of the filter bit -- where the scan keeps the counters' copies
+__device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u64 h, u64 idx, bool active, long long *map_id, long long *rank,
+                                                  u64 *map_slot = nullptr, u64 *bf_ent = nullptr)
 {
     const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
     u64 s = map_home(m, idx);
@@ -422,6 +503,7 @@ __device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u6
             if (a.x == 0) map_open = false;
             else if (a.x == tag && a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) {
                 *map_id = (long long)a.y;
+                if (map_slot) *map_slot = s;
                 map_open = false;
             }
         }
@@ -429,9 +511,11 @@ __device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u6
             const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
             if (b0 == want) {
                 *rank = (long long)b.z;
+                if (bf_ent) *bf_ent = 2 * s;
                 bf_open = false;
             } else if (b1 == want) {
                 *rank = (long long)b.w;
+                if (bf_ent) *bf_ent = 2 * s + 1;
                 bf_open = false;
             } else if (b0 == 0 || b1 == 0)
                 bf_open = false;
@@ -445,7 +529,7 @@ __device__ __forceinline__ void bucket_probe_coop(const MapView &m, U128 key, u6
     }
 }
 // bucket_rank likewise
-__device__ __forceinline__ long long bucket_rank_coop(const MapView &m, u64 idx, bool active)
+__device__ __forceinline__ long long bucket_rank_coop(const MapView &m, u64 idx, bool active, u64 *bf_ent = nullptr)
 {
     const u64 mask = (1ULL << m.cap_log2) - 1, want = idx + 1;
     u64 s = map_home(m, idx);
@@ -454,8 +538,14 @@ __device__ __forceinline__ long long bucket_rank_coop(const MapView &m, u64 idx,
     if (!active) return -1;
     for (;;) {
         const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
-        if (b0 == want) return (long long)b.z;
-        if (b1 == want) return (long long)b.w;
+        if (b0 == want) {
+            if (bf_ent) *bf_ent = 2 * s;
+            return (long long)b.z;
+        }
+        if (b1 == want) {
+            if (bf_ent) *bf_ent = 2 * s + 1;
+            return (long long)b.w;
+        }
         if (b0 == 0 || b1 == 0) return -1;
         s = (s + 1) & mask;
         const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);

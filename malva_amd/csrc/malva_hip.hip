@@ -86,6 +86,13 @@ struct mg_ctx {
     bool blocks_stats_valid = false;
     int blocks_grid[3] = {0, 0, 0};            // persistent grid of cover_blocks_kernel<MODE> (found at first use)
     int use_flat_tier = 1;                     // 0: every general record takes the workgroup kernel (A/B, tests)
+    // the records' own copies of their counters (MapSlot::cval / cbf): current for epoch rec_epoch while rec_ok.  Every ABI call
+    // drops rec_ok on entry unless it is one of those that cannot change a counter behind the copies' back (DeviceGuard, KEEP).
+    int use_record_counters = 1;
+    mutable bool rec_ok = false;
+    bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
+    u32 rec_epoch = 1;
+    int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
     int use_ctx_set = 1;                       // 1: large context filters answer the scan's hit kernel from the set of their set positions (A/B)
     int use_packed_ref_scan = 1;               // 0: the byte-wise reference scan for every window (A/B, tests)
@@ -238,6 +245,14 @@ BFView view(const mg_ctx *c, int which)
     v.pos_set_log2 = b.pos_set_log2;
     return v;
 }
+// Are the records' counter copies worth keeping?  They cost the scan a compare-and-swap per hit beside its add to the vector
+// and save a lookup its second random line.  While vals[] / counts[] stay in the caches (C3: 8 MB) that line is cheap and
+// the copies lose (measured: 1.043 against 1.000 ms per C3 step); beyond that they win (use_record_counters: 0 never, 2 always).
+bool records_wanted(const mg_ctx *c)
+{
+    if (!c->use_record_counters || c->rec_off || c->comm_world > 1 || !c->local_group.empty()) return false;
+    return c->use_record_counters >= 2 || (u64)(c->bf[MG_BF_ALT].nset + c->map.rows_total) * 4 > (256ull << 20);
+}
 MapView view(const mg_ctx *c)
 {
     const MapState &m = c->map;
@@ -246,6 +261,8 @@ MapView view(const mg_ctx *c)
     v.vals = m.vals;
     v.cap_log2 = m.cap_log2;
     v.klen = c->k;
+    v.home_mul = c->map_ordered ? ~0ULL / c->bf[MG_BF_ALT].mod.size : 0x9E3779B97F4A7C15ULL;
+    v.epoch = c->rec_ok && records_wanted(c) ? c->rec_epoch : 0;
     return v;
 }
 
@@ -363,6 +380,7 @@ int map_reserve(mg_ctx *c, u64 extra)
         ov.slots = m.slots;
         ov.cap_log2 = m.cap_log2;
         ov.klen = c->k;
+        ov.home_mul = view(c).home_mul;
         m.slots = nullptr;
         TRY(map_alloc(c, m, want));
         MapView nv = view(c);
@@ -471,10 +489,12 @@ int fill_geno_params(mg_ctx *c, float error_rate, int max_cov, int haploid, Geno
 
 // Every entry point may be called from any host thread: make the context's device current for the calling thread
 // (HIP's current device is per thread; a thread that never called hipSetDevice sits on device 0).
+constexpr bool KEEP = true; // for DeviceGuard: this entry point leaves the counters alone, or changes them together with the records' copies
 struct DeviceGuard {
     int prev = -1;
-    explicit DeviceGuard(const mg_ctx *c)
+    explicit DeviceGuard(const mg_ctx *c, bool keeps_record_counters = false)
     {
+        if (c && !keeps_record_counters) c->rec_ok = false;
         int cur = -1;
         if (c && hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
     }
@@ -589,7 +609,7 @@ MG_EXPORT const char *mg_last_error(const mg_ctx *c) { return c ? c->err.c_str()
 
 MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -597,14 +617,14 @@ MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 }
 MG_EXPORT int mg_synchronize(mg_ctx *c)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
 }
 MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || !name) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) c->use_summary = value != 0;
     else if (!strcmp(name, "scan_rows")) c->scan_rows = (int)value;
@@ -614,6 +634,14 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
     else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
+    else if (!strcmp(name, "map_ordered")) {
+        if (c->map.slots && (value != 0) != (c->map_ordered != 0)) return fail(c, MG_ERR_STATE, "map_ordered is a layout: set it before the index is built or loaded");
+        c->map_ordered = value != 0;
+    }
+    else if (!strcmp(name, "use_record_counters")) {
+        c->use_record_counters = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+        c->rec_ok = false; // (the next scan brings the copies up to date)
+    }
     else if (!strcmp(name, "use_ctx_set")) {
         c->use_ctx_set = (int)value; // (2: whatever the filter's size -- tests)
         c->bf[MG_BF_CTX].pos_set_valid = false;
@@ -656,13 +684,16 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 
 MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || !name || !value) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) *value = c->use_summary;
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
     else if (!strcmp(name, "use_partition")) *value = c->use_partition;
     else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
     else if (!strcmp(name, "map_dense")) *value = c->map_dense;
+    else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
+    else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
+    else if (!strcmp(name, "record_counters_live")) *value = view(c).epoch != 0; // diagnostic: would a lookup launched now read the records' copies?
     else if (!strcmp(name, "use_ctx_set")) *value = c->use_ctx_set;
     else if (!strcmp(name, "ctx_set_log2")) *value = c->bf[MG_BF_CTX].pos_set_valid ? c->bf[MG_BF_CTX].pos_set_log2 : 0;
     else if (!strcmp(name, "use_packed_ref_scan")) *value = c->use_packed_ref_scan;
@@ -701,7 +732,7 @@ MG_EXPORT int mg_bf_insert(mg_ctx *c, int which, const char *rows, size_t stride
 }
 MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint8_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -709,7 +740,7 @@ MG_EXPORT int mg_bf_test(mg_ctx *c, int which, const char *rows, size_t stride, 
 }
 MG_EXPORT int mg_debug_bf_index(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint64_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -795,7 +826,7 @@ MG_EXPORT int mg_bf_increment(mg_ctx *c, int which, const char *rows, size_t str
 }
 MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t stride, size_t n, uint16_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     TRY(check_rows(c, rows, stride, n));
     if (n && !out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -807,7 +838,7 @@ MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t str
 }
 MG_EXPORT int mg_bf_info(mg_ctx *c, int which, uint64_t *size_bits, uint64_t *n_set, int *mode)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     if (size_bits) *size_bits = c->bf[which].size;
     if (n_set) *n_set = c->bf[which].nset;
@@ -839,7 +870,7 @@ MG_EXPORT int mg_map_insert(mg_ctx *c, const char *rows, size_t stride, size_t n
 }
 MG_EXPORT int mg_map_test(mg_ctx *c, const char *rows, size_t stride, size_t n, uint8_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -868,7 +899,7 @@ MG_EXPORT int mg_map_increment(mg_ctx *c, const char *rows, size_t stride, size_
 }
 MG_EXPORT int mg_map_get_count(mg_ctx *c, const char *rows, size_t stride, size_t n, int32_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_rows(c, rows, stride, n));
     if (n == 0) return MG_OK;
     if (!out) return fail(c, MG_ERR_ARG, "out is NULL");
@@ -920,7 +951,7 @@ int map_dump(mg_ctx *c, std::vector<u64> *klo, std::vector<u64> *khi, std::vecto
 
 MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || !n_keys) return MG_ERR_ARG;
     std::vector<u64> a, b;
     std::vector<u32> ids;
@@ -1033,6 +1064,24 @@ MG_EXPORT int mg_ref_scan_resident(mg_ctx *c, uint64_t offset, size_t len)
 
 namespace {
 // `context_bf` for the hit kernel: its set positions as a hash set, (re)built at the first scan after the bits changed
+// Before a scan: bring the records' counter copies up to date (one pass over the record table, once after anything
+// other than a scan has changed a counter: an index load, an import, a per-k-mer increment).  A context that is part of
+// a multi-GPU group, or whose counter vector has been handed out, keeps its counters in the vectors alone.
+int records_current(mg_ctx *c)
+{
+    if (!records_wanted(c)) {
+        c->rec_ok = false;
+        return MG_OK;
+    }
+    if (c->rec_ok || !c->map.slots) return MG_OK;
+    ++c->rec_epoch;
+    MapView m = view(c);
+    hipLaunchKernelGGL(rec_publish_kernel, dim3((unsigned)std::min<u64>(nblocks(1ULL << m.cap_log2), 1u << 20)), dim3(TPB), 0, c->stream, m,
+                       (const u32 *)(c->bf[MG_BF_ALT].mode ? c->bf[MG_BF_ALT].counts : nullptr), c->rec_epoch);
+    HIP_TRY(c, hipGetLastError());
+    c->rec_ok = true;
+    return MG_OK;
+}
 int ctx_set_ready(mg_ctx *c)
 {
     BFState &b = c->bf[MG_BF_CTX];
@@ -1168,7 +1217,7 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
 
 MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     if (c->ref_k > MG_MAX_PACKED_K)
@@ -1177,6 +1226,7 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     if (!d_hi || !d_lo || !d_cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
     if (!c->map.slots) TRY(map_reserve(c, 0));
     TRY(ctx_set_ready(c));
+    TRY(records_current(c));
     // large index: tickets by gate slice (takes precedence over the row-moving partition below)
     const BFState &alt = c->bf[MG_BF_ALT];
     const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6); // slices of half the L2-resident size: 2 MiB
@@ -1268,7 +1318,7 @@ MG_EXPORT size_t mg_kmc_rows_bytes(size_t n) { return (n + 3) / 4 * 4 * 12; }
 
 MG_EXPORT int mg_kmc_pack_rows_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n, void *d_rows_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     TRY(rows12_ok(c));
     if (n == 0) return MG_OK;
@@ -1287,7 +1337,7 @@ MG_EXPORT int mg_kmc_pack_rows_device(mg_ctx *c, const void *d_hi, const void *d
 
 MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     TRY(rows12_ok(c));
@@ -1295,6 +1345,7 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(c, MG_ERR_ARG, "packed rows must be 16-byte aligned");
     if (!c->map.slots) TRY(map_reserve(c, 0));
     TRY(ctx_set_ready(c));
+    TRY(records_current(c));
     u32 row_bits = 27;
     const bool tickets = ticket_form(c, &row_bits);
     const u64 chunk = std::max<u64>(4, 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2)); // (a multiple of 4 rows: chunks start on whole quads)
@@ -1355,7 +1406,7 @@ struct StreamsDrained {
 
 MG_EXPORT int mg_kmc_scan(mg_ctx *c, const uint64_t *hi, const uint64_t *lo, const uint32_t *cnt, size_t n)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n == 0) return MG_OK;
     if (!hi || !lo || !cnt) return fail(c, MG_ERR_ARG, "NULL table pointer");
@@ -1400,7 +1451,7 @@ MG_EXPORT int mg_host_free(void *p)
 MG_EXPORT int mg_kmc_set_lut(mg_ctx *c, const uint64_t *lut, size_t n_lut, uint32_t lut_prefix_len, uint32_t suffix_bytes,
                              uint32_t counter_bytes, uint32_t min_count, uint64_t max_count, uint64_t total_records)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!lut || n_lut == 0) return fail(c, MG_ERR_ARG, "mg_kmc_set_lut: empty prefix table");
     if (lut_prefix_len == 0 || lut_prefix_len > 15) return fail(c, MG_ERR_ARG, "mg_kmc_set_lut: lut_prefix_len %u (1..15)", lut_prefix_len);
@@ -1430,7 +1481,7 @@ MG_EXPORT int mg_kmc_set_lut(mg_ctx *c, const uint64_t *lut, size_t n_lut, uint3
 
 MG_EXPORT int mg_kmc_scan_records(mg_ctx *c, const void *records, size_t n, uint64_t first_record)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n == 0) return MG_OK;
     if (!records) return fail(c, MG_ERR_ARG, "NULL records");
@@ -1468,7 +1519,7 @@ MG_EXPORT int mg_kmc_scan_records(mg_ctx *c, const void *records, size_t n, uint
 MG_EXPORT int mg_kmc_decode_records(mg_ctx *c, const void *records, size_t n, uint64_t first_record, uint64_t *hi_out, uint64_t *lo_out,
                                     uint32_t *cnt_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n == 0) return MG_OK;
     if (!records || !hi_out || !lo_out || !cnt_out) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -1494,7 +1545,7 @@ MG_EXPORT int mg_kmc_decode_records(mg_ctx *c, const void *records, size_t n, ui
 
 MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!c->stats_valid) return fail(c, MG_ERR_STATE, "no scan has run");
     HIP_TRY(c, hipEventSynchronize(c->ev[3]));
@@ -1515,7 +1566,7 @@ MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, const uint64_t *lo, size_t n, uint32_t klen,
                                     uint64_t *out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     if (klen < 1 || klen > MG_MAX_PACKED_K) return fail(c, MG_ERR_LIMIT, "packed k-mers: 1 <= k <= 64");
     if (n == 0) return MG_OK;
@@ -1535,7 +1586,7 @@ MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, co
 
 MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     if (n_bf) *n_bf = c->bf[0].nset;
@@ -1572,6 +1623,7 @@ MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t
     const DeviceGuard on_device(c);
     if (!c || !d_ptr) return MG_ERR_ARG;
     TRY(ensure_joined(c));
+    c->rec_off = true; // the caller may write the vector (an all-reduce by other means): from here on it alone holds the counters
     *d_ptr = c->joined;
     if (n_bf) *n_bf = c->bf[MG_BF_ALT].nset;
     if (n_map) *n_map = c->map.rows_total;
@@ -1579,7 +1631,7 @@ MG_EXPORT int mg_counters_view(mg_ctx *c, void **d_ptr, uint64_t *n_bf, uint64_t
 }
 MG_EXPORT int mg_counters_export_device(mg_ctx *c, void *d_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || !d_out) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     const u64 nb = c->bf[0].nset, nm = c->map.rows_total;
@@ -1599,11 +1651,13 @@ MG_EXPORT int mg_counters_import_device(mg_ctx *c, const void *d_in)
 }
 MG_EXPORT int mg_counters_reset(mg_ctx *c)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
     if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
     for (auto &kv : c->map.irregular) kv.second = 0;
+    ++c->rec_epoch; // every record's copy is now of an older epoch: it reads as zero, like the vectors just cleared
+    c->rec_ok = true;
     return MG_OK;
 }
 
@@ -1865,7 +1919,7 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
                               const uint64_t *sig_kmer_off, size_t n_sigs, const uint64_t *allele_sig_off, size_t n_alleles,
                               uint32_t *cov_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_rows(c, rows, stride, n_rows));
     if (n_alleles == 0) return MG_OK;
     if (!sig_kmer_off || !allele_sig_off || !cov_out || (n_rows && !is_ref)) return fail(c, MG_ERR_ARG, "NULL descriptor");
@@ -1897,7 +1951,7 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
 MG_EXPORT int mg_genotype_device(mg_ctx *c, const void *d_cov, const void *d_freq, const void *d_var_allele_off, size_t n_vars, float error_rate,
                                  int max_cov, int haploid, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs, const void *d_var_gt_off)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!d_cov || !d_freq || !d_var_allele_off || !d_gt1 || !d_gt2 || !d_gq || !d_status) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -1915,7 +1969,7 @@ MG_EXPORT int mg_genotype(mg_ctx *c, const uint32_t *cov, const float *freq, con
                           float error_rate, int max_cov, int haploid, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status,
                           double *probs, const uint64_t *var_gt_off)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!cov || !freq || !var_allele_off || !gt1 || !gt2 || !gq || !status) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -2121,7 +2175,7 @@ template <int MODE> int blocks_tier3(BlocksRun &R, bool compact, u32 *d_cov, u8 
 // block cutting for a batch of kept records in file order (main.cpp:341, 547; var_block.hpp:77-80), on the device
 MG_EXPORT int mg_cut_blocks_device(mg_ctx *c, const mg_panel_dev *p, void *d_blk_var_off_out, void *d_var_block_out, void *d_n_blocks_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     TRY(check_panel(c, p, false));
     if (!d_n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -2142,7 +2196,7 @@ MG_EXPORT int mg_cut_blocks_device(mg_ctx *c, const mg_panel_dev *p, void *d_blk
 MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const uint32_t *ref_size, const uint32_t *min_size, const uint32_t *contig_id,
                             uint32_t *blk_var_off_out, size_t *n_blocks_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (!n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
     *n_blocks_out = 0;
@@ -2172,7 +2226,7 @@ MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const 
 MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const void *d_blk_var_off, const void *d_var_block, const void *d_n_blocks, int haploid,
                                      void *d_cov_out, void *d_overflow_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     TRY(check_panel(c, p, true));
     if (p->n_vars == 0) return MG_OK;
@@ -2214,7 +2268,7 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
 // timing and counts of the most recent mg_cover_blocks_device (waits for it)
 MG_EXPORT int mg_blocks_stats(mg_ctx *c, float *ms_out, uint64_t *counts_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || !ms_out || !counts_out) return MG_ERR_ARG;
     if (!c->blocks_stats_valid) return fail(c, MG_ERR_STATE, "no mg_cover_blocks_device yet");
     HIP_TRY(c, hipEventSynchronize(c->ev_b[3]));
@@ -2344,7 +2398,7 @@ int cover_blocks_host(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, 
                       const uint32_t *allele_off, const char *pool, size_t pool_len, const uint8_t *canon, const uint16_t *gt, const uint32_t *sp_off,
                       const uint32_t *sp_sample, const uint16_t *sp_gt, uint16_t sp_default, uint32_t n_samples, int haploid, uint32_t *cov_out, uint8_t *overflow_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!cov_out || !overflow_out) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -2505,7 +2559,7 @@ int reference_alloc(mg_ctx *c, size_t len)
 
 MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || (len && !ascii)) return MG_ERR_ARG;
     TRY(reference_alloc(c, len));
     if (len) HIP_TRY(c, hipMemcpyAsync(c->d_ref, ascii, len, hipMemcpyHostToDevice, c->stream));
@@ -2517,7 +2571,7 @@ MG_EXPORT int mg_reference_upload(mg_ctx *c, const char *ascii, size_t len)
 // the same from a buffer already on the device (a copy is kept: the caller's buffer may go)
 MG_EXPORT int mg_reference_upload_device(mg_ctx *c, const void *d_ascii, size_t len)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c || (len && !d_ascii)) return MG_ERR_ARG;
     TRY(reference_alloc(c, len));
     if (len) HIP_TRY(c, hipMemcpyAsync(c->d_ref, d_ascii, len, hipMemcpyDeviceToDevice, c->stream));
@@ -2533,7 +2587,7 @@ MG_EXPORT int mg_call_isolated_device(mg_ctx *c, size_t n_vars, const void *d_po
                                       void *d_cov_out, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs,
                                       const void *d_var_gt_off)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!c->d_ref) return fail(c, MG_ERR_STATE, "mg_reference_upload first");
@@ -2564,7 +2618,7 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
                                uint32_t *cov_out, int32_t *gt1, int32_t *gt2, int32_t *gq, uint8_t *status, double *probs,
                                const uint64_t *var_gt_off)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!pos || !var_allele_off || !allele_off || !allele_pool || !freq || !present_mask || !flags || !cov_out || !gt1 || !gt2 ||
@@ -2627,7 +2681,7 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
 
 MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *counts_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (words_out) HIP_TRY(c, hipMemcpy(words_out, b.words, b.nwords * 8, hipMemcpyDeviceToHost));
@@ -2683,7 +2737,7 @@ MG_EXPORT int mg_bf_import(mg_ctx *c, int which, int mode, uint64_t size_bits, c
 // ascending positions of the set bits (= counter order) instead of gigabytes of zeros.
 MG_EXPORT int mg_bf_export_sparse(mg_ctx *c, int which, uint64_t *positions_out, uint16_t *counts_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     TRY(check_which(c, which));
     BFState &b = c->bf[which];
     if (!b.mode) return fail(c, MG_ERR_STATE, "sparse export needs the filter finalised (rank directory)");
@@ -2759,7 +2813,7 @@ void unpack_lform(u64 lo, u64 hi, u32 k, char *out)
 // expected to be k long, as every signature k-mer of the reference is).
 MG_EXPORT int mg_map_export(mg_ctx *c, char *rows_out, size_t stride, int32_t *vals_out)
 {
-    const DeviceGuard on_device(c);
+    const DeviceGuard on_device(c, KEEP);
     if (!c) return MG_ERR_ARG;
     std::vector<u64> lo, hi;
     std::vector<u32> ids;

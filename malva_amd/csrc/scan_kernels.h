@@ -1006,8 +1006,12 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
             long long id, rank; // one record answers both: exact-map key?  bit idx of bf set?
-            bucket_probe_coop(map, c, h, idx, live, &id, &rank); // (whole waves: the records are fetched four lanes to a record)
-            if (id >= 0) atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
+            u64 slot = 0;
+            bucket_probe_coop(map, c, h, idx, live, &id, &rank, &slot); // (whole waves: the records are fetched four lanes to a record)
+            if (id >= 0) {
+                atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
+                if (map.epoch) rec_add_val(&map.slots[slot], map.epoch, count); // ... and the record's copy, on the line just read
+            }
             hit = rank >= 0;
         }
         st.push(hit, m, count);
@@ -1035,8 +1039,12 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
         // both random reads are in flight together)
         const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
         const bool in_ctx = live && bf_bit_via_set(ctx, cidx);            // context_bf.test_key (main.cpp:496)
-        const long long rank = bucket_rank_coop(map, idx, live);          // set for every row of this list
-        if (!in_ctx && rank >= 0) atomicAdd(&bf.counts[rank], hits.cnt[j]); // bf.increment (main.cpp:498)
+        u64 ent = 0;
+        const long long rank = bucket_rank_coop(map, idx, live, &ent);    // set for every row of this list
+        if (!in_ctx && rank >= 0) {
+            atomicAdd(&bf.counts[rank], hits.cnt[j]); // bf.increment (main.cpp:498)
+            if (map.epoch) rec_add_bf(&map.slots[ent >> 1], (int)(ent & 1), map.epoch, hits.cnt[j]);
+        }
     }
 }
 

@@ -329,3 +329,24 @@ __global__ void __launch_bounds__(TPB) widen_u16_kernel(const uint16_t *in, u32 
     if (i < n) out[i] = in[i];
 }
 
+
+// Every record's counter copies set from the vectors (MapSlot::cval / cbf, epoch `epoch`): see records_current.
+__global__ void __launch_bounds__(TPB) rec_publish_kernel(MapView m, const u32 *__restrict__ counts, u32 epoch)
+{
+    const u64 n = 1ULL << m.cap_log2;
+    for (u64 s = (u64)blockIdx.x * TPB + threadIdx.x; s < n; s += (u64)gridDim.x * TPB) {
+        MapSlot *rec = &m.slots[s];
+        const uint4 *p = reinterpret_cast<const uint4 *>(rec);
+        const uint4 a = p[0], b = p[1], c = p[2];
+        const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+        if (a.x < 2 && !b0) continue; // an empty record: its copies are of epoch 0 and are never read
+        const u32 val = a.x >= 2 ? m.vals[a.y] : 0u;
+        u32 both = 0;
+        if (counts) {
+            if (b0) both |= counts[b.z] & 0xFFFFu;
+            if (b1) both |= (counts[b.w] & 0xFFFFu) << 16;
+        }
+        rec->cval = (unsigned long long)epoch << 32 | val;
+        rec->cbf = (unsigned long long)epoch << 32 | both;
+    }
+}

@@ -59,8 +59,7 @@ template <class IN> __device__ __forceinline__ i32 weight_bytes(const IN &in, in
         U128 key;
         if (pack_regular(can, k, (int)map.klen, &key)) {
             const u64 h = xxh3_bytes(can, k);
-            const long long id = map_find_id(map, key, h, mod_size(h, bf.mod));
-            if (id >= 0) return (i32)map.vals[id];
+            return map_value(map, key, h, mod_size(h, bf.mod));
         }
         return 0;
     }
@@ -203,13 +202,8 @@ __device__ __forceinline__ void iso_cover_body(const u8 *reference, const u64 *_
                 const U128 key = lt128(L, rc) ? L : rc;
                 const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
                 const u64 idx = mod_size(h, bf.mod);
-                if (a == 0) {
-                    const long long id = map_find_id(map, key, h, idx);
-                    w = id >= 0 ? (i32)map.vals[id] : 0;
-                } else { // the filter's directory entry sits in the exact map's record of the same slot
-                    const long long rank = bucket_rank(map, idx);
-                    w = rank >= 0 ? (i32)(uint16_t)bf.counts[rank] : 0;
-                }
+                if (a == 0) w = map_value(map, key, h, idx);
+                else w = (i32)bucket_count(map, bf.counts, idx); // the filter's directory entry sits in the exact map's record of the same slot
                 if (w > 0) out = (u32)(float)(u32)w;
             }
         }
@@ -580,8 +574,7 @@ __device__ __forceinline__ i32 bk_weight(const u8 *buf, int len, bool is_ref, co
             const u64 h = xxh3_packed(key, len);
             if (is_ref) {
                 if (len != (int)map.klen) return 0;
-                const long long id = map_find_id(map, key, h, mod_size(h, bf.mod));
-                return id >= 0 ? (i32)map.vals[id] : 0;
+                return map_value(map, key, h, mod_size(h, bf.mod));
             }
             const u64 idx = mod_size(h, bf.mod);
             return (i32)(uint16_t)bf_count_at(bf, idx);
