@@ -7,6 +7,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <sys/stat.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -335,6 +337,31 @@ class LineReader {
     LineReader(const LineReader &) = delete;
     LineReader &operator=(const LineReader &) = delete;
     bool ok() const { return f != nullptr; }
+    bool is_bcf() const { return bcf; }
+    // Text files only: about `want` bytes of whole lines (terminators included; the last line of the file may lack one) appended
+    // to `blk`; false at end of file.  One bulk copy per block instead of one string per line: the thread that reads a
+    // panel of millions of short records is otherwise what the decoding threads wait for.
+    bool next_block(std::string &blk, size_t want)
+    {
+        const size_t at0 = blk.size();
+        for (;;) {
+            if (pos == end && !fill()) break;
+            const size_t have = blk.size() - at0;
+            if (have < want) { // bulk
+                const size_t take = std::min(end - pos, want - have);
+                blk.append(buf.data() + pos, take);
+                pos += take;
+                continue;
+            }
+            if (blk.back() == '\n') break; // ... then up to the end of the line
+            const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
+            const size_t take = nl ? (size_t)(nl - (buf.data() + pos)) + 1 : end - pos;
+            blk.append(buf.data() + pos, take);
+            pos += take;
+            if (nl) break;
+        }
+        return blk.size() > at0;
+    }
     // next line without its terminator ('\n' or "\r\n"); false at end of file
     bool next(std::string &line)
     {
@@ -437,6 +464,7 @@ struct Variant {
     bool has_alts = true, is_present = true;
     std::vector<float> frequencies;
     std::vector<uint32_t> coverages;
+    std::string text_prefix; // VcfReader::want_prefix: CHROM .. QUAL of the output record (output_variants, var_block.hpp:337-352), made by the decoding thread
 
     int n_alleles() const { return (int)alts.size() + 1; }
     const std::string &allele(int i) const { return i == 0 ? ref_sub : alts.at((size_t)i - 1); }
@@ -470,7 +498,8 @@ class VcfReader {
     // the records out in file order.  An exception raised by a record is rethrown by next() when that record's
     // turn comes, after every record in front of it.
     struct Chunk {
-        std::vector<std::string> lines;
+        std::string text;               // text files: a block of whole lines, cut into records by the decoding thread ...
+        std::vector<std::string> lines; // ... BCF: the records as the reader translated them
         std::vector<Variant> vars;
         size_t n_ok = 0;          // records decoded before `err` (all of them when err is empty)
         std::exception_ptr err;
@@ -488,6 +517,8 @@ class VcfReader {
     size_t cur_at = 0;
 
   public:
+    bool want_prefix = false;    // `call`: fill Variant::text_prefix (set before the first next())
+    uint64_t file_bytes = 0;     // size of the file on disk (0 when unknown): decides whether decoding goes to the pool
     std::vector<std::string> header_lines; // the ## lines
     std::vector<std::string> samples;
     std::vector<int> keep; // kept sample columns, VCF order (htslib keeps a mask)
@@ -498,6 +529,10 @@ class VcfReader {
         if (!in.ok()) {
             error = "cannot open " + path;
             return;
+        }
+        {
+            struct stat st;
+            if (stat(path.c_str(), &st) == 0) file_bytes = (uint64_t)st.st_size;
         }
         std::string line;
         while (in.next(line)) {
@@ -542,6 +577,16 @@ class VcfReader {
     // one record line -> Variant; throws std::runtime_error on records the reference would crash on
     void parse(const std::string &line, Variant &v, const std::string &freq_key, bool uniform, Scratch &sc) const
     {
+        parse(line.data(), line.size(), v, freq_key, uniform, sc);
+    }
+    // the record's text as a span with text[size] == '\0'
+    void parse(const char *text, size_t size, Variant &v, const std::string &freq_key, bool uniform, Scratch &sc) const
+    {
+        decode(text, size, v, freq_key, uniform, sc);
+        if (want_prefix && v.has_alts) make_prefix(v);
+    }
+    void decode(const char *text, size_t size, Variant &v, const std::string &freq_key, bool uniform, Scratch &sc) const
+    {
         auto &cols = sc.cols;
         auto &fmt = sc.fmt;
         auto &fld = sc.fld;
@@ -551,9 +596,9 @@ class VcfReader {
         auto &tok_off = sc.tok_off;
         // the nine fixed columns; the sample columns (tens of thousands on a panel) are walked in place below
         cols.clear();
-        const char *const line_end = line.data() + line.size();
+        const char *const line_end = text + size;
         const char *samples_at = nullptr;
-        for (const char *p = line.data();;) {
+        for (const char *p = text;;) {
             const char *t = (const char *)memchr(p, '\t', (size_t)(line_end - p));
             cols.emplace_back(p, (size_t)((t ? t : line_end) - p));
             if (!t) break;
@@ -563,7 +608,7 @@ class VcfReader {
                 break;
             }
         }
-        if (cols.size() < 8) throw std::runtime_error("malformed VCF record: " + line.substr(0, 60));
+        if (cols.size() < 8) throw std::runtime_error("malformed VCF record: " + std::string(text, std::min<size_t>(size, 60)));
         v = Variant();
         v.seq_name = std::string(cols[0]);
         v.ref_pos = atoi(std::string(cols[1]).c_str()) - 1;
@@ -743,6 +788,29 @@ class VcfReader {
             v.phasing[i] = is_ph ? 1 : 0;
         }
     }
+    static void make_prefix(Variant &v)
+    {
+        std::string &s = v.text_prefix;
+        char num[64];
+        s.reserve(v.seq_name.size() + v.idx.size() + v.ref_sub.size() + 40);
+        s = v.seq_name;
+        snprintf(num, sizeof num, "\t%d\t", v.ref_pos + 1);
+        s += num;
+        s += v.idx;
+        s += '\t';
+        s += v.ref_sub;
+        s += '\t';
+        for (size_t i = 0; i < v.alts.size(); ++i) {
+            if (i) s += ',';
+            s += v.alts[i];
+        }
+        s += '\t';
+        if (std::isnan(v.quality)) s += '.';
+        else { // ostream << float, default precision
+            snprintf(num, sizeof num, "%g", v.quality);
+            s += num;
+        }
+    }
 
     void start(const std::string &freq_key, bool uniform)
     {
@@ -756,7 +824,16 @@ class VcfReader {
             for (;;) {
                 auto ch = std::make_shared<Chunk>();
                 size_t bytes = 0;
-                while (ch->lines.size() < 2048 && bytes < (8u << 20)) {
+                if (!in.is_bcf()) {
+                    if (have_pending) {
+                        ch->text = pending;
+                        ch->text += '\n';
+                        have_pending = false;
+                    }
+                    ch->text.reserve((1u << 20) + (64u << 10));
+                    in.next_block(ch->text, 1u << 20);
+                }
+                while (in.is_bcf() && ch->lines.size() < 2048 && bytes < (8u << 20)) {
                     if (have_pending) {
                         line.swap(pending);
                         have_pending = false;
@@ -768,7 +845,7 @@ class VcfReader {
                     line.clear();
                 }
                 std::unique_lock<std::mutex> lk(mu);
-                if (ch->lines.empty()) {
+                if (ch->lines.empty() && ch->text.empty()) {
                     eof = true;
                     cv.notify_all();
                     return;
@@ -792,16 +869,36 @@ class VcfReader {
                         ch = todo.front();
                         todo.pop_front();
                     }
-                    ch->vars.resize(ch->lines.size());
                     size_t i = 0;
                     try {
-                        for (; i < ch->lines.size(); ++i) parse(ch->lines[i], ch->vars[i], freq_key, uniform, sc);
+                        if (!ch->text.empty()) { // lines cut in place: each terminator becomes the NUL the decoder stops at
+                            char *p = &ch->text[0], *const e = p + ch->text.size();
+                            ch->vars.reserve(ch->text.size() / 40 < 4096 ? ch->text.size() / 40 + 1 : 4096);
+                            while (p < e) {
+                                char *nl = (char *)memchr(p, '\n', (size_t)(e - p));
+                                char *le = nl ? nl : e;
+                                size_t n = (size_t)(le - p);
+                                if (n && p[n - 1] == '\r') --n;
+                                p[n] = '\0'; // (at the very end of the block this is the string's own terminator)
+                                if (n && p[0] != '#') {
+                                    ch->vars.emplace_back();
+                                    parse(p, n, ch->vars.back(), freq_key, uniform, sc);
+                                    ++i;
+                                }
+                                p = le + 1;
+                            }
+                        } else {
+                            ch->vars.resize(ch->lines.size());
+                            for (; i < ch->lines.size(); ++i) parse(ch->lines[i], ch->vars[i], freq_key, uniform, sc);
+                        }
                     } catch (...) {
                         ch->err = std::current_exception();
+                        if (!ch->text.empty()) ch->vars.pop_back(); // the record that threw
                     }
                     ch->n_ok = i;
                     ch->lines.clear();
                     ch->lines.shrink_to_fit();
+                    std::string().swap(ch->text);
                     std::lock_guard<std::mutex> lk(mu);
                     ch->done = true;
                     cv.notify_all();
@@ -810,13 +907,24 @@ class VcfReader {
     }
 
   public:
+    // Start decoding now (pool mode only), before the first next(): a caller with other start-up work to do -- the devices, the
+    // index, the sample's table -- finds the first 2 x threads blocks decoded when it comes for them.  Same arguments as next().
+    void decode_ahead(const std::string &freq_key, bool uniform)
+    {
+        if (started) return;
+        threaded = keep.size() >= 32 || file_bytes >= (8u << 20);
+        if (const char *e = getenv("MALVA_GENO_VCF_POOL")) threaded = atoi(e) != 0;
+        if (threaded) start(freq_key, uniform);
+    }
     // false at end of file; throws what parse() threw for the record whose turn it is
     bool next(Variant &v, const std::string &freq_key, bool uniform)
     {
         if (!started) {
             // a handful of sample columns: decoding a record costs less than handing it between threads (measured:
             // 0.53 us inline, 0.88 us through the pool); a panel's line is tens of kilobytes and the pool pays
-            threaded = keep.size() >= 32;
+            // -- unless the file is large: then the thread that calls next() has the batches to build, and every
+            // microsecond of decoding it does not do itself shortens the run (1e6 records x 2 samples: 0.36 s of 0.83)
+            threaded = keep.size() >= 32 || file_bytes >= (8u << 20);
             if (const char *e = getenv("MALVA_GENO_VCF_POOL")) threaded = atoi(e) != 0; // tests force either path
             if (threaded) start(freq_key, uniform);
             else {

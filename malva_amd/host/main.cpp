@@ -134,6 +134,33 @@ bool parse_arguments(int argc, char **argv, Options &o)
     return true;
 }
 
+// MALVA_GENO_TIMERS=1: where the host threads spend their time, summed per label, printed at exit (profiles/*cli*)
+struct Timers {
+    bool on = getenv("MALVA_GENO_TIMERS") != nullptr;
+    std::mutex mu;
+    std::map<std::string, double> acc;
+    void add(const char *what, double s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        acc[what] += s;
+    }
+    ~Timers()
+    {
+        if (!on) return;
+        for (const auto &kv : acc) fprintf(stderr, "[malva-geno/timer] %-28s %.3fs\n", kv.first.c_str(), kv.second);
+    }
+};
+Timers g_timers;
+struct Timed {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit Timed(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~Timed()
+    {
+        if (g_timers.on) g_timers.add(what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // pelapsed(), main.cpp:93-115
 auto t_start = std::chrono::steady_clock::now();
 auto t_last = t_start;
@@ -203,9 +230,15 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
                                          Device *cutter = nullptr)
 {
     static const std::string empty;
+    std::string ref_name;            // (a panel names a few dozen sequences over millions of records: the last answer is nearly always the next one)
+    const std::string *ref_seq = nullptr;
     auto ref_of = [&](const std::string &name) -> const std::string & {
-        auto it = refs.seqs.find(name);
-        return it == refs.seqs.end() ? empty : it->second;
+        if (!ref_seq || name != ref_name) {
+            auto it = refs.seqs.find(name);
+            ref_seq = it == refs.seqs.end() ? &empty : &it->second;
+            ref_name = name;
+        }
+        return *ref_seq;
     };
     if (cutter && !getenv("MALVA_GENO_HOST_CUT")) {
         // records per cut batch; MALVA_GENO_CUT_BATCH exists so tests can put a batch seam inside every block
@@ -224,6 +257,7 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
         while (more) {
             kept.clear();
             cells = 0;
+            Timed *t_parse = new Timed("main: vcf.next");
             while (kept.size() < batch_max && cells < (64u << 20) && (more = vcf.next(v, o.freq_key, o.uniform))) {
                 ++i;
                 if (i % 5000 == 0) pelapsed("Processed " + std::to_string(i) + " variants", true);
@@ -235,6 +269,7 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
                 cells += v.genotypes.size();
                 kept.push_back(std::move(v));
             }
+            delete t_parse;
             if (kept.empty()) continue;
             const bool carry = !vb.empty();
             const size_t n = kept.size() + (carry ? 1 : 0);
@@ -254,12 +289,14 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
             }
             size_t nb = 0;
             {
+                Timed t_cut("main: mg_cut_blocks (+ lock)");
                 std::lock_guard<std::mutex> lk(cutter->mu);
                 cutter->check(mg_cut_blocks(cutter->ctx, n, pos.data(), ref_size.data(), min_size.data(), cid.data(), off.data(), &nb), "mg_cut_blocks");
             }
             last_cid = cid[n - 1];
             ++n_batches;
             size_t b = 0; // off[b] = next block start at or after the current element
+            Timed t_blocks("main: blocks -> batches");
             for (size_t q = carry ? 1 : 0; q < n; ++q) {
                 while (b < nb && off[b] < q) ++b;
                 const bool cut = b < nb && off[b] == q;
@@ -395,22 +432,63 @@ void save_index(Device &dev, const Options &o)
     p.rows.resize(nkeys * STRIDE);
     p.vals.resize(nkeys);
     if (nkeys) dev.check(mg_map_export(dev.ctx, p.rows.data(), STRIDE, p.vals.data()), "mg_map_export");
+    // Both containers by default: the reference's (.zst: one zstd stream over the filters' full bit vectors -- gigabytes of
+    // zeros through a single-threaded codec, ~1.5 s to write and ~1.2 s to read at -b 4) for the reference's own binary, and
+    // this build's sparse one (.hipz, milliseconds), which `call` prefers while it is not older than the .zst beside it.
+    // MALVA_GENO_INDEX_FORMAT=zst | hipz writes one of them only.  Each is written under a temporary name and renamed: a run
+    // that dies mid-write leaves no truncated index for `call` to find.
     const char *fmt = getenv("MALVA_GENO_INDEX_FORMAT");
-    // written under a temporary name and renamed: a run that dies mid-write leaves no truncated index for `call` to prefer
-    const bool hipz = fmt && std::string(fmt) == "hipz";
-    const std::string final_path = index_path(o, hipz ? ".hipz" : ".zst"), tmp_path = final_path + ".tmp." + std::to_string((long)getpid());
+    const std::string want = fmt ? fmt : "both";
+    if (want != "both" && want != "zst" && want != "hipz") throw std::runtime_error("MALVA_GENO_INDEX_FORMAT: zst, hipz or both");
+    auto write_one = [&](bool hipz) {
+        const std::string final_path = index_path(o, hipz ? ".hipz" : ".zst");
+        if (want != "both" && (want == "hipz") != hipz) {
+            unlink(final_path.c_str()); // no stale index of the other kind beside the new one
+            return;
+        }
+        const std::string tmp_path = final_path + ".tmp." + std::to_string((long)getpid());
+        try {
+            Timed t(hipz ? "index file: .hipz" : "index file: .zst");
+            if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size);
+            else save_index_zst(tmp_path, p, o.bf_size);
+        } catch (...) {
+            unlink(tmp_path.c_str());
+            throw;
+        }
+        if (rename(tmp_path.c_str(), final_path.c_str()) != 0) {
+            unlink(tmp_path.c_str());
+            throw std::runtime_error("cannot write " + final_path);
+        }
+    };
+    // side by side (the .zst takes seconds, single-threaded inside libzstd); the .hipz is renamed into place after the .zst,
+    // so it is the newer file of the two
+    auto zst_job = std::async(std::launch::async, [&]() { write_one(false); });
+    std::exception_ptr hipz_err;
+    const std::string hipz_final = index_path(o, ".hipz"), hipz_tmp = hipz_final + ".tmp." + std::to_string((long)getpid());
+    if (want == "zst") unlink(hipz_final.c_str());
+    else {
+        try {
+            Timed t("index file: .hipz");
+            save_index_hipz(hipz_tmp, p, o.k, o.ref_k, o.bf_size);
+        } catch (...) {
+            unlink(hipz_tmp.c_str());
+            hipz_err = std::current_exception();
+        }
+    }
     try {
-        if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size);
-        else save_index_zst(tmp_path, p, o.bf_size);
+        zst_job.get();
     } catch (...) {
-        unlink(tmp_path.c_str());
+        unlink(hipz_tmp.c_str());
         throw;
     }
-    if (rename(tmp_path.c_str(), final_path.c_str()) != 0) {
-        unlink(tmp_path.c_str());
-        throw std::runtime_error("cannot write " + final_path);
+    if (hipz_err) std::rethrow_exception(hipz_err);
+    if (want != "zst") {
+        if (rename(hipz_tmp.c_str(), hipz_final.c_str()) != 0) {
+            unlink(hipz_tmp.c_str());
+            throw std::runtime_error("cannot write " + hipz_final);
+        }
+        utimensat(AT_FDCWD, hipz_final.c_str(), nullptr, 0); // (a rename keeps the time of the last write, which was before the .zst's)
     }
-    unlink(index_path(o, hipz ? ".zst" : ".hipz").c_str()); // (`call` prefers .zst: no stale index of the other kind beside the new one)
 }
 
 // every device of a multi-GPU call holds the whole index (the read-only structures are replicated):
@@ -433,12 +511,24 @@ template <class F> void on_all_devices(std::vector<Device> &devs, F f)
         if (e) std::rethrow_exception(e);
 }
 
-void load_index(std::vector<Device> &devs, const Options &o)
+// the index file -> payload (host only: runs beside the devices' start-up), then payload -> every context
+void read_index(const Options &o, IndexPayload &p)
 {
-    IndexPayload p;
-    if (file_exists(index_path(o, ".zst"))) load_index_zst(index_path(o, ".zst"), p, o.bf_size, STRIDE);
-    else if (file_exists(index_path(o, ".hipz"))) load_index_hipz(index_path(o, ".hipz"), p, o.k, o.ref_k, o.bf_size, STRIDE);
+    Timed t("startup: index file -> payload");
+    const std::string zst = index_path(o, ".zst"), hipz = index_path(o, ".hipz");
+    struct stat sz, sh;
+    const bool has_zst = stat(zst.c_str(), &sz) == 0, has_hipz = stat(hipz.c_str(), &sh) == 0;
+    auto newer = [](const struct stat &a, const struct stat &b) { // a strictly newer than b
+        return a.st_mtim.tv_sec != b.st_mtim.tv_sec ? a.st_mtim.tv_sec > b.st_mtim.tv_sec : a.st_mtim.tv_nsec > b.st_mtim.tv_nsec;
+    };
+    // the sparse container unless the reference's one is newer (an index brought over from the reference's binary)
+    if (has_hipz && !(has_zst && newer(sz, sh))) load_index_hipz(hipz, p, o.k, o.ref_k, o.bf_size, STRIDE);
+    else if (has_zst) load_index_zst(zst, p, o.bf_size, STRIDE);
     else throw std::runtime_error("cannot open index " + index_path(o, ".zst") + " (run `malva-geno index` with the same -k -r -b first)");
+}
+void import_index(std::vector<Device> &devs, const Options &o, const IndexPayload &p)
+{
+    Timed t("startup: payload -> device");
     on_all_devices(devs, [&](Device &dev, size_t) {
         const int which[2] = {MG_BF_CTX, MG_BF_ALT};
         for (int i = 0; i < 2; ++i)
@@ -971,40 +1061,46 @@ struct Batch { // inputs of mg_call_isolated (isolated) or mg_lookup_cover + mg_
     size_t n() const { return var_allele_off.size() - 1; }
 };
 
-std::string fmt_float(float q) // ostream << float, default precision
-{
-    char b[64];
-    snprintf(b, sizeof b, "%g", q);
-    return b;
-}
-
 int call_main(const Options &o)
 {
+    // Start-up runs three things side by side: the FASTA (host), the index file (host) and the devices (HIP start-up is
+    // ~0.4 s by itself).  The sample's table is scanned as soon as the index is on the device; the reference joins after it.
     Reference refs;
-    if (!read_fasta(o.fasta_path, o.strip_chr, refs)) {
-        std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
-        return 1;
+    auto fasta_read = std::async(std::launch::async, [&]() {
+        Timed t("startup: FASTA");
+        return read_fasta(o.fasta_path, o.strip_chr, refs);
+    });
+    IndexPayload payload;
+    auto index_read = std::async(std::launch::async, [&]() { read_index(o, payload); });
+    VcfReader vcf(o.vcf_path, o.samples); // (a panel of any size is decoded by a pool of threads: started here, it works through start-up)
+    if (vcf.ok()) {
+        vcf.want_prefix = true;
+        vcf.decode_ahead(o.freq_key, o.uniform);
     }
+    auto fail_early = [&](const std::string &msg) { // (the readers hold references to this frame: let them finish first)
+        fasta_read.wait();
+        index_read.wait();
+        std::cerr << msg << std::endl;
+        return 1;
+    };
     // the sample's k-mers: the KMC database the reference opens (main.cpp:444-449), or -- when there is none -- a text dump
     std::string table = o.kmc_path;
     const bool use_db = KmcDb::present(o.kmc_path);
     if (!use_db) {
         if (file_exists(o.kmc_path + ".txt")) table = o.kmc_path + ".txt";
-        if (!file_exists(table)) {
-            std::cerr << "ERROR: cannot open " << o.kmc_path << std::endl;
-            return 1;
-        }
+        if (!file_exists(table)) return fail_early("ERROR: cannot open " + o.kmc_path);
     }
     // --gpus N: one context per device -d .. -d+N-1.  MALVA_GENO_SHARE_DEVICE=1 puts all N contexts on device -d: the
     // N-way layout (sharded scan, exchange, split genotyping) rehearsed on a one-GPU box, the exchange then being a
     // kernel instead of RCCL (which rejects two ranks on one device).
     const bool share_device = getenv("MALVA_GENO_SHARE_DEVICE") && atoi(getenv("MALVA_GENO_SHARE_DEVICE")) != 0;
     std::vector<Device> devs((size_t)o.gpus);
-    for (int d = 0; d < o.gpus; ++d)
-        if (mg_create(&devs[(size_t)d].ctx, share_device ? o.device : o.device + d, o.k, o.ref_k, o.bf_size) != MG_OK) {
-            std::cerr << "ERROR: no usable MI355X/HIP device " << (share_device ? o.device : o.device + d) << "; this build has no CPU path" << std::endl;
-            return 1;
-        }
+    {
+        Timed t("startup: devices");
+        for (int d = 0; d < o.gpus; ++d)
+            if (mg_create(&devs[(size_t)d].ctx, share_device ? o.device : o.device + d, o.k, o.ref_k, o.bf_size) != MG_OK)
+                return fail_early("ERROR: no usable MI355X/HIP device " + std::to_string(share_device ? o.device : o.device + d) + "; this build has no CPU path");
+    }
     if (o.gpus > 1) {
         std::vector<mg_ctx *> ctxs;
         for (auto &d : devs) ctxs.push_back(d.ctx);
@@ -1013,11 +1109,25 @@ int call_main(const Options &o)
         mg_comm_info(devs[0].ctx, nullptr, nullptr, &backend);
         std::cerr << "[malva-geno] " << o.gpus << " contexts, exchange: " << (backend == MG_COMM_RCCL ? "RCCL all-reduce" : "one device, kernel sum") << std::endl;
     }
-    load_index(devs, o);
-    pelapsed("Reference processed");
-    if (use_db) scan_kmc_db(devs, o, o.kmc_path); // main.cpp:482-500
-    else scan_table(devs, o, table);
+    try {
+        index_read.get();
+    } catch (...) {
+        fasta_read.wait();
+        throw;
+    }
+    import_index(devs, o, payload);
+    payload = IndexPayload();
+    pelapsed("Reference processed"); // (the phase names are the reference's, main.cpp:452-470; the FASTA itself may still be on its way)
+    {
+        Timed t("startup: table scan");
+        if (use_db) scan_kmc_db(devs, o, o.kmc_path); // main.cpp:482-500
+        else scan_table(devs, o, table);
+    }
     pelapsed("BF weights created");
+    if (!fasta_read.get()) {
+        std::cerr << "ERROR: cannot open " << o.fasta_path << std::endl;
+        return 1;
+    }
 
     // concatenated reference for the fused isolated path
     std::map<std::string, uint64_t> contig_base;
@@ -1027,6 +1137,7 @@ int call_main(const Options &o)
             contig_base[name] = all.size();
             all += refs.seqs.at(name);
         }
+        Timed t("startup: reference upload");
         on_all_devices(devs, [&](Device &d, size_t) { d.check(mg_reference_upload(d.ctx, all.data(), all.size()), "mg_reference_upload"); });
     }
     {
@@ -1036,8 +1147,8 @@ int call_main(const Options &o)
             return 1;
         }
         std::cout << cleaned_header(hdr.header_lines, o.verbose); // main.cpp:505-510
+        std::cout.flush();
     }
-    VcfReader vcf(o.vcf_path, o.samples);
     if (!vcf.ok()) {
         std::cerr << vcf.error << std::endl;
         return 1;
@@ -1063,6 +1174,7 @@ int call_main(const Options &o)
         std::vector<Rec> &recs = job.recs;
         Batch &iso = job.iso, &gen = job.gen;
         Device &dev = devs[job.device];
+        Timed *t_dev = new Timed("worker: device calls");
         std::unique_lock<std::mutex> device_lock(dev.mu); // (the parsing thread cuts blocks on device 0 meanwhile)
         if (iso.n()) {
             const size_t n = iso.n(), na = iso.var_allele_off.back();
@@ -1139,6 +1251,8 @@ int call_main(const Options &o)
                       "mg_genotype"); // vb.genotype + the GT/GQ part of output_variants, main.cpp:558-559
         }
         device_lock.unlock(); // the records' text needs no device
+        delete t_dev;
+        Timed t_text("worker: records' text");
         std::string out;
         char num[64];
         for (const Rec &r : recs) { // output_variants, var_block.hpp:337-396
@@ -1186,9 +1300,11 @@ int call_main(const Options &o)
     std::deque<std::future<std::string>> in_flight;
     size_t jobs_started = 0;
     auto drain = [&](size_t keep) {
+        Timed t_drain("main: wait for worker + write");
         while (in_flight.size() > keep) {
-            std::cout << in_flight.front().get(); // (or the batch's exception comes back here)
+            const std::string text = in_flight.front().get(); // (or the batch's exception comes back here)
             in_flight.pop_front();
+            if (fwrite(text.data(), 1, text.size(), stdout) != text.size()) throw std::runtime_error("cannot write the output");
         }
     };
     auto run_and_print = [&]() {
@@ -1201,26 +1317,31 @@ int call_main(const Options &o)
         recs.clear();
         iso = Batch();
         gen = Batch();
+        recs.reserve(batch_records + 64);
         in_flight.push_back(std::async(std::launch::async, [&process, job]() { return process(*job); }));
     };
 
-    auto prefix_of = [&](const Variant &v) {
-        std::string s = v.seq_name + "\t" + std::to_string(v.ref_pos + 1) + "\t" + v.idx + "\t" + v.ref_sub + "\t";
-        for (size_t i = 0; i < v.alts.size(); ++i) s += (i ? "," : "") + v.alts[i];
-        s += "\t";
-        s += std::isnan(v.quality) ? "." : fmt_float(v.quality);
-        return s;
-    };
+    auto prefix_of = [&](Variant &v) { return std::move(v.text_prefix); }; // (made by the thread that decoded the record)
 
+    std::string base_name;
+    bool base_known = false, base_found = false;
+    uint64_t base_value = 0;
     const size_t n = for_each_block(vcf, o, refs, false, nullptr, [&](Block &vb, const std::string &seq_name, const std::string &reference) {
         // The fused kernel reads ceil(k/2) bases to the right of the REF allele.  A lone variant whose right flank
         // would cross the contig end (a deletion longer than about k/2 within k of it) gets a CLIPPED, shorter
         // k-mer in the reference (std::string(reference, pos, n), var_block.hpp:187) and in extract_lone at index
         // time: such a variant takes the general path, whose device enumerator hands clipped windows to the host.
-        const bool lone = vb.is_lone_short() && contig_base.count(seq_name) &&
+        if (!base_known || seq_name != base_name) { // (as ref_of: one map lookup per sequence, not per record)
+            auto cb = contig_base.find(seq_name);
+            base_found = cb != contig_base.end();
+            base_value = base_found ? cb->second : 0;
+            base_name = seq_name;
+            base_known = true;
+        }
+        const bool lone = vb.is_lone_short() && base_found &&
                           (long)vb.vars[0].ref_pos + vb.vars[0].ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
         if (lone) {
-            const Variant &v = vb.vars[0];
+            Variant &v = vb.vars[0];
             const uint32_t A = (uint32_t)v.n_alleles();
             recs.push_back({prefix_of(v), A, true, iso.n(), iso.var_allele_off.back(), iso.var_gt_off.back()});
             const bool eligible = v.is_present && v.ref_pos >= (int)o.k && v.ref_pos <= (int)reference.size() - (int)o.k; // var_block.hpp:104
@@ -1230,7 +1351,7 @@ int call_main(const Options &o)
                     mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
                     if (!o.haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
                 }
-            iso.pos.push_back(contig_base.at(seq_name) + (uint64_t)std::max(v.ref_pos, 0));
+            iso.pos.push_back(base_value + (uint64_t)std::max(v.ref_pos, 0));
             iso.present.push_back(mask);
             iso.flags.push_back(eligible ? 1 : 0);
             for (uint32_t a = 0; a < A; ++a) {
@@ -1243,10 +1364,9 @@ int call_main(const Options &o)
             iso.var_gt_off.push_back(iso.var_gt_off.back() + n_gt(A));
         } else {
             // main.cpp:556-557: extract_kmers + set_coverages happen on the device for the whole batch of blocks
-            auto cb = contig_base.find(seq_name);
-            gen.blk_base.push_back(cb == contig_base.end() ? 0 : cb->second);
+            gen.blk_base.push_back(base_value);
             gen.blk_len.push_back((uint32_t)reference.size());
-            for (const Variant &v : vb.vars) {
+            for (Variant &v : vb.vars) {
                 const uint32_t A = (uint32_t)v.n_alleles();
                 recs.push_back({prefix_of(v), A, false, gen.n(), gen.var_allele_off.back(), gen.var_gt_off.back()});
                 gen.ipos.push_back(v.ref_pos);
@@ -1274,7 +1394,7 @@ int call_main(const Options &o)
     }, &devs[0]);
     run_and_print();
     drain(0);
-    std::cout.flush();
+    fflush(stdout);
     if (gt_bytes_uploaded) std::cerr << "[malva-geno] panel genotypes of the general blocks: " << gt_bytes_uploaded.load() << " bytes uploaded" << std::endl;
     pelapsed("Processed " + std::to_string(n) + " variants");
     pelapsed("Execution completed");

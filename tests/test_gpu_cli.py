@@ -225,8 +225,9 @@ def test_index_file_is_the_references_container_and_interchanges_with_the_oracle
     vcf_synth.donor_table(contigs, records, 43, 41, table + ".txt")
     args = ["-k", "35", "-r", "43", "-b", "1", "-p", "-v", prefix + ".fa", prefix + ".vcf", table]
     run_cli(["index"] + args)
-    zst = prefix + ".vcf.c43.k35.malvax.zst"
-    assert os.path.exists(zst) and not os.path.exists(prefix + ".vcf.c43.k35.malvax.hipz")
+    zst, hipz = prefix + ".vcf.c43.k35.malvax.zst", prefix + ".vcf.c43.k35.malvax.hipz"
+    assert os.path.exists(zst) and os.path.exists(hipz)                  # both by default: the reference's container and the sparse one
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
     opt = pipeline.Options(haploid=False, verbose=True, k=35, ref_k=43, bf_size=1 << 33, strip_chr=True)
     idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
     filters, keys = index_file.read_index(zst)
@@ -236,13 +237,22 @@ def test_index_file_is_the_references_container_and_interchanges_with_the_oracle
         assert counts.size == pos.size and not counts.any()             # switch_mode leaves zeroed counters (bloom_filter.hpp:96)
     assert filters[1][2].size > 100                                      # (context_bf may well be empty on a panel this small)
     assert keys == dict(idx.ref_bf.items()) and len(keys) > 100
-    from_own = run_cli(["call"] + args)
-    # the compact container holds the same payload
+    from_own = run_cli(["call"] + args)                                  # (reads the sparse container: the newer of the two)
+    os.remove(hipz)
+    assert run_cli(["call"] + args) == from_own                          # the reference's container alone
+    # one container on request, and nothing stale of the other kind left beside it
     run_cli(["index"] + args, env=dict(os.environ, MALVA_GENO_INDEX_FORMAT="hipz"))
-    assert os.path.exists(prefix + ".vcf.c43.k35.malvax.hipz") and not os.path.exists(zst)
+    assert os.path.exists(hipz) and not os.path.exists(zst)
     assert run_cli(["call"] + args) == from_own
-    os.remove(prefix + ".vcf.c43.k35.malvax.hipz")
-    # an index written by the oracle (as the reference binary would have), read by the product
+    run_cli(["index"] + args, env=dict(os.environ, MALVA_GENO_INDEX_FORMAT="zst"))
+    assert os.path.exists(zst) and not os.path.exists(hipz)
+    # an index written by the oracle (as the reference binary would have) beside an OLDER sparse file of some other
+    # index: the newer file is the one read
+    other = str(tmp_path / "other")
+    vcf_synth.make_case(other, 43, haploid=False, k=35, n_clusters=20, vcf_strip_chr=True)
+    run_cli(["index", "-k", "35", "-r", "43", "-b", "1", "-p", other + ".fa", other + ".vcf", table], env=dict(os.environ, MALVA_GENO_INDEX_FORMAT="hipz"))
+    shutil.copy(other + ".vcf.c43.k35.malvax.hipz", hipz)
+    os.utime(hipz, (1, 1))
     index_file.write_index(zst, idx.context_bf, idx.bf, idx.ref_bf)
     assert run_cli(["call"] + args) == from_own
     assert sum(1 for l in from_own.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20

@@ -83,12 +83,13 @@ def main():
     for sub in ("index", "call"):
         t0 = time.time()
         with open(os.path.join(args.dir, "out.vcf"), "w") as so:
-            r = subprocess.run([os.path.join(ROOT, "bin", "malva-geno"), sub] + common, stdout=so, stderr=subprocess.PIPE, text=True)
+            r = subprocess.run([os.path.join(ROOT, "bin", "malva-geno"), sub] + common, stdout=so, stderr=subprocess.PIPE, text=True,
+                               env=dict(os.environ, MALVA_GENO_TIMERS="1"))
         dt = time.time() - t0
         if r.returncode:
             print(r.stderr[-2000:])
             raise SystemExit("malva-geno %s failed" % sub)
-        phases = [l for l in r.stderr.split("\n") if ("Execution Time" in l and "000 variants]" not in l) or "on the device" in l or "on the host" in l]
+        phases = [l for l in r.stderr.split("\n") if ("Execution Time" in l and "000 variants]" not in l) or "on the device" in l or "on the host" in l or "/timer]" in l]
         print("== malva-geno %s: %.2f s wall = %.3g variants/s\n   %s" % (sub, dt, n / dt, "\n   ".join(phases)), flush=True)
     nrec = sum(1 for l in open(os.path.join(args.dir, "out.vcf")) if not l.startswith("#"))
     print("records written by call: %d" % nrec)

@@ -15,6 +15,8 @@ GROUPS_=(
  "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE SQ_WAVES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"
  "FETCH_SIZE"
  "WRITE_SIZE"
+ "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_WAIT_INST_LDS"
 )
 cd /tmp
 i=0
