@@ -289,6 +289,25 @@ int mg_cover_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d
 int mg_index_blocks_device(mg_ctx *ctx, const mg_panel_dev *panel, const void *d_blk_var_off, const void *d_var_block /* or NULL */,
                            const void *d_n_blocks, int haploid, void *d_overflow_out);
 
+/* Panel genotypes straight from VCF text: Variant::extract_genotypes (variant.hpp:158-211) over the sample columns of a batch
+ * of records, decoded on the device into the sparse form of mg_panel_dev.  The host finds each record's ninth tab and the
+ * position of GT in its FORMAT column and parses nothing else of the sample columns.
+ *   text, text_bytes      host buffer holding the records' lines (only the range the spans cover is uploaded)
+ *   span_off/span_len[r]  record r's sample columns: from the byte after the FORMAT column's tab to the end of the line
+ *                         (terminator excluded); length 0 = the record has no sample columns (every kept sample reads ".")
+ *   gt_index[r]           position of GT among the ':'-separated FORMAT keys (the caller has checked that it is there)
+ *   n_columns, keep       sample columns of the header; keep[i] != 0: column i is one of the kept samples (-s), NULL = all
+ * Out, per record: sp_off[n_records + 1] (entries of record r at [sp_off[r], sp_off[r + 1])), raw_mask (bit a: raw allele
+ * number a, mod 64, occurs in a kept sample -- both alleles unless haploid), max_allele (the largest allele number: the
+ * caller checks it against the record's allele count as variant.hpp would crash on it, and decodes a record with a number
+ * above 127 itself, whose words here are truncated).  *sp_default = the word of the samples without an entry (0|0 phased or
+ * 0/0, whichever the batch holds more of), *n_entries = sp_off[n_records].  The entries themselves stay on the device until
+ * mg_decode_gt_entries copies them out (sample numbers count KEPT samples, ascending inside a record).  Synchronous. */
+int mg_decode_gt_text(mg_ctx *ctx, const char *text, size_t text_bytes, size_t n_records, const uint64_t *span_off, const uint32_t *span_len,
+                      const int32_t *gt_index, uint32_t n_columns, const uint8_t *keep, int haploid, uint16_t *sp_default, uint32_t *sp_off,
+                      uint64_t *raw_mask, uint32_t *max_allele, uint64_t *n_entries);
+int mg_decode_gt_entries(mg_ctx *ctx, uint32_t *sp_sample, uint16_t *sp_gt);
+
 /* mg_cover_blocks / mg_index_blocks with the panel's genotypes in the sparse form of mg_panel_dev (sp_off, sp_sample, sp_gt:
  * only the samples whose genotype word is not sp_default).  What crosses PCIe for a 27,934-sample panel drops from 56 KB per
  * record to a few bytes per non-reference genotype. */

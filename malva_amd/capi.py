@@ -105,6 +105,8 @@ def lib():
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
+        "mg_decode_gt_text": [vp, vp, sz, sz, vp, vp, vp, u32, vp, it, vp, vp, vp, vp, vp],
+        "mg_decode_gt_entries": [vp, vp, vp],
         "mg_cover_blocks_sparse": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint16, u32, it, vp, vp],
         "mg_index_blocks_sparse": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, C.c_uint16, u32, it, vp],
         "mg_cut_blocks": [vp, sz, vp, vp, vp, vp, vp, vp],
@@ -148,7 +150,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
-            "mg_counters_allreduce_all", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
+            "mg_counters_allreduce_all", "mg_decode_gt_text", "mg_decode_gt_entries", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
             "mg_index_isolated",
             "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_cover_blocks_sparse", "mg_index_blocks_sparse", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
@@ -465,6 +467,24 @@ class Context:
         return float(ms[0]), float(ms[1]), float(ms[2]), int(nr[0]), int(nr[1]), int(nr[2]), int(nr[3])
 
     # counters exchange
+    def decode_gt_text(self, text, span_off, span_len, gt_index, n_columns, keep=None, haploid=False):
+        """-> (sp_default, sp_off, sp_sample, sp_gt, raw_mask, max_allele): the panel genotypes of a batch of records from
+        the text of their sample columns (mg_decode_gt_text + mg_decode_gt_entries)"""
+        text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        so, sl = np.ascontiguousarray(span_off, dtype=np.uint64), np.ascontiguousarray(span_len, dtype=np.uint32)
+        gi = np.ascontiguousarray(gt_index, dtype=np.int32)
+        n = len(so)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        dflt, ne = C.c_uint16(), C.c_uint64()
+        sp_off = np.zeros(n + 1, dtype=np.uint32)
+        mask, mx = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
+        self._ck(self._L.mg_decode_gt_text(self.h, _p(text), text.size, n, _p(so), _p(sl), _p(gi), n_columns, _p(kp), int(haploid), C.byref(dflt), _p(sp_off),
+                                           _p(mask), _p(mx), C.byref(ne)))
+        ss, sg = np.zeros(ne.value, dtype=np.uint32), np.zeros(ne.value, dtype=np.uint16)
+        if n:
+            self._ck(self._L.mg_decode_gt_entries(self.h, _p(ss), _p(sg)))
+        return dflt.value, sp_off, ss, sg, mask, mx
+
     def counters_size(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self._L.mg_counters_size(self.h, C.byref(a), C.byref(b)))

@@ -37,6 +37,7 @@ constexpr int TPB = 256;
 #include "scan_kernels.h"
 #include "variant_kernels.h"
 #include "block_pipeline.h"
+#include "gt_text_kernels.h"
 
 } // namespace
 
@@ -79,7 +80,9 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[11];
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[11], s_gt[10];
+    u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
+    u64 gt_entries = 0;
     unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch,
                                                // [2] signature k-mers of the lone records, [3] of the others (mg_blocks_stats)
     hipEvent_t ev_b[4] = {nullptr, nullptr, nullptr, nullptr}; // mg_cover_blocks_device: before / after the preparation, the lone kernels, the enumerating kernel
@@ -2678,6 +2681,102 @@ MG_EXPORT int mg_call_isolated(mg_ctx *c, size_t n_vars, const uint64_t *pos, co
 }
 
 // ---- index payloads ---------------------------------------------------------------------------
+
+// ---- panel genotypes from VCF text (gt_text_kernels.h) ------------------------------------------------------------------
+MG_EXPORT int mg_decode_gt_text(mg_ctx *c, const char *text, size_t text_bytes, size_t n_records, const uint64_t *span_off, const uint32_t *span_len,
+                                const int32_t *gt_index, uint32_t n_columns, const uint8_t *keep, int haploid, uint16_t *sp_default, uint32_t *sp_off,
+                                uint64_t *raw_mask, uint32_t *max_allele, uint64_t *n_entries)
+{
+    const DeviceGuard on_device(c, KEEP);
+    if (!c) return MG_ERR_ARG;
+    c->gt_records = 0;
+    c->gt_entries = 0;
+    if (!sp_default || !sp_off || !n_entries) return fail(c, MG_ERR_ARG, "NULL argument");
+    *n_entries = 0;
+    *sp_default = (uint16_t)(1u << 14);
+    sp_off[0] = 0;
+    if (n_records == 0) return MG_OK;
+    if (!span_off || !span_len || !gt_index || !raw_mask || !max_allele || (text_bytes && !text)) return fail(c, MG_ERR_ARG, "NULL argument");
+    if (n_columns == 0) return fail(c, MG_ERR_ARG, "mg_decode_gt_text: no sample columns");
+    std::vector<u32> rank(n_columns, 0xFFFFFFFFu);
+    u32 n_keep = 0;
+    for (u32 i = 0; i < n_columns; ++i)
+        if (!keep || keep[i]) rank[i] = n_keep++;
+    if (n_keep == 0) return fail(c, MG_ERR_ARG, "mg_decode_gt_text: no sample kept");
+    if (n_records >= 0xFFFFFFFFull || (u64)n_records * n_keep > (1ull << 31)) return fail(c, MG_ERR_LIMIT, "mg_decode_gt_text takes at most 2^31 genotypes per batch");
+    // the part of the text the spans lie in
+    u64 lo = ~0ull, hi = 0;
+    for (size_t r = 0; r < n_records; ++r) {
+        if (span_off[r] > text_bytes || span_len[r] > text_bytes - span_off[r]) return fail(c, MG_ERR_ARG, "record %zu: sample columns outside the text", r);
+        if (gt_index[r] < 0 || gt_index[r] > 1000) return fail(c, MG_ERR_ARG, "record %zu: GT index %d", r, gt_index[r]);
+        if (!span_len[r]) continue;
+        lo = std::min<u64>(lo, span_off[r]);
+        hi = std::max<u64>(hi, span_off[r] + span_len[r]);
+    }
+    if (lo > hi) lo = hi = 0;
+    std::vector<unsigned long long> off(n_records);
+    for (size_t r = 0; r < n_records; ++r) off[r] = span_len[r] ? span_off[r] - lo : 0;
+    void *d_text, *d_off, *d_len, *d_gi, *d_rank, *d_tok, *d_words, *d_stats;
+    TRY(upload(c, c->s_gt[0], text + lo, hi - lo, &d_text));
+    TRY(upload(c, c->s_gt[1], off.data(), 8 * n_records, &d_off));
+    TRY(upload(c, c->s_gt[2], span_len, 4 * n_records, &d_len));
+    TRY(upload(c, c->s_gt[3], gt_index, 4 * n_records, &d_gi));
+    TRY(upload(c, c->s_gt[4], rank.data(), 4 * (size_t)n_columns, &d_rank));
+    const unsigned grid = (unsigned)std::min<u64>(n_records, 1024);
+    TRY(scratch(c, c->s_gt[5], 8 * (size_t)grid * n_keep, &d_tok));
+    TRY(scratch(c, c->s_gt[6], 2 * (size_t)n_records * n_keep, &d_words));
+    TRY(scratch(c, c->s_gt[7], sizeof(GtStats) * n_records, &d_stats));
+    hipLaunchKernelGGL(gt_decode_kernel, dim3(grid), dim3(GT_TPB), 0, c->stream, (const char *)d_text, (const unsigned long long *)d_off, (const u32 *)d_len,
+                       (const i32 *)d_gi, (u32)n_records, n_columns, (const u32 *)d_rank, n_keep, haploid, (unsigned long long *)d_tok, (uint16_t *)d_words,
+                       (GtStats *)d_stats);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<GtStats> st(n_records);
+    HIP_TRY(c, hipMemcpyAsync(st.data(), d_stats, sizeof(GtStats) * n_records, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // (also: the host vectors uploaded above may go)
+    // the default word: 0|0 phased or 0/0, whichever the batch holds more of
+    u64 p0 = 0, u0 = 0;
+    for (const GtStats &g : st) {
+        p0 += g.n_phased0;
+        u0 += g.n_unphased0;
+    }
+    const u32 dflt = u0 > p0 ? 0u : 1u << 14;
+    u64 total = 0;
+    for (size_t r = 0; r < n_records; ++r) {
+        raw_mask[r] = st[r].raw_mask;
+        max_allele[r] = st[r].max_allele;
+        total += n_keep - (dflt ? st[r].n_phased0 : st[r].n_unphased0);
+        if (total > 0xFFFFFFFFull) return fail(c, MG_ERR_LIMIT, "mg_decode_gt_text: 2^32 or more entries in one batch");
+        sp_off[r + 1] = (u32)total;
+    }
+    *sp_default = (uint16_t)dflt;
+    *n_entries = total;
+    c->gt_records = (u32)n_records;
+    c->gt_keep = n_keep;
+    c->gt_default = dflt;
+    c->gt_entries = total;
+    void *d_spoff;
+    TRY(upload(c, c->s_gt[8], sp_off, 4 * (n_records + 1), &d_spoff));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
+MG_EXPORT int mg_decode_gt_entries(mg_ctx *c, uint32_t *sp_sample, uint16_t *sp_gt)
+{
+    const DeviceGuard on_device(c, KEEP);
+    if (!c) return MG_ERR_ARG;
+    if (!c->gt_records) return fail(c, MG_ERR_STATE, "mg_decode_gt_entries follows a mg_decode_gt_text that decoded something");
+    if (!c->gt_entries) return MG_OK;
+    if (!sp_sample || !sp_gt) return fail(c, MG_ERR_ARG, "NULL argument");
+    void *d_s, *d_g;
+    TRY(scratch(c, c->s_gt[5], 4 * c->gt_entries, &d_s)); // (the token scratch is free again)
+    TRY(scratch(c, c->s_gt[9], 2 * c->gt_entries, &d_g));
+    hipLaunchKernelGGL(gt_compact_kernel, dim3(std::min<u32>(c->gt_records, 2048)), dim3(GT_TPB), 0, c->stream, (const uint16_t *)c->s_gt[6].p, c->gt_records, c->gt_keep,
+                       c->gt_default, (const u32 *)c->s_gt[8].p, (u32 *)d_s, (uint16_t *)d_g);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(sp_sample, d_s, 4 * c->gt_entries, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sp_gt, d_g, 2 * c->gt_entries, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MG_OK;
+}
 
 MG_EXPORT int mg_bf_export(mg_ctx *c, int which, uint64_t *words_out, uint16_t *counts_out)
 {
