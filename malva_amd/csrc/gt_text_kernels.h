@@ -11,7 +11,7 @@
 // What extract_genotypes sees, per kept sample i (after `-s`): bcf_get_genotypes returns `ploidy` ints per sample, ploidy =
 // the largest number of alleles any kept sample of the RECORD has; shorter samples are padded with vector_end.  The
 // function reads curr_gt[0] and curr_gt[1] of the flat array at i * ploidy: with ploidy 1 the second is the NEXT sample's
-// first value (and past the last sample, nothing: restated as vector_end, as oracle/model.py does).  A second value of
+// first value (and past the last sample, nothing: restated as vector_end).  A second value of
 // vector_end makes the sample (a, a) phased; otherwise (first, second) with the phase bit of the second.  Missing alleles
 // (".", -1) and negative numbers read as 0.  The word is a1 | a2 << 7 | phased << 14, or a1 | 1 << 14 in haploid mode
 // (var_block.hpp:751 reads the first allele only).

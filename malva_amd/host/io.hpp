@@ -344,10 +344,23 @@ class LineReader {
     bool next_block(std::string &blk, size_t want)
     {
         const size_t at0 = blk.size();
+        if (pos < end) { // what an earlier line-wise read left in the buffer
+            const size_t take = std::min(end - pos, want);
+            blk.append(buf.data() + pos, take);
+            pos += take;
+        }
+        while (pos == end && blk.size() - at0 < want) { // bulk: straight into the block (zlib hands large requests on a plain file to read())
+            const size_t old = blk.size(), ask = std::min<size_t>(want - (old - at0), 1u << 30);
+            blk.resize(old + ask);
+            const int n = gzread(f, &blk[old], (unsigned)ask);
+            blk.resize(old + (n > 0 ? (size_t)n : 0));
+            if (n <= 0) break;
+        }
         for (;;) {
+            if (blk.size() - at0 < want && pos == end) break; // end of file inside the bulk part
             if (pos == end && !fill()) break;
             const size_t have = blk.size() - at0;
-            if (have < want) { // bulk
+            if (have < want) { // (only when the buffer held more than the block wanted)
                 const size_t take = std::min(end - pos, want - have);
                 blk.append(buf.data() + pos, take);
                 pos += take;
@@ -464,6 +477,18 @@ struct Variant {
     bool has_alts = true, is_present = true;
     std::vector<float> frequencies;
     std::vector<uint32_t> coverages;
+    // VcfReader::defer_genotypes: the sample columns are not decoded by the reader; the record says where they are (a span of
+    // the block of text it was cut from, kept alive by the pointer) and the device decodes them (mg_decode_gt_text), after
+    // which sp_* hold the kept samples whose genotype word is not sp_default -- the record loop's sparse layout
+    std::shared_ptr<const std::string> gt_text;
+    uint32_t gt_off = 0, gt_len = 0, n_kept = 0, max_allele = 0;
+    int32_t gt_index = -1;
+    bool gt_deferred = false;
+    uint16_t sp_default = 0;
+    uint64_t raw_mask = 0; // raw allele numbers (mod 64) that occur among the kept samples (first alleles only in haploid mode)
+    std::vector<uint32_t> sp_sample;
+    std::vector<uint16_t> sp_gt;
+    size_t n_genotypes() const { return gt_deferred ? n_kept : genotypes.size(); }
     std::string text_prefix; // VcfReader::want_prefix: CHROM .. QUAL of the output record (output_variants, var_block.hpp:337-352), made by the decoding thread
 
     int n_alleles() const { return (int)alts.size() + 1; }
@@ -490,6 +515,7 @@ class VcfReader {
         std::vector<int> tok_allele;      // GT tokens of the current record, all kept samples
         std::vector<uint8_t> tok_phased;  // separator in front of each token was '|'
         std::vector<uint32_t> tok_off;    // per kept sample: its first token
+        std::shared_ptr<const std::string> block; // the block of text the record is being cut from (pool mode, text files), or null
     };
     std::vector<uint8_t> keep_mask;       // per sample column: kept
 
@@ -498,7 +524,7 @@ class VcfReader {
     // the records out in file order.  An exception raised by a record is rethrown by next() when that record's
     // turn comes, after every record in front of it.
     struct Chunk {
-        std::string text;               // text files: a block of whole lines, cut into records by the decoding thread ...
+        std::shared_ptr<std::string> text = std::make_shared<std::string>(); // text files: a block of whole lines, cut into records by the decoding thread ...
         std::vector<std::string> lines; // ... BCF: the records as the reader translated them
         std::vector<Variant> vars;
         size_t n_ok = 0;          // records decoded before `err` (all of them when err is empty)
@@ -517,6 +543,18 @@ class VcfReader {
     size_t cur_at = 0;
 
   public:
+    bool defer_genotypes = false; // leave the sample columns to mg_decode_gt_text (pool mode over a text file only; set before the first next())
+    // a deferred record decoded on the host after all (an allele number the device's words cannot hold; the host enumerator)
+    void genotypes_on_host(Variant &v)
+    {
+        if (!v.gt_deferred) return;
+        const char *at = v.gt_text->data() + v.gt_off;
+        parse_samples(v.gt_len ? at : nullptr, at + v.gt_len, v.gt_index, v, inline_scratch); // (no columns and an empty ninth column read the same: every sample ".")
+        v.gt_deferred = false;
+        v.sp_sample.clear();
+        v.sp_gt.clear();
+        v.gt_text.reset();
+    }
     bool want_prefix = false;    // `call`: fill Variant::text_prefix (set before the first next())
     uint64_t file_bytes = 0;     // size of the file on disk (0 when unknown): decides whether decoding goes to the pool
     std::vector<std::string> header_lines; // the ## lines
@@ -591,9 +629,6 @@ class VcfReader {
         auto &fmt = sc.fmt;
         auto &fld = sc.fld;
         auto &vals = sc.vals;
-        auto &tok_allele = sc.tok_allele;
-        auto &tok_phased = sc.tok_phased;
-        auto &tok_off = sc.tok_off;
         // the nine fixed columns; the sample columns (tens of thousands on a panel) are walked in place below
         cols.clear();
         const char *const line_end = text + size;
@@ -677,6 +712,23 @@ class VcfReader {
             v.has_alts = false; // variant.hpp:169-174
             return;
         }
+        if (defer_genotypes && sc.block) { // left to the device: where the sample columns are
+            v.gt_deferred = true;
+            v.gt_text = sc.block;
+            v.gt_off = (uint32_t)((samples_at ? samples_at : line_end) - sc.block->data());
+            v.gt_len = (uint32_t)(samples_at ? line_end - samples_at : 0);
+            v.gt_index = gi;
+            v.n_kept = (uint32_t)keep.size();
+            return;
+        }
+        parse_samples(samples_at, line_end, gi, v, sc);
+    }
+    // the sample columns [samples_at, line_end) (NUL at line_end; samples_at null: none) -> v.genotypes / v.phasing
+    void parse_samples(const char *samples_at, const char *line_end, int gi, Variant &v, Scratch &sc) const
+    {
+        auto &tok_allele = sc.tok_allele;
+        auto &tok_phased = sc.tok_phased;
+        auto &tok_off = sc.tok_off;
         // what bcf_get_genotypes returns: per sample `ploidy` values, short samples padded with vector_end.
         // One flat token list for the record (panels carry tens of thousands of samples: no per-sample allocation).
         struct G {
@@ -826,12 +878,14 @@ class VcfReader {
                 size_t bytes = 0;
                 if (!in.is_bcf()) {
                     if (have_pending) {
-                        ch->text = pending;
-                        ch->text += '\n';
+                        *ch->text = pending;
+                        *ch->text += '\n';
                         have_pending = false;
                     }
-                    ch->text.reserve((1u << 20) + (64u << 10));
-                    in.next_block(ch->text, 1u << 20);
+                    // (deferred genotypes: one device call decodes a block's records, so a block holds hundreds of panel lines)
+                    const size_t want = defer_genotypes ? 16u << 20 : 1u << 20;
+                    ch->text->reserve(want + (64u << 10));
+                    in.next_block(*ch->text, want);
                 }
                 while (in.is_bcf() && ch->lines.size() < 2048 && bytes < (8u << 20)) {
                     if (have_pending) {
@@ -845,7 +899,7 @@ class VcfReader {
                     line.clear();
                 }
                 std::unique_lock<std::mutex> lk(mu);
-                if (ch->lines.empty() && ch->text.empty()) {
+                if (ch->lines.empty() && ch->text->empty()) {
                     eof = true;
                     cv.notify_all();
                     return;
@@ -871,9 +925,10 @@ class VcfReader {
                     }
                     size_t i = 0;
                     try {
-                        if (!ch->text.empty()) { // lines cut in place: each terminator becomes the NUL the decoder stops at
-                            char *p = &ch->text[0], *const e = p + ch->text.size();
-                            ch->vars.reserve(ch->text.size() / 40 < 4096 ? ch->text.size() / 40 + 1 : 4096);
+                        if (!ch->text->empty()) { // lines cut in place: each terminator becomes the NUL the decoder stops at
+                            char *p = &(*ch->text)[0], *const e = p + ch->text->size();
+                            ch->vars.reserve(ch->text->size() / 40 < 4096 ? ch->text->size() / 40 + 1 : 4096);
+                            sc.block = ch->text;
                             while (p < e) {
                                 char *nl = (char *)memchr(p, '\n', (size_t)(e - p));
                                 char *le = nl ? nl : e;
@@ -893,12 +948,13 @@ class VcfReader {
                         }
                     } catch (...) {
                         ch->err = std::current_exception();
-                        if (!ch->text.empty()) ch->vars.pop_back(); // the record that threw
+                        if (!ch->text->empty()) ch->vars.pop_back(); // the record that threw
                     }
+                    sc.block.reset();
                     ch->n_ok = i;
                     ch->lines.clear();
                     ch->lines.shrink_to_fit();
-                    std::string().swap(ch->text);
+                    ch->text.reset(); // (records with deferred genotypes hold on to it)
                     std::lock_guard<std::mutex> lk(mu);
                     ch->done = true;
                     cv.notify_all();

@@ -220,6 +220,102 @@ std::string index_path(const Options &o, const char *suffix)
     return o.vcf_path + ".c" + std::to_string(o.ref_k) + ".k" + std::to_string(o.k) + ".malvax" + suffix;
 }
 
+// ---- genotypes the reader left to the device (VcfReader::defer_genotypes) ---------------------------------------------------
+// A panel of a thousand samples or more has its sample columns decoded on the device (MALVA_GENO_GT_DEVICE=0 / 1 forces either way;
+// the reader defers only where it can: a text file read through the pool).
+inline bool device_gt_wanted(const VcfReader &vcf)
+{
+    if (const char *e = getenv("MALVA_GENO_GT_DEVICE")) return atoi(e) != 0;
+    return vcf.keep.size() >= 1024;
+}
+// The records of one cut batch, block of text by block of text: mg_decode_gt_text over the spans, the entries back into the records.
+inline void decode_deferred(std::vector<Variant> &kept, Device &dev, VcfReader &vcf, const Options &o)
+{
+    std::vector<uint64_t> off, mask;
+    std::vector<uint32_t> len, sp_off, mx, ss;
+    std::vector<int32_t> gi;
+    std::vector<uint16_t> sg;
+    std::vector<uint8_t> keep_cols(vcf.samples.size(), 0);
+    for (int i : vcf.keep) keep_cols[(size_t)i] = 1;
+    for (size_t a = 0; a < kept.size();) {
+        if (!kept[a].gt_deferred) {
+            ++a;
+            continue;
+        }
+        size_t b = a;
+        while (b < kept.size() && kept[b].gt_deferred && kept[b].gt_text == kept[a].gt_text) ++b;
+        const size_t n = b - a;
+        off.resize(n); len.resize(n); gi.resize(n); sp_off.resize(n + 1); mask.resize(n); mx.resize(n);
+        for (size_t r = 0; r < n; ++r) {
+            off[r] = kept[a + r].gt_off;
+            len[r] = kept[a + r].gt_len;
+            gi[r] = kept[a + r].gt_index;
+        }
+        uint16_t dflt = 0;
+        uint64_t n_entries = 0;
+        {
+            Timed t("main: mg_decode_gt_text (+ lock)");
+            std::lock_guard<std::mutex> lk(dev.mu);
+            const std::string &text = *kept[a].gt_text;
+            dev.check(mg_decode_gt_text(dev.ctx, text.data(), text.size(), n, off.data(), len.data(), gi.data(), (uint32_t)keep_cols.size(), keep_cols.data(), o.haploid,
+                                        &dflt, sp_off.data(), mask.data(), mx.data(), &n_entries),
+                      "mg_decode_gt_text");
+            ss.resize(n_entries);
+            sg.resize(n_entries);
+            dev.check(mg_decode_gt_entries(dev.ctx, ss.data(), sg.data()), "mg_decode_gt_entries");
+        }
+        for (size_t r = 0; r < n; ++r) {
+            Variant &v = kept[a + r];
+            v.sp_default = dflt;
+            v.raw_mask = mask[r];
+            v.max_allele = mx[r];
+            if (mx[r] > 127) { // an allele number the 7-bit words cannot hold: this record is decoded here after all
+                vcf.genotypes_on_host(v);
+                continue;
+            }
+            v.sp_sample.assign(ss.begin() + sp_off[r], ss.begin() + sp_off[r + 1]);
+            v.sp_gt.assign(sg.begin() + sp_off[r], sg.begin() + sp_off[r + 1]);
+            v.gt_text.reset(); // (the block of text goes when its last record has let go)
+        }
+        a = b;
+    }
+}
+// v.genotypes / v.phasing of a deferred record, for the host enumerator (a block the device handed back, dump-kmers' cousin paths)
+inline void genotypes_from_entries(Variant &v)
+{
+    if (!v.gt_deferred) return;
+    const auto pair_of = [](uint16_t w) { return std::make_pair((int)(w & 127), (int)((w >> 7) & 127)); };
+    v.genotypes.assign(v.n_kept, pair_of(v.sp_default));
+    v.phasing.assign(v.n_kept, (uint8_t)((v.sp_default >> 14) & 1));
+    for (size_t e = 0; e < v.sp_sample.size(); ++e) {
+        v.genotypes[v.sp_sample[e]] = pair_of(v.sp_gt[e]);
+        v.phasing[v.sp_sample[e]] = (uint8_t)((v.sp_gt[e] >> 14) & 1);
+    }
+    v.gt_deferred = false;
+    v.sp_sample.clear();
+    v.sp_gt.clear();
+}
+inline void genotypes_from_entries(Block &b)
+{
+    for (Variant &v : b.vars) genotypes_from_entries(v);
+}
+// build_alleles_combs on a chain of one (var_block.hpp:734-786): the (canonical) alleles some kept haplotype carries
+inline uint64_t carried_mask(const Variant &v, bool haploid)
+{
+    uint64_t mask = 0;
+    if (v.gt_deferred) {
+        if (v.max_allele >= (uint32_t)v.n_alleles()) (void)v.alts.at(v.max_allele); // (throws what the loop below would)
+        for (int a = 0; a < v.n_alleles() && a < 64; ++a)
+            if ((v.raw_mask >> a) & 1) mask |= 1ULL << v.allele_index(v.allele(a));
+        return mask;
+    }
+    for (size_t g = 0; g < v.genotypes.size(); ++g) {
+        mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
+        if (!haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
+    }
+    return mask;
+}
+
 // The record loop shared by index_main (main.cpp:309-370) and call_main (:522-579).  on_block(block, reference
 // of `last_seq_name`) is called for every closed block.  Keeps the reference's control flow, including that
 // last_seq_name is refreshed only when a block is flushed.
@@ -266,11 +362,12 @@ template <class F> size_t for_each_block(VcfReader &vcf, const Options &o, const
                     if (used) used->push_back(block_name);
                 }
                 if (for_index ? (!v.has_alts || !v.is_present) : !v.has_alts) continue;
-                cells += v.genotypes.size();
+                cells += v.n_genotypes();
                 kept.push_back(std::move(v));
             }
             delete t_parse;
             if (kept.empty()) continue;
+            decode_deferred(kept, *cutter, vcf, o);
             const bool carry = !vb.empty();
             const size_t n = kept.size() + (carry ? 1 : 0);
             pos.resize(n); ref_size.resize(n); min_size.resize(n); cid.resize(n); off.resize(n + 1);
@@ -371,6 +468,8 @@ inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_
 {
     PanelGenotypes g;
     g.sparse = n_samples > SPARSE_GT_SAMPLES;
+    for (const Block &b : blocks) // (records decoded on the device arrive in the sparse form whatever the panel's size)
+        for (const Variant &v : b.vars) g.sparse = g.sparse || v.gt_deferred;
     if (!g.sparse) g.gt.assign(n_vars * n_samples, 0);
     // haploid mode reads the first allele only (var_block.hpp:751): the word is reduced to it, so that a ploidy-1 panel --
     // whose second "allele" is whatever htslib's layout puts behind the first -- is as sparse as it looks
@@ -385,12 +484,18 @@ inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_
     if (g.sparse) { // the default word: 0|0 phased or 0/0 unphased, whichever the batch holds more of (a sample of it decides)
         size_t phased0 = 0, unphased0 = 0, seen = 0;
         for (const Block &b : blocks) {
-            for (const Variant &v : b.vars)
+            for (const Variant &v : b.vars) {
+                if (v.gt_deferred) { // decoded on the device: its batch's default stands for its samples
+                    (v.sp_default ? phased0 : unphased0) += 64;
+                    seen += 64;
+                    continue;
+                }
                 for (size_t s_ = 0; s_ < v.genotypes.size() && seen < 200000; s_ += 7, ++seen) {
                     const uint16_t w = word(v, s_);
                     phased0 += w == (1u << 14);
                     unphased0 += w == 0;
                 }
+            }
             if (seen >= 200000) break;
         }
         g.sp_default = unphased0 > phased0 ? 0 : (uint16_t)(1u << 14);
@@ -398,6 +503,29 @@ inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_
     size_t row = 0;
     for (const Block &b : blocks)
         for (const Variant &v : b.vars) {
+            if (v.gt_deferred) { // already the sparse layout (mg_decode_gt_text), against its own batch's default
+                if (!g.sparse) throw std::runtime_error("internal: deferred genotypes on a panel of few samples");
+                if (v.max_allele >= (uint32_t)v.n_alleles())
+                    throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
+                                             " (the reference reads out of bounds here)");
+                if (v.sp_default == g.sp_default) {
+                    g.sp_sample.insert(g.sp_sample.end(), v.sp_sample.begin(), v.sp_sample.end());
+                    g.sp_gt.insert(g.sp_gt.end(), v.sp_gt.begin(), v.sp_gt.end());
+                } else { // (a panel that mixes phased and unphased records: the samples WITHOUT an entry are the ones that differ here)
+                    size_t e = 0;
+                    for (uint32_t s_ = 0; s_ < v.n_kept; ++s_) {
+                        uint16_t w = v.sp_default;
+                        if (e < v.sp_sample.size() && v.sp_sample[e] == s_) w = v.sp_gt[e++];
+                        if (w != g.sp_default) {
+                            g.sp_sample.push_back(s_);
+                            g.sp_gt.push_back(w);
+                        }
+                    }
+                }
+                g.sp_off.push_back((uint32_t)g.sp_sample.size());
+                ++row;
+                continue;
+            }
             for (size_t s_ = 0; s_ < v.genotypes.size(); ++s_) {
                 const uint16_t w = word(v, s_);
                 if (!g.sparse) g.gt[row * n_samples + s_] = w;
@@ -551,6 +679,8 @@ int index_main(const Options &o)
         std::cerr << vcf.error << std::endl;
         return 1;
     }
+    vcf.defer_genotypes = device_gt_wanted(vcf) && !getenv("MALVA_GENO_HOST_CUT"); // (the decode rides on the device cutter's batches)
+    vcf.decode_ahead(o.freq_key, o.uniform);
     pelapsed("Reference processed");
     Device dev;
     if (mg_create(&dev.ctx, o.device, o.k, o.ref_k, o.bf_size) != MG_OK) {
@@ -651,6 +781,7 @@ int index_main(const Options &o)
             pool_t.emplace_back([&, t]() {
                 for (size_t q = t; q < nt; q += n_threads) {
                     try {
+                        genotypes_from_entries(waiting[todo[q]]);
                         sigs[q] = waiting[todo[q]].extract(*waiting_ref[todo[q]], o.haploid); // main.cpp:349
                     } catch (...) {
                         errs[t] = std::current_exception();
@@ -703,6 +834,7 @@ int index_main(const Options &o)
                 continue;
             }
             ++n_lone_host;
+            genotypes_from_entries(lone.blocks[v]);
             lone.blocks[v].extract_lone(*lone.refs[v], o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
             flush(false);
         }
@@ -714,17 +846,13 @@ int index_main(const Options &o)
             const bool on_device = !host_only && contig_base.count(seq_name) && v.n_alleles() <= 64 &&
                                    (long)v.ref_pos + v.ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
             if (!on_device) { // one k-mer per carried allele, no containers
+                genotypes_from_entries(vb);
                 vb.extract_lone(reference, o.haploid, [&](int a, const std::string &kmer) { (a == 0 ? ref_rows : alt_rows).add(kmer); });
                 flush(false);
                 return;
             }
             const bool eligible = v.is_present && v.ref_pos >= (int)o.k && v.ref_pos <= (int)reference.size() - (int)o.k; // var_block.hpp:104
-            uint64_t mask = 0;
-            if (eligible)
-                for (size_t g = 0; g < v.genotypes.size(); ++g) { // build_alleles_combs on a chain of one
-                    mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
-                    if (!o.haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
-                }
+            const uint64_t mask = eligible ? carried_mask(v, o.haploid) : 0;
             lone.pos.push_back(contig_base.at(seq_name) + (uint64_t)std::max(v.ref_pos, 0));
             lone.present.push_back(mask);
             lone.flags.push_back(eligible ? 1 : 0);
@@ -734,7 +862,7 @@ int index_main(const Options &o)
                 lone.allele_off.push_back((uint32_t)lone.pool.size());
             }
             lone.var_allele_off.push_back(lone.var_allele_off.back() + (uint32_t)v.n_alleles());
-            lone.cells += v.genotypes.size();
+            lone.cells += v.n_genotypes();
             lone.refs.push_back(&reference);
             lone.blocks.push_back(std::move(vb));
             vb = Block((int)o.k);
@@ -744,7 +872,7 @@ int index_main(const Options &o)
         auto cb = contig_base.find(seq_name);
         waiting_base.push_back(cb == contig_base.end() ? 0 : cb->second);
         waiting_ref.push_back(&reference);
-        for (const Variant &v : vb.vars) waiting_cells += v.genotypes.size();
+        for (const Variant &v : vb.vars) waiting_cells += v.n_genotypes();
         waiting.push_back(std::move(vb));
         vb = Block((int)o.k);
         if (waiting.size() >= 4096 || waiting_cells >= (200u << 20)) enumerate_waiting(); // bound the panel genotypes held in memory
@@ -1075,6 +1203,7 @@ int call_main(const Options &o)
     VcfReader vcf(o.vcf_path, o.samples); // (a panel of any size is decoded by a pool of threads: started here, it works through start-up)
     if (vcf.ok()) {
         vcf.want_prefix = true;
+        vcf.defer_genotypes = device_gt_wanted(vcf) && !getenv("MALVA_GENO_HOST_CUT"); // (the decode rides on the device cutter's batches)
         vcf.decode_ahead(o.freq_key, o.uniform);
     }
     auto fail_early = [&](const std::string &msg) { // (the readers hold references to this frame: let them finish first)
@@ -1221,7 +1350,8 @@ int call_main(const Options &o)
                 for (uint32_t v = gen.blk_var_off[b]; v < gen.blk_var_off[b + 1]; ++v) redo = redo || overflow[v];
                 if (!redo) continue;
                 ++n_fallback;
-                const Block &blk = gen.blocks[b];
+                Block &blk = gen.blocks[b];
+                genotypes_from_entries(blk);
                 const auto sigs = blk.extract(*gen.block_ref[b], o.haploid);
                 Rows rows;
                 std::vector<uint8_t> is_ref;
@@ -1345,12 +1475,7 @@ int call_main(const Options &o)
             const uint32_t A = (uint32_t)v.n_alleles();
             recs.push_back({prefix_of(v), A, true, iso.n(), iso.var_allele_off.back(), iso.var_gt_off.back()});
             const bool eligible = v.is_present && v.ref_pos >= (int)o.k && v.ref_pos <= (int)reference.size() - (int)o.k; // var_block.hpp:104
-            uint64_t mask = 0;
-            if (eligible)
-                for (size_t g = 0; g < v.genotypes.size(); ++g) { // build_alleles_combs on a chain of one
-                    mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].first));
-                    if (!o.haploid) mask |= 1ULL << v.allele_index(v.allele(v.genotypes[g].second));
-                }
+            const uint64_t mask = eligible ? carried_mask(v, o.haploid) : 0;
             iso.pos.push_back(base_value + (uint64_t)std::max(v.ref_pos, 0));
             iso.present.push_back(mask);
             iso.flags.push_back(eligible ? 1 : 0);
@@ -1382,7 +1507,7 @@ int call_main(const Options &o)
                 }
                 gen.var_allele_off.push_back(gen.var_allele_off.back() + A);
                 gen.var_gt_off.push_back(gen.var_gt_off.back() + n_gt(A));
-                gen.genotype_cells += v.genotypes.size();
+                gen.genotype_cells += v.n_genotypes();
             }
             gen.blk_var_off.push_back((uint32_t)gen.n());
             gen.block_ref.push_back(&reference);

@@ -330,3 +330,45 @@ def test_cli_options_match_oracle(tmp_path, what):
     base_opt = pipeline.Options(haploid=False, verbose=True, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
     base = pipeline.call(prefix + ".fa", prefix + ".vcf", pipeline.index(prefix + ".fa", prefix + ".vcf", base_opt), kmers, base_opt)
     assert strip(base) != strip(want)
+
+
+@pytest.mark.parametrize("seed,haploid,dense,subset", [(21, False, False, False), (22, True, False, False), (23, False, True, True), (24, True, True, True)])
+def test_sample_columns_decoded_on_the_device_give_the_same_records(tmp_path, seed, haploid, dense, subset):
+    """VcfReader::defer_genotypes + mg_decode_gt_text (what a panel of >= 1024 samples gets by itself; forced here on a
+    small one): index and call leave the sample columns to the device -- lone records take their presence mask from the
+    raw-allele mask, general blocks their sparse entries, blocks handed back to the host enumerator rebuild the pairs from
+    the entries -- and must write the bytes of the run in which the host decoded every column, which in turn are the oracle's."""
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, seed, haploid=haploid, k=35, n_clusters=70, n_samples=9, vcf_strip_chr=True, dense=dense)
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, 43, seed, table + ".txt")
+    args = ["-k", "35", "-r", "43", "-b", "1", "-p", "-v"] + (["-1"] if haploid else [])
+    samples = "-"
+    if subset:
+        samples = str(tmp_path / "keep.txt")
+        open(samples, "w").write("S7\nS1\nS4\nS2\n")
+        args += ["-s", samples]
+    args += [prefix + ".fa", prefix + ".vcf", table]
+    host = dict(os.environ, MALVA_GENO_GT_DEVICE="0", MALVA_GENO_VCF_POOL="1")
+    dev = dict(os.environ, MALVA_GENO_GT_DEVICE="1", MALVA_GENO_VCF_POOL="1", MALVA_GENO_CUT_BATCH="37")   # (batch seams inside blocks of text)
+    run_cli(["index"] + args, env=host)
+    want = run_cli(["call"] + args, env=host)
+    import numpy as np
+    from oracle import index_file
+    filt_host, keys_host = index_file.read_index(prefix + ".vcf.c43.k35.malvax.zst")
+    run_cli(["index"] + args, env=dev)
+    filt_dev, keys_dev = index_file.read_index(prefix + ".vcf.c43.k35.malvax.zst")
+    assert keys_dev == keys_host and len(keys_dev) > 50                                 # the same index: keys, and both filters' set bits
+    for a, b in zip(filt_dev, filt_host):
+        assert a[:2] == b[:2] and np.array_equal(a[2], b[2])
+    got = run_cli(["call"] + args, env=dev)
+    assert got == want
+    assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
+    # blocks the device hands back (forced: all of them) rebuild the genotype pairs from the entries
+    forced = run_cli(["call"] + args, env=dict(dev, MALVA_GENO_HOST_ENUM="1"))
+    assert forced == want
+    opt = pipeline.Options(haploid=haploid, verbose=True, k=35, ref_k=43, bf_size=1 << 33, strip_chr=True, samples=samples)
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+    strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)
+    assert strip(got) == strip(pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt))
