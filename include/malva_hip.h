@@ -270,6 +270,9 @@ typedef struct mg_panel_dev {
     const uint32_t *sp_sample;
     const uint16_t *sp_gt;
     uint32_t sp_default;
+    /* bytes of `pool` (= allele_off[last allele slot]).  Given (non-zero, and `pool` 4-byte aligned) the record loop packs the
+     * alleles to 2 bits per base at the start of every call and assembles signature k-mers from the packed form; 0: from the bytes. */
+    uint64_t pool_bytes;
 } mg_panel_dev;
 /* The cut (main.cpp:341, 547) of all n_vars records: d_blk_var_off_out ([n_vars + 1] u32), d_n_blocks_out (one u64), and
  * -- optional, NULL to skip -- d_var_block_out ([n_vars] u32: the block of every record, which the two calls below

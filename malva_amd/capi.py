@@ -166,7 +166,7 @@ class PanelDev(C.Structure):
     _fields_ = [("n_vars", C.c_uint64), ("n_contigs", C.c_uint32), ("n_samples", C.c_uint32), ("contig_base", C.c_void_p), ("contig_len", C.c_void_p),
                 ("contig_id", C.c_void_p), ("pos", C.c_void_p), ("ref_size", C.c_void_p), ("min_size", C.c_void_p), ("present", C.c_void_p),
                 ("var_allele_off", C.c_void_p), ("allele_off", C.c_void_p), ("pool", C.c_void_p), ("canon", C.c_void_p), ("gt", C.c_void_p),
-                ("sp_off", C.c_void_p), ("sp_sample", C.c_void_p), ("sp_gt", C.c_void_p), ("sp_default", C.c_uint32)]
+                ("sp_off", C.c_void_p), ("sp_sample", C.c_void_p), ("sp_gt", C.c_void_p), ("sp_default", C.c_uint32), ("pool_bytes", C.c_uint64)]
 
 
 def sparse_genotypes(gt, n_samples, default=1 << 14):

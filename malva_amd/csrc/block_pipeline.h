@@ -637,9 +637,23 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
             const u32 a = (u32)(item.code >> sh) & ((1u << bits) - 1);
             sh += bits;
-            const u8 *ap = B.pool + B.allele_off[s0 + a];
-            const int al = (int)(B.allele_off[s0 + a + 1] - B.allele_off[s0 + a]);
-            for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) put(x, ap[x - mp - vs]);
+            const u32 ao = B.allele_off[s0 + a];
+            const u8 *ap = B.pool + ao;
+            const int al = (int)(B.allele_off[s0 + a + 1] - ao);
+            if (B.pool2) { // the allele's part of the window out of the packed pool: two loads and a shift per 32 bases, like the reference's
+                int x = max(0, vs + mp);
+                const int xe = min(k, vs + al + mp);
+                while (x < xe) {
+                    const int n = xe - x < 32 ? xe - x : 32;
+                    const u64 at = (u64)ao + (u64)(x - mp - vs);
+                    ok = ok && !ref_bad(B.poolbad, at, n);
+                    const U128 sp = shl128(U128{ref_codes(B.pool2, at, n), 0}, 2 * x);
+                    Lf.lo |= sp.lo;
+                    Lf.hi |= sp.hi;
+                    x += n;
+                }
+            } else
+                for (int x = max(0, vs + mp), xe = min(k, vs + al + mp); x < xe; ++x) put(x, ap[x - mp - vs]);
             vs += al;
             if (j + 1 < m) {
                 const int gs = B.pos[v] + (int)B.ref_size[v];

@@ -80,7 +80,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[11], s_gt[10];
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[13], s_gt[10];
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
     u64 gt_entries = 0;
     unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch,
@@ -95,6 +95,7 @@ struct mg_ctx {
     mutable bool rec_ok = false;
     bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
     u32 rec_epoch = 1;
+    int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
     int use_ctx_set = 1;                       // 1: large context filters answer the scan's hit kernel from the set of their set positions (A/B)
@@ -637,6 +638,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_partition")) c->use_partition = value != 0;
     else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
     else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
+    else if (!strcmp(name, "use_packed_pool")) c->use_packed_pool = value != 0;
     else if (!strcmp(name, "map_ordered")) {
         if (c->map.slots && (value != 0) != (c->map_ordered != 0)) return fail(c, MG_ERR_STATE, "map_ordered is a layout: set it before the index is built or loaded");
         c->map_ordered = value != 0;
@@ -694,6 +696,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_partition")) *value = c->use_partition;
     else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
     else if (!strcmp(name, "map_dense")) *value = c->map_dense;
+    else if (!strcmp(name, "use_packed_pool")) *value = c->use_packed_pool;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
     else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
     else if (!strcmp(name, "record_counters_live")) *value = view(c).epoch != 0; // diagnostic: would a lookup launched now read the records' copies?
@@ -2093,6 +2096,15 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.sp_off = p->sp_off; B.sp_sample = p->sp_sample; B.sp_gt = p->sp_gt; B.sp_default = p->sp_default;
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
+    if (p->pool_bytes && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) { // the alleles packed like the reference (every call: the panel is the caller's)
+        void *p2, *pb;
+        const u64 n_words = (p->pool_bytes + 31) / 32 + 4;
+        TRY(scratch(c, c->s_blk[11], 8 * n_words, &p2));
+        TRY(scratch(c, c->s_blk[12], 4 * n_words, &pb));
+        TRY(reference_pack(c, (const u8 *)p->pool, p->pool_bytes, (u64 *)p2, (u32 *)pb));
+        B.pool2 = (const u64 *)p2;
+        B.poolbad = (const u32 *)pb;
+    }
     R.B = B;
     R.P = panel_view(p);
     R.gen_list = (u32 *)q[0]; R.fb_list = (u32 *)q[1]; R.fb_flag = (u8 *)q[2];
@@ -2343,7 +2355,7 @@ int upload_blocks(mg_ctx *c, size_t n_blocks, const uint64_t *blk_ref_base, cons
     p.n_contigs = (uint32_t)n_blocks;
     p.contig_base = (const uint64_t *)d[0]; p.contig_len = (const uint32_t *)d[1]; p.contig_id = (const uint32_t *)d[3];
     p.pos = (const int32_t *)d[4]; p.ref_size = (const uint32_t *)d[5]; p.min_size = (const uint32_t *)d[6]; p.present = (const uint8_t *)d[7];
-    p.var_allele_off = (const uint32_t *)d[8]; p.allele_off = (const uint32_t *)d[9]; p.pool = (const char *)d[10]; p.canon = (const uint8_t *)d[11];
+    p.var_allele_off = (const uint32_t *)d[8]; p.allele_off = (const uint32_t *)d[9]; p.pool = (const char *)d[10]; p.pool_bytes = pool_len; p.canon = (const uint8_t *)d[11];
     p.gt = (const uint16_t *)d[12]; p.n_samples = n_samples;
     p.sp_off = (const uint32_t *)d_sp[0]; p.sp_sample = (const uint32_t *)d_sp[1]; p.sp_gt = (const uint16_t *)d_sp[2];
     *out = p;

@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(TPB) ref_pack_kernel(const u8 *__restrict__ as
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const u64 at = 32 * w + 4 * (u64)j;
-        const u32 d = at < n ? q[j] : 0u;
+        u32 d = 0u;
+        if (at + 4 <= n) d = q[j];
+        else // the last, partial dword byte by byte: the buffer may end with its last base (the record loop's allele pool)
+            for (u64 i = at; i < n; ++i) d |= (u32)ascii[i] << (8 * (i - at));
         u32 t = (d >> 1) & 0x03030303u; // per byte: A0 C1 G3 T2
         t ^= (t >> 1) & 0x01010101u;    //           A0 C1 G2 T3
         const u32 c8 = (t * 0x01041040u) >> 24;

@@ -41,6 +41,7 @@ class ResidentPanel:
         d.n_vars, d.n_contigs, d.n_samples = self.n, len(panel.contig_len), self.n_samples
         for name in ("contig_base", "contig_len", "contig_id", "pos", "ref_size", "min_size", "present", "var_allele_off", "allele_off", "pool", "canon", "gt"):
             setattr(d, name, self.t[name].data_ptr())
+        d.pool_bytes = int(len(panel.pool))
         if sparse:
             so, ss, sg = sparse_genotypes(panel.gt, self.n_samples, sp_default)
             d.sp_default = sp_default

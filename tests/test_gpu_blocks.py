@@ -65,6 +65,7 @@ def _run_case(tmp_path, seed, haploid, k, ref_k, dense, set_limit=None, flat=1, 
     # the same index and counters on the device, through the ASCII batch calls
     ctx = Context(k, ref_k, opt.bf_size)
     ctx.set_option("use_flat_tier", flat)
+    ctx.set_option("use_packed_pool", seed % 2)   # signature k-mers assembled from the packed allele pool (odd seeds) or from its bytes
     if set_limit is not None:
         ctx.set_option("blocks_set_limit", set_limit)
     bits = idx.bf.set_positions()
