@@ -640,7 +640,8 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             const u32 ao = B.allele_off[s0 + a];
             const u8 *ap = B.pool + ao;
             const int al = (int)(B.allele_off[s0 + a + 1] - ao);
-            if (B.pool2) { // the allele's part of the window out of the packed pool: two loads and a shift per 32 bases, like the reference's
+            if (B.pool2 && al > 4) { // the allele's part of the window out of the packed pool: two loads and a shift per 32 bases, like the
+                                     // reference's (a SNP's single byte is cheaper as it is: measured at the C4 recipe, 7.5 against 8.0 ms)
                 int x = max(0, vs + mp);
                 const int xe = min(k, vs + al + mp);
                 while (x < xe) {
@@ -720,17 +721,21 @@ __global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W,
         const u32 a0 = B.var_allele_off[g];
         const u32 a = (u32)(item.code & 127);
         const u32 canon = B.canon[a0 + a];
-        const u8 *ap = B.pool + B.allele_off[a0 + a];
-        const int al = (int)(B.allele_off[a0 + a + 1] - B.allele_off[a0 + a]);
+        const u32 ao = B.allele_off[a0 + a];
+        const u8 *ap = B.pool + ao;
+        const int al = (int)(B.allele_off[a0 + a + 1] - ao);
         const bool is_ref = canon == 0;
         const int n_kmers = al - k + 1;
         // first: is every base ACGT?  (nothing is counted or inserted for a record the workgroup kernel will redo)
         bool good = k >= 17 && k <= MG_MAX_PACKED_K;
-        for (int x = lane; x < al; x += 64) {
-            bool o;
-            acgt_code(ap[x], &o);
-            good = good && o;
-        }
+        if (B.pool2) {
+            for (int x = 32 * lane; x < al; x += 32 * 64) good = good && !ref_bad(B.poolbad, (u64)ao + (u64)x, al - x < 32 ? al - x : 32);
+        } else
+            for (int x = lane; x < al; x += 64) {
+                bool o;
+                acgt_code(ap[x], &o);
+                good = good && o;
+            }
         if (!__all(good)) {
             if (lane == 0) W.fb_flag[g] = 1;
             continue;
@@ -742,12 +747,16 @@ __global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W,
             i32 w = 0;
             if (p < n_kmers) {
                 U128 Lf{0, 0};
-                for (int x = 0; x < k; ++x) {
-                    bool o;
-                    const u64 code = acgt_code(ap[p + x], &o);
-                    if (x < 32) Lf.lo |= code << (2 * x);
-                    else Lf.hi |= code << (2 * (x - 32));
-                }
+                if (B.pool2) { // the window out of the packed pool
+                    Lf.lo = ref_codes(B.pool2, (u64)ao + (u64)p, k < 32 ? k : 32);
+                    if (k > 32) Lf.hi = ref_codes(B.pool2, (u64)ao + (u64)p + 32, k - 32);
+                } else
+                    for (int x = 0; x < k; ++x) {
+                        bool o;
+                        const u64 code = acgt_code(ap[p + x], &o);
+                        if (x < 32) Lf.lo |= code << (2 * x);
+                        else Lf.hi |= code << (2 * (x - 32));
+                    }
                 const U128 mk = mask128(2 * k);
                 const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
                 const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
