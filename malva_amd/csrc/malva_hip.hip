@@ -1941,10 +1941,36 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
     TRY(upload(c, c->s_misc[3], allele_sig_off, 8 * (n_alleles + 1), &d_ao));
     TRY(scratch(c, c->s_misc[4], 4 * n_alleles, &d_cov));
     if (n_rows) {
+        // exact-map keys the packed table cannot hold (every key, when k > MG_MAX_PACKED_K) live in the context's host list:
+        // the kernel marks such rows and their values are filled in from there (KMAP::get_count, kmap.hpp:124-131)
+        void *d_irr = nullptr;
+        const bool host_keys = !c->map.irregular.empty();
+        if (host_keys) {
+            TRY(scratch(c, c->s_irr, n_rows, &d_irr));
+            HIP_TRY(c, hipMemsetAsync(d_irr, 0, n_rows, c->stream));
+        }
         hipLaunchKernelGGL(rows_kernel<OP_WEIGHT>, dim3(nblocks(n_rows)), dim3(TPB), 0, c->stream, (const u8 *)d_rows, stride,
                            n_rows, view(c, MG_BF_ALT), view(c), (const u32 *)nullptr, (const u8 *)d_isref, d_w,
-                           (u8 *)nullptr);
+                           (u8 *)d_irr);
         HIP_TRY(c, hipGetLastError());
+        if (host_keys) {
+            std::vector<u8> irr(n_rows);
+            std::vector<i32> w(n_rows);
+            HIP_TRY(c, hipMemcpyAsync(irr.data(), d_irr, n_rows, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(w.data(), d_w, 4 * n_rows, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            bool any = false;
+            for (size_t i = 0; i < n_rows; ++i)
+                if (irr[i]) {
+                    auto it = c->map.irregular.find(host_irregular_key(rows + i * stride, stride));
+                    w[i] = it != c->map.irregular.end() ? it->second : 0;
+                    any = true;
+                }
+            if (any) {
+                HIP_TRY(c, hipMemcpyAsync(d_w, w.data(), 4 * n_rows, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream)); // (w leaves scope)
+            }
+        }
     }
     hipLaunchKernelGGL(cover_kernel, dim3(nblocks(n_alleles)), dim3(TPB), 0, c->stream, (const i32 *)d_w, (const u64 *)d_so,
                        (const u64 *)d_ao, (u64)n_alleles, (u32 *)d_cov);

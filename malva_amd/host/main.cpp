@@ -953,7 +953,7 @@ inline void parse_table_line(const char *p, const char *e, const Options &o, Tab
     while (q < e && isspace((unsigned char)*q)) ++q;
     uint64_t count = 0; // strtoul: leading digits
     while (q < e && *q >= '0' && *q <= '9') count = count * 10 + (uint64_t)(*q++ - '0');
-    if (!acgt) {
+    if (!acgt || o.ref_k > MG_MAX_PACKED_K) { // (a row the 2-bit table cannot hold -- or any row, beyond 64 bases: the ASCII batch forms below)
         std::string ctx(p, len);
         upper_inplace(ctx);
         odd.ctx.add(ctx);
@@ -1468,7 +1468,8 @@ int call_main(const Options &o)
             base_name = seq_name;
             base_known = true;
         }
-        const bool lone = vb.is_lone_short() && base_found &&
+        // (k beyond the packed forms: exact-map keys live in the context's host-side list, which only the ASCII batch lookups reach)
+        const bool lone = o.k <= MG_MAX_PACKED_K && vb.is_lone_short() && base_found &&
                           (long)vb.vars[0].ref_pos + vb.vars[0].ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
         if (lone) {
             Variant &v = vb.vars[0];

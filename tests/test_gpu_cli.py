@@ -372,3 +372,23 @@ def test_sample_columns_decoded_on_the_device_give_the_same_records(tmp_path, se
     kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
     strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)
     assert strip(got) == strip(pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt))
+
+
+@pytest.mark.parametrize("k,ref_k,haploid", [(71, 79, False), (65, 65, True)])
+def test_k_above_64_goes_through_the_bytewise_forms(tmp_path, k, ref_k, haploid):
+    """the reference takes any k (argument_parser.hpp:57-58); the packed kernels hold k-mers of up to 64 bases, so beyond that
+    `index` and `call` use the host enumerator and the ASCII batch forms of every store call -- same records as the oracle"""
+    prefix = str(tmp_path / "case")
+    contigs, records = vcf_synth.make_case(prefix, 90 + k, haploid=haploid, k=k, n_clusters=40, vcf_strip_chr=True)
+    table = str(tmp_path / "donor.kmers")
+    vcf_synth.donor_table(contigs, records, ref_k, 90 + k, table + ".txt")
+    opt = pipeline.Options(haploid=haploid, verbose=True, k=k, ref_k=ref_k, bf_size=1 << 33, strip_chr=True)
+    idx = pipeline.index(prefix + ".fa", prefix + ".vcf", opt)
+    kmers = [(l.split()[0].encode(), int(l.split()[1])) for l in open(table + ".txt")]
+    want = pipeline.call(prefix + ".fa", prefix + ".vcf", idx, kmers, opt)
+    args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p", "-v"] + (["-1"] if haploid else []) + [prefix + ".fa", prefix + ".vcf", table]
+    run_cli(["index"] + args)
+    got = run_cli(["call"] + args)
+    strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)
+    assert strip(got) == strip(want)
+    assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 10
