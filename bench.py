@@ -581,11 +581,18 @@ def record(job, elapsed, steps, warmup, kt, sustained):
         fname = ("scan_filter12_kernel<%s>" if job.compact else "scan_filter_kernel<%s,2>") % spec
         sname = "%s + scan_probe_kernel + scan_hits_kernel" % fname
     traffic, tsrc = traffic_of(job)
+    # the three kernels' counted HBM bytes (profiles/traffic_scan_c3.json: FETCH_SIZE / WRITE_SIZE passes at HEAD), when this IS that workload
+    scan_traffic, scan_tsrc = None, None
+    t3 = os.path.join(ROOT, "profiles", "traffic_scan_c3.json")
+    if job.compact and os.path.exists(t3) and not job.args.scan_ablate and not ctx.get_option("scan_tickets") and not ctx.get_option("scan_bins"):
+        t = json.load(open(t3))
+        if t.get("units_per_launch") == job.n_rows and t.get("bf_bits") == job.bf_bits and (K, R) == (35, 43):
+            scan_traffic, scan_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_scan_c3.json (rocprofv3 PMC)"
     # the whole H10 loop (filter + probe + hit kernels, summed): the fraction SURVEY 8(d)'s 44 B/k-mer budget is about
     roof_scan = {"kernel": sname, "bound": "hbm", "achieved": ach_scan, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_scan / HBM_PEAK_GBS,
-                 "traffic": None, "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch, "bytes_per_unit": SCAN_BYTES_PER_KMER,
-                 "units_per_launch": rows_per_launch, "avg_launch_ms": scan_sum,
-                 "note": "the three kernels of one scan chunk, back to back on one stream; traffic is counted for the filter kernel alone (roofline_filter)"}
+                 "traffic": scan_traffic, "traffic_source": scan_tsrc, "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch,
+                 "bytes_per_unit": SCAN_BYTES_PER_KMER, "units_per_launch": rows_per_launch, "avg_launch_ms": scan_sum,
+                 "note": "the three kernels of one scan chunk, back to back on one stream (roofline_filter: the filter kernel alone)"}
     roof_filter = {"kernel": fname, "bound": "hbm", "achieved": ach_filter, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_filter / HBM_PEAK_GBS,
                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch,
                    "bytes_per_unit": SCAN_BYTES_PER_KMER, "units_per_launch": rows_per_launch, "avg_launch_ms": filt}

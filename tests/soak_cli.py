@@ -38,6 +38,10 @@ for seed in range(first, first + n):
         args = ["-k", str(k), "-r", str(ref_k), "-b", "1", "-p"] + (["-1"] if haploid else []) + (["-v"] if verbose else [])
         args += [prefix + ".fa", prefix + ".vcf", table]
         env = dict(os.environ, MALVA_GENO_CUT_BATCH=str(1 + seed % 13)) if seed % 3 == 0 else dict(os.environ)   # block-cut batch seams everywhere
+        if seed % 5 in (1, 2):       # the sample columns decoded on the device (what a panel of >= 1024 samples gets by itself)
+            env.update(MALVA_GENO_GT_DEVICE="1", MALVA_GENO_VCF_POOL="1")
+        elif seed % 5 == 3:          # the reader's thread pool over blocks of whole lines (what a file of >= 8 MB gets by itself)
+            env.update(MALVA_GENO_VCF_POOL="1")
         r = subprocess.run([BIN, "index"] + args, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-500:]
         r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, env=env)
@@ -46,7 +50,8 @@ for seed in range(first, first + n):
         nonref = sum(1 for l in want.split("\n") if l and not l.startswith("#") and not l.split("\t")[-1].startswith(("0:", "0/0:")))
         print("seed %d far=%d haploid=%d dense=%d verbose=%d k=%d r=%d records=%d nonref=%d %s %s" % (
             seed, far, haploid, dense, verbose, k, ref_k, want.count("\n"), nonref, "OK" if ok else "MISMATCH",
-            "(host blocks)" if "enumerated on the host" in r.stderr else ""), flush=True)
+            ("(host blocks)" if "enumerated on the host" in r.stderr else "") + (" gt-device" if env.get("MALVA_GENO_GT_DEVICE") == "1" else "") +
+            (" pool" if env.get("MALVA_GENO_VCF_POOL") == "1" else "")), flush=True)
         if not ok:
             bad += 1
             for a, b in zip(r.stdout.split("\n"), want.split("\n")):

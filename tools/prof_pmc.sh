@@ -18,6 +18,8 @@ GROUPS_=(
  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_WAIT_INST_LDS"
 )
+# PMC_GROUPS="FETCH_SIZE;WRITE_SIZE" (groups separated by ';') replaces the default set
+if [ -n "$PMC_GROUPS" ]; then IFS=';' read -r -a GROUPS_ <<< "$PMC_GROUPS"; fi
 cd /tmp
 i=0
 for grp in "${GROUPS_[@]}"; do
