@@ -81,6 +81,8 @@ struct mg_ctx {
     BFState bf[2];
     MapState map;
     Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[13], s_gt[10];
+    void *h_gt_stage = nullptr;                       // pinned staging for mg_decode_gt_text's text (a pageable source is copied by the runtime in small synchronous pieces)
+    size_t h_gt_stage_cap = 0;
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
     u64 gt_entries = 0;
     unsigned long long *d_gen_count = nullptr; // [0] records listed for cover_blocks_kernel, [1] insertion-row cursor / block count of a host-form batch,
@@ -569,6 +571,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
         hipFree(c->s_raw[i].p);
     }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->h_gt_stage) hipHostFree(c->h_gt_stage);
     hipFree(c->d_kmc_lut);
     if (c->joined) { // the two counter arrays alias one allocation
         hipFree(c->joined);
@@ -595,6 +598,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
     for (auto &s : c->s_blk) hipFree(s.p);
+    for (auto &s : c->s_gt) hipFree(s.p);
     hipFree(c->d_gen_count);
     hipFree(c->d_hit_count);
     hipFree(c->d_ln);
@@ -2755,7 +2759,18 @@ MG_EXPORT int mg_decode_gt_text(mg_ctx *c, const char *text, size_t text_bytes, 
     std::vector<unsigned long long> off(n_records);
     for (size_t r = 0; r < n_records; ++r) off[r] = span_len[r] ? span_off[r] - lo : 0;
     void *d_text, *d_off, *d_len, *d_gi, *d_rank, *d_tok, *d_words, *d_stats;
-    TRY(upload(c, c->s_gt[0], text + lo, hi - lo, &d_text));
+    { // the text goes through a pinned staging buffer: one memcpy at memory speed, then one DMA
+        const size_t nb = hi - lo;
+        if (nb > c->h_gt_stage_cap) {
+            if (c->h_gt_stage) hipHostFree(c->h_gt_stage);
+            c->h_gt_stage = nullptr;
+            c->h_gt_stage_cap = 0;
+            HIP_TRY(c, hipHostMalloc(&c->h_gt_stage, nb + nb / 4 + 4096, hipHostMallocDefault));
+            c->h_gt_stage_cap = nb + nb / 4 + 4096;
+        }
+        if (nb) memcpy(c->h_gt_stage, text + lo, nb);
+        TRY(upload(c, c->s_gt[0], c->h_gt_stage, nb, &d_text));
+    }
     TRY(upload(c, c->s_gt[1], off.data(), 8 * n_records, &d_off));
     TRY(upload(c, c->s_gt[2], span_len, 4 * n_records, &d_len));
     TRY(upload(c, c->s_gt[3], gt_index, 4 * n_records, &d_gi));

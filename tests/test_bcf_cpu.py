@@ -50,3 +50,32 @@ def test_truncated_bcf_is_an_error(tmp_path, golden_dir):
     open(bcf, "wb").write(data[:len(data) * 2 // 3])
     r = subprocess.run([BIN, "dump-kmers", "-1", os.path.join(golden_dir, "haploid.fa"), bcf, "call"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("group", [None, "70000", "1"])
+def test_bgzipped_vcf_is_inflated_member_by_member(tmp_path, group):
+    """a .vcf.gz as bgzip writes it (BGZF: what tabix needs, what panels ship as): the reader inflates the members of a group side
+    by side, each to its place; lines cross members and groups (`group`: inflated bytes per group, forced small); the text
+    panel, the BGZF one and the BGZF one through zlib's gzread (MALVA_GENO_NO_BGZF) must enumerate identically; a member
+    with a flipped bit is an error"""
+    prefix = str(tmp_path / "case")
+    vcf_synth.make_case(prefix, 9, haploid=False, k=35, n_clusters=300, n_samples=40, vcf_strip_chr=True)
+    gz = prefix + ".bgzf.vcf.gz"
+    data = open(prefix + ".vcf", "rb").read()
+    with open(gz, "wb") as out:
+        bcf_writer._bgzf(data, out)
+    assert len(data) > 3 * 0xFF00                                              # several members
+    args = ["-k", "35", "-p", prefix + ".fa"]
+    want = _dump(args + [prefix + ".vcf", "call"])
+    env = dict(os.environ, MALVA_GENO_VCF_POOL="1")
+    if group:
+        env["MALVA_GENO_BGZF_GROUP"] = group
+    for e in (env, dict(env, MALVA_GENO_NO_BGZF="1")):
+        r = subprocess.run([BIN, "dump-kmers"] + args + [gz, "call"], capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout == want and want.count("SIG ") > 1000
+    bad = bytearray(open(gz, "rb").read())
+    bad[len(bad) // 2] ^= 0x10
+    open(gz, "wb").write(bytes(bad))
+    r = subprocess.run([BIN, "dump-kmers"] + args + [gz, "call"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
