@@ -374,6 +374,14 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
         for (int j = 0; j < 22; ++j) d.rel[j] = 0;
         for (int j = 0; j < len_l; ++j) d.rel[j] = L.mem[cl][len_l - 1 - j];
         for (int j = 0; j < len_r; ++j) d.rel[len_l + 1 + j] = R.mem[cr][j];
+        // rel[21] (never a member: a chain has at most 21) = 1: every member replaces one base and has a one-base allele --
+        // a chain of SNPs unless a pick takes a longer ALT; fw_eval_kernel tries its fixed-geometry assembly only then
+        bool snps = true;
+        for (int j = 0; j < d.m; ++j) {
+            const u32 v = g + d.rel[j];
+            snps = snps && B.ref_size[v] == 1 && B.min_size[v] == 1;
+        }
+        d.rel[21] = snps ? 1 : 0;
         out[c] = d;
     }
 }
@@ -574,6 +582,21 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
         if (W.fb_flag[g]) continue;
         const int m = d.m, jm = d.jm;
         const i32 ref_len = (i32)B.contig_len[d.cid];
+        // A chain of SNPs (every member one base for one base -- all of a whole-genome SNP panel's clusters) has the same geometry
+        // whatever the pick: the window is the reference around the central record, k/2 bases to its left, with the members'
+        // bases put in.  It is built beside the lengths below and used when every member turned out to be such a record.
+        const u64 cbase = B.contig_base[d.cid];
+        const int w0 = B.pos[g] - k / 2;
+        const bool snp_try = d.rel[21] == 1 && B.snp_chains && k >= 17 && k <= MG_MAX_PACKED_K && w0 >= 0 && w0 + k <= ref_len;
+        U128 Ls{0, 0};
+        bool snp_ok = snp_try;
+        if (snp_try) { // (requested before the members' loads are: they wait for nothing)
+            const u64 at = cbase + (u64)w0;
+            Ls.lo = ref_codes(B.ref2, at, k < 32 ? k : 32);
+            if (k > 32) Ls.hi = ref_codes(B.ref2, at + 32, k - 32);
+            snp_ok = !ref_bad(B.refbad, at, k < 32 ? k : 32) && (k <= 32 || !ref_bad(B.refbad, at + 32, k - 32));
+        }
+        bool all_snp = true;
         // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
         int len_v = 0, mid_pos = 0, mid_len = 0, sh = 0;
         u32 mid_allele = 0;
@@ -585,14 +608,27 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
             const u32 a = (u32)(item.code >> sh) & ((1u << bits) - 1);
             sh += bits;
-            const int al = (int)(B.allele_off[s0 + a + 1] - B.allele_off[s0 + a]);
+            const u32 ao = B.allele_off[s0 + a];
+            const int al = (int)(B.allele_off[s0 + a + 1] - ao);
+            const int pv = B.pos[v], rs = (int)B.ref_size[v];
             if (j == jm) {
                 mid_pos = len_v;
                 mid_len = al;
                 mid_allele = a;
             }
+            all_snp = all_snp && al == 1 && rs == 1;
+            if (snp_try && al == 1) { // the member's base at its own place in the window (a member outside it changes nothing)
+                const int x = pv - w0;
+                if (x >= 0 && x < k) {
+                    bool o;
+                    const u64 code = acgt_code(B.pool[ao], &o);
+                    snp_ok = snp_ok && o;
+                    if (x < 32) Ls.lo = (Ls.lo & ~(3ULL << (2 * x))) | code << (2 * x);
+                    else Ls.hi = (Ls.hi & ~(3ULL << (2 * (x - 32)))) | code << (2 * (x - 32));
+                }
+            }
             len_v += al;
-            last_end = B.pos[v] + (int)B.ref_size[v];
+            last_end = pv + rs;
             if (j + 1 < m) len_v += B.pos[g + d.rel[j + 1]] - last_end;
         }
         const u32 a0 = B.var_allele_off[g];
@@ -608,7 +644,7 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
         // out of the packed reference 32 bases at a time (two loads and a shift each), alleles byte by byte
         U128 Lf{0, 0};
         bool ok = k >= 17 && k <= MG_MAX_PACKED_K;
-        const u64 cbase = B.contig_base[d.cid];
+        const bool fast_snp = snp_try && all_snp;
         auto put = [&](int x, u32 byte) {
             bool o;
             const u64 code = acgt_code(byte, &o);
@@ -628,6 +664,10 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
                 from += n;
             }
         };
+        if (fast_snp) {
+            Lf = Ls;
+            ok = snp_ok;
+        } else {
         put_ref(0, mp < k ? (mp > 0 ? mp : 0) : k, (long long)first_pos - mp);
         int vs = 0;
         sh = 0;
@@ -668,6 +708,7 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             const int x0 = max(0, len_v + mp);
             if (x0 < k) put_ref(x0, k, (long long)last_end + (x0 - mp - len_v));
         }
+        } // (general assembly)
         if (!ok) { // a base outside ACGT (or a k the packed form does not hold): the byte-wise path of the workgroup kernel
             W.fb_flag[g] = 1;
             continue;

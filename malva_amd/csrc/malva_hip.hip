@@ -97,6 +97,7 @@ struct mg_ctx {
     mutable bool rec_ok = false;
     bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
     u32 rec_epoch = 1;
+    int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
@@ -643,6 +644,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_flat_tier")) c->use_flat_tier = value != 0;
     else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
     else if (!strcmp(name, "use_packed_pool")) c->use_packed_pool = value != 0;
+    else if (!strcmp(name, "use_snp_chains")) c->use_snp_chains = value != 0;
     else if (!strcmp(name, "map_ordered")) {
         if (c->map.slots && (value != 0) != (c->map_ordered != 0)) return fail(c, MG_ERR_STATE, "map_ordered is a layout: set it before the index is built or loaded");
         c->map_ordered = value != 0;
@@ -701,6 +703,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_flat_tier")) *value = c->use_flat_tier;
     else if (!strcmp(name, "map_dense")) *value = c->map_dense;
     else if (!strcmp(name, "use_packed_pool")) *value = c->use_packed_pool;
+    else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
     else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
     else if (!strcmp(name, "record_counters_live")) *value = view(c).epoch != 0; // diagnostic: would a lookup launched now read the records' copies?
@@ -2126,6 +2129,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.sp_off = p->sp_off; B.sp_sample = p->sp_sample; B.sp_gt = p->sp_gt; B.sp_default = p->sp_default;
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
+    B.snp_chains = c->use_snp_chains;
     if (p->pool_bytes && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) { // the alleles packed like the reference (every call: the panel is the caller's)
         void *p2, *pb;
         const u64 n_words = (p->pool_bytes + 31) / 32 + 4;
