@@ -80,7 +80,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[13], s_gt[10];
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[13], s_gt[10], s_scan;
     void *h_gt_stage = nullptr;                       // pinned staging for mg_decode_gt_text's text (a pageable source is copied by the runtime in small synchronous pieces)
     size_t h_gt_stage_cap = 0;
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
@@ -202,6 +202,18 @@ int scratch(mg_ctx *c, Scratch &s, size_t bytes, void **out)
         s.cap = want;
     }
     *out = s.p;
+    return MG_OK;
+}
+// exclusive scan of n_tiles u32 sums in place, their total (u64) to *d_total: store_kernels.h
+int launch_tile_scan(mg_ctx *c, u32 *d_tiles, u64 n_tiles, unsigned long long *d_total)
+{
+    const u64 n_part = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    void *part;
+    TRY(scratch(c, c->s_scan, 8 * (n_part ? n_part : 1), &part));
+    if (n_part) hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)n_part), dim3(SCAN_TPB), 0, c->stream, (const u32 *)d_tiles, n_tiles, (unsigned long long *)part);
+    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(SCAN_TPB), 0, c->stream, (unsigned long long *)part, n_part, d_total);
+    if (n_part) hipLaunchKernelGGL(tile_rescan_kernel, dim3((unsigned)n_part), dim3(SCAN_TPB), 0, c->stream, d_tiles, n_tiles, (const unsigned long long *)part);
+    HIP_TRY(c, hipGetLastError());
     return MG_OK;
 }
 int upload(mg_ctx *c, Scratch &s, const void *host, size_t bytes, void **dev)
@@ -600,6 +612,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     for (auto &s : c->s_misc) hipFree(s.p);
     for (auto &s : c->s_blk) hipFree(s.p);
     for (auto &s : c->s_gt) hipFree(s.p);
+    hipFree(c->s_scan.p);
     hipFree(c->d_gen_count);
     hipFree(c->d_hit_count);
     hipFree(c->d_ln);
@@ -777,7 +790,7 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
     unsigned long long *d_total = c->d_hit_count;
     hipLaunchKernelGGL(blk_pop_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, b.words, b.nwords, b.n_blk, b.blk,
                        (u32 *)d_tiles);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (u32 *)d_tiles, n_tiles, d_total);
+    TRY(launch_tile_scan(c, (u32 *)d_tiles, n_tiles, d_total));
     HIP_TRY(c, hipGetLastError());
     unsigned long long total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2044,7 +2057,7 @@ namespace {
 int scan_flags(mg_ctx *c, u64 n, const u8 *d_flags, u32 *d_tile_sums, u32 *d_blk_var_off, u32 *d_var_block, unsigned long long *d_n_blocks)
 {
     const u64 n_tiles = nblocks(n);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_tile_sums, n_tiles, c->d_hit_count + 2); // (the total is re-derived by the scatter)
+    TRY(launch_tile_scan(c, d_tile_sums, n_tiles, c->d_hit_count + 2)); // (the total is re-derived by the scatter)
     hipLaunchKernelGGL(flag_scatter_kernel, dim3((unsigned)n_tiles), dim3(TPB), 0, c->stream, n, d_flags, (const u32 *)d_tile_sums, d_blk_var_off, d_var_block,
                        d_n_blocks);
     HIP_TRY(c, hipGetLastError());
@@ -2130,7 +2143,9 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
     B.snp_chains = c->use_snp_chains;
-    if (p->pool_bytes && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) { // the alleles packed like the reference (every call: the panel is the caller's)
+    // the alleles packed like the reference (every call: the panel is the caller's) -- unless the pool is too small to hold alleles worth
+    // it (a SNP panel: two one-base alleles per record; fw_eval takes alleles of up to 4 bases from the bytes anyway)
+    if (p->pool_bytes && p->pool_bytes * 2 > n * 5 && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) {
         void *p2, *pb;
         const u64 n_words = (p->pool_bytes + 31) / 32 + 4;
         TRY(scratch(c, c->s_blk[11], 8 * n_words, &p2));
