@@ -97,6 +97,7 @@ struct mg_ctx {
     mutable bool rec_ok = false;
     bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
     u32 rec_epoch = 1;
+    int blocks_round_log2 = 24;                // see blocks_setup
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
@@ -658,6 +659,10 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
     else if (!strcmp(name, "use_packed_pool")) c->use_packed_pool = value != 0;
     else if (!strcmp(name, "use_snp_chains")) c->use_snp_chains = value != 0;
+    else if (!strcmp(name, "blocks_round_log2")) {
+        if (value < 10 || value > 24) return fail(c, MG_ERR_ARG, "blocks_round_log2: 10..24");
+        c->blocks_round_log2 = (int)value;
+    }
     else if (!strcmp(name, "map_ordered")) {
         if (c->map.slots && (value != 0) != (c->map_ordered != 0)) return fail(c, MG_ERR_STATE, "map_ordered is a layout: set it before the index is built or loaded");
         c->map_ordered = value != 0;
@@ -717,6 +722,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "map_dense")) *value = c->map_dense;
     else if (!strcmp(name, "use_packed_pool")) *value = c->use_packed_pool;
     else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
+    else if (!strcmp(name, "blocks_round_log2")) *value = c->blocks_round_log2;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
     else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
     else if (!strcmp(name, "record_counters_live")) *value = view(c).epoch != 0; // diagnostic: would a lookup launched now read the records' copies?
@@ -2107,7 +2113,10 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     BlocksRun R{};
     R.c = c;
     R.p = p;
-    R.round = std::min<u64>(n, 1ULL << 22);
+    // general records per round of tier 2.  The list's length lives on the device, so ceil(n / round) rounds are launched and those
+    // beyond its end find nothing to do -- at ~30 us of empty launches each: 2^24 records per round (13.5 GB of round buffers at most,
+    // of 288) leaves a whole-genome panel 5 rounds instead of 20
+    R.round = std::min<u64>(n, 1ULL << c->blocks_round_log2);
     R.n_rounds = (n + R.round - 1) / R.round;
     void *q[8];
     TRY(scratch(c, c->s_blk[0], 4 * n, &q[0]));                                                   // gen_list

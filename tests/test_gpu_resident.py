@@ -36,6 +36,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, spars
         ocapi.ref_scan(obf, octx, panel.genome[int(b):int(b) + int(l)].tobytes(), k, ref_k)
     octx.switch_mode()
     with Context(k, ref_k, bits) as ctx:
+        ctx.set_option("blocks_round_log2", 14)             # several rounds of tier 2 (and a round seam inside the general list) on panels this size
         ctx.reference_upload(panel.genome)
         rp = ResidentPanel(panel, 0, haploid=haploid, sparse=sparse)
         ovf = rp.index(ctx)
