@@ -680,8 +680,8 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             const u32 ao = B.allele_off[s0 + a];
             const u8 *ap = B.pool + ao;
             const int al = (int)(B.allele_off[s0 + a + 1] - ao);
-            if (B.pool2 && al > 4) { // the allele's part of the window out of the packed pool: two loads and a shift per 32 bases, like the
-                                     // reference's (a SNP's single byte is cheaper as it is: measured at the C4 recipe, 7.5 against 8.0 ms)
+            if (B.pool2) { // the allele's part of the window out of the packed pool: two loads and a shift per 32 bases, like the reference's
+                           // (chains of SNPs, for whose single bytes this costs more than it saves, take the fixed-geometry form above)
                 int x = max(0, vs + mp);
                 const int xe = min(k, vs + al + mp);
                 while (x < xe) {
