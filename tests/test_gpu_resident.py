@@ -37,6 +37,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, spars
     octx.switch_mode()
     with Context(k, ref_k, bits) as ctx:
         ctx.set_option("blocks_round_log2", 14)             # several rounds of tier 2 (and a round seam inside the general list) on panels this size
+        ctx.set_option("use_record_counters", 2)            # the tiers' lookups read the records' own counter copies, as they do by themselves at whole-genome size
         ctx.reference_upload(panel.genome)
         rp = ResidentPanel(panel, 0, haploid=haploid, sparse=sparse)
         ovf = rp.index(ctx)
@@ -56,6 +57,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, spars
         assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
         assert map_values_by_key(ctx) == dict(omap.items())
         # ---- call: cut, cover, genotype, everything resident ----
+        assert ctx.get_option("record_counters_live") == 1
         rp.call_step(ctx)
         got = rp.results()
         assert np.array_equal(got["blk_var_off"], args["blk_var_off"])
