@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(TPB) blk_pop_kernel(const u64 *words, u64 nwor
 }
 // Exclusive scan of tile sums in place, total to *total (u64), in three launches (launch_tile_scan): per chunk of SCAN_CHUNK sums a
 // workgroup adds them up; one workgroup scans the chunk totals; every workgroup rescans its chunk from its base.  (The single
-// workgroup below, each thread walking its own stretch, took 0.94 ms for the 3.1e5 tile sums of an 8e7-record cut: the loads
-// of a wave were 1.2 KB apart and a thousand of them came one after the other.)
+// workgroup this replaces, each thread walking its own stretch, took 0.94 ms for the 3.1e5 tile sums of an 8e7-record cut: the
+// loads of a wave were 1.2 KB apart and a thousand of them came one after the other.)
 constexpr int SCAN_TPB = 1024, SCAN_PER = 8, SCAN_CHUNK = SCAN_TPB * SCAN_PER;
 __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long *sh16)
 {
@@ -325,30 +325,6 @@ __global__ void __launch_bounds__(SCAN_TPB) tile_rescan_kernel(u32 *x, u64 n, co
         carry += round_total;
         __syncthreads();
     }
-}
-// single workgroup: exclusive scan of tile sums in place; total to *total (u64)  (kept for reference: see above)
-__global__ void __launch_bounds__(1024) tile_scan_kernel(u32 *tile_sums, u64 n_tiles, unsigned long long *total)
-{
-    __shared__ unsigned long long sh[1024];
-    const u64 per = (n_tiles + 1023) / 1024;
-    const u64 lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    unsigned long long s = 0;
-    for (u64 i = lo; i < hi; ++i) s += tile_sums[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned long long v = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned long long run = sh[threadIdx.x] - s;
-    for (u64 i = lo; i < hi; ++i) {
-        const u32 v = tile_sums[i];
-        tile_sums[i] = (u32)run; // valid while the grand total fits 32 bits (checked by the host)
-        run += v;
-    }
-    if (threadIdx.x == 1023) *total = sh[1023];
 }
 __global__ void __launch_bounds__(TPB) blk_add_kernel(u32 *blk, u64 n_blk, const u32 *tile_sums, u32 total)
 {

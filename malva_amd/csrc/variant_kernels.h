@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(TPB) block_heads_kernel(const u32 *__restrict_
     const u64 b = (u64)blockIdx.x * TPB + threadIdx.x;
     if (b < *n_blocks && blk_var_off[b] < n) flags[blk_var_off[b]] = 1;
 }
-// With the tiles' counts scanned (tile_scan_kernel): blk_var_off[b] = first record of block b, blk_var_off[n_blocks] = n,
+// With the tiles' counts scanned (launch_tile_scan): blk_var_off[b] = first record of block b, blk_var_off[n_blocks] = n,
 // var_block[i] = block of record i.  Any of the three outputs may be NULL.
 __global__ void __launch_bounds__(TPB) flag_scatter_kernel(u64 n, const u8 *__restrict__ flags, const u32 *__restrict__ tile_base, u32 *__restrict__ blk_var_off,
                                                            u32 *__restrict__ var_block, unsigned long long *n_blocks_out)
