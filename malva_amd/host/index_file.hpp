@@ -10,8 +10,9 @@
 //       The rank directory is not stored; both sides rebuild it on load (bloom_filter.hpp:143).
 //       sdsl-lite is a third-party library absent from the reference checkout and no index fixture exists there:
 //       FORMAT UNPINNED (restated from sdsl's published serialisation), see DESIGN.md.
-//   <vcf>.c<ref_k>.k<k>.malvax.hipz  this build's compact form (gzip): the filters as sorted bit positions.  A filter
-//       is a few million set bits in 2^33..2^37: the reference's form costs two passes over gigabytes of zeros.
+//   <vcf>.c<ref_k>.k<k>.malvax.hipz  this build's compact form: the filters as sorted bit positions (a filter is a few million
+//       set bits in 2^33..2^37: the reference's form costs two passes over gigabytes of zeros), the keys without padding, all of
+//       it in independently compressed chunks (zstd level 1 + CRC-32) that every host core writes and reads side by side.
 //
 // `index` writes the reference's container unless MALVA_GENO_INDEX_FORMAT=hipz; `call` reads whichever exists
 // (.zst first).  The payload in memory is sparse either way: that is what mg_bf_import_sparse / export_sparse take.
@@ -24,8 +25,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace malva {
@@ -287,37 +290,178 @@ template <class T> void gz_get(gzFile f, T *p, size_t n)
 const char MAGIC[8] = {'M', 'G', 'H', 'I', 'P', 'X', '2', '\n'};
 } // namespace hipz
 
+// Version 3 of the compact container: the payload's arrays as SECTIONS of independently compressed chunks (zstd level 1, 8 MiB of
+// raw bytes each), so that writing and reading run on all host cores.  (Version 2 pushed everything through one gzip stream: 5 s to
+// write and 2.3 s to read the index of 1e7 SNPs, 40 s and 18 s at whole-genome size.)  Layout, all integers little-endian u64:
+//   "MGHIPX3\n", k, ref_k, bf_bits
+//   mode[0], n_set[0], mode[1], n_set[1], n_keys, key_bytes        (key_bytes: the keys as rows of this many bytes, NUL-padded)
+//   six sections -- pos[0] (u64), cnt[0] (u16), pos[1], cnt[1], keys, vals (i32) -- each:
+//       raw_bytes, n_chunks, then per chunk its compressed size and the CRC-32 of its raw bytes, then the chunks back to back
+// Version 2 files are still read.
+namespace hipz {
+const char MAGIC3[8] = {'M', 'G', 'H', 'I', 'P', 'X', '3', '\n'};
+constexpr size_t CHUNK = 8u << 20;
+template <class F> void parallel_for(size_t n, F f)
+{
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, n}));
+    std::vector<std::exception_ptr> errs(nt);
+    std::vector<std::thread> th;
+    auto work = [&](unsigned t) {
+        try {
+            for (size_t i = t; i < n; i += nt) f(i);
+        } catch (...) {
+            errs[t] = std::current_exception();
+        }
+    };
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+}
+inline void put_section(FILE *f, const void *data, size_t bytes)
+{
+    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    std::vector<std::vector<char>> out(n_chunks);
+    std::vector<uint64_t> crcs(n_chunks);
+    parallel_for(n_chunks, [&](size_t i) {
+        const size_t at = i * CHUNK, n = std::min(CHUNK, bytes - at);
+        crcs[i] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)data + at, (uInt)n);
+        out[i].resize(ZSTD_compressBound(n));
+        const size_t c = ZSTD_compress(out[i].data(), out[i].size(), (const char *)data + at, n, 1);
+        if (ZSTD_isError(c)) throw std::runtime_error(std::string("index file: zstd: ") + ZSTD_getErrorName(c));
+        out[i].resize(c);
+    });
+    std::vector<uint64_t> head{(uint64_t)bytes, (uint64_t)n_chunks};
+    for (size_t i = 0; i < n_chunks; ++i) {
+        head.push_back(out[i].size());
+        head.push_back(crcs[i]);
+    }
+    if (fwrite(head.data(), 8, head.size(), f) != head.size()) throw std::runtime_error("index file: write failed");
+    for (auto &o : out)
+        if (!o.empty() && fwrite(o.data(), 1, o.size(), f) != o.size()) throw std::runtime_error("index file: write failed");
+}
+inline void get_section(FILE *f, void *data, size_t bytes, uint64_t file_bytes, const std::string &path)
+{
+    uint64_t head[2];
+    if (fread(head, 8, 2, f) != 2) throw std::runtime_error("index file: truncated");
+    const size_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    if (head[0] != bytes || head[1] != n_chunks) throw std::runtime_error("index " + path + " is corrupt (section header)");
+    std::vector<uint64_t> pairs(2 * n_chunks), csize(n_chunks), crcs(n_chunks);
+    if (n_chunks && fread(pairs.data(), 8, 2 * n_chunks, f) != 2 * n_chunks) throw std::runtime_error("index file: truncated");
+    for (size_t i = 0; i < n_chunks; ++i) {
+        csize[i] = pairs[2 * i];
+        crcs[i] = pairs[2 * i + 1];
+    }
+    uint64_t total = 0;
+    for (uint64_t c : csize) {
+        if (c > file_bytes) throw std::runtime_error("index " + path + " is corrupt (chunk size)");
+        total += c;
+    }
+    if (total > file_bytes) throw std::runtime_error("index " + path + " is corrupt (chunk sizes)");
+    std::vector<char> comp(total);
+    if (total && fread(comp.data(), 1, total, f) != total) throw std::runtime_error("index file: truncated");
+    std::vector<uint64_t> at(n_chunks + 1, 0);
+    for (size_t i = 0; i < n_chunks; ++i) at[i + 1] = at[i] + csize[i];
+    parallel_for(n_chunks, [&](size_t i) {
+        const size_t o = i * CHUNK, n = std::min(CHUNK, bytes - o);
+        const size_t d = ZSTD_decompress((char *)data + o, n, comp.data() + at[i], csize[i]);
+        if (ZSTD_isError(d) || d != n || crc32(crc32(0L, Z_NULL, 0), (const Bytef *)data + o, (uInt)n) != crcs[i])
+            throw std::runtime_error("index " + path + " is corrupt (chunk " + std::to_string(i) + ")");
+    });
+}
+} // namespace hipz
+
 inline void save_index_hipz(const std::string &path, const IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits)
 {
     using namespace hipz;
-    gzFile f = gzopen(path.c_str(), "wb1");
+    zstd_check();
+    FILE *f = fopen(path.c_str(), "wb");
     if (!f) throw std::runtime_error("cannot write " + path);
     try {
-        gz_put(f, MAGIC, 8);
-        const uint64_t hdr[3] = {k, ref_k, bf_bits};
-        gz_put(f, hdr, 3);
+        const uint64_t nkeys = p.vals.size();
+        uint64_t key_bytes = 1;
+        for (uint64_t i = 0; i < nkeys; ++i) key_bytes = std::max<uint64_t>(key_bytes, strnlen(&p.rows[i * p.stride], p.stride) + 1);
+        key_bytes = std::min<uint64_t>(key_bytes, p.stride);
+        const uint64_t hdr[9] = {k, ref_k, bf_bits, p.filt[0].mode, p.filt[0].pos.size(), p.filt[1].mode, p.filt[1].pos.size(), nkeys, key_bytes};
+        if (fwrite(MAGIC3, 1, 8, f) != 8 || fwrite(hdr, 8, 9, f) != 9) throw std::runtime_error("index file: write failed");
         for (int i = 0; i < 2; ++i) {
-            const uint64_t h2[2] = {p.filt[i].mode, p.filt[i].pos.size()};
-            gz_put(f, h2, 2);
-            gz_put(f, p.filt[i].pos.data(), p.filt[i].pos.size());
-            gz_put(f, p.filt[i].cnt.data(), p.filt[i].cnt.size());
+            put_section(f, p.filt[i].pos.data(), p.filt[i].pos.size() * 8);
+            put_section(f, p.filt[i].cnt.data(), p.filt[i].cnt.size() * 2);
         }
-        const uint64_t nkeys = p.vals.size(), stride = p.stride;
-        gz_put(f, &nkeys, 1);
-        gz_put(f, &stride, 1);
-        gz_put(f, p.rows.data(), p.rows.size());
-        gz_put(f, p.vals.data(), p.vals.size());
+        std::vector<char> keys(nkeys * key_bytes, 0); // the rows without their padding up to the ABI's stride
+        parallel_for((nkeys + 65535) / 65536, [&](size_t c) {
+            for (uint64_t i = c * 65536, e = std::min<uint64_t>(nkeys, (c + 1) * 65536); i < e; ++i)
+                memcpy(&keys[i * key_bytes], &p.rows[i * p.stride], std::min<size_t>(key_bytes, p.stride));
+        });
+        put_section(f, keys.data(), keys.size());
+        put_section(f, p.vals.data(), p.vals.size() * 4);
     } catch (...) {
-        gzclose(f);
+        fclose(f);
         throw;
     }
-    if (gzclose(f) != Z_OK) throw std::runtime_error("index file: close failed");
+    if (fclose(f) != 0) throw std::runtime_error("index file: close failed");
+}
+
+inline void load_index_hipz3(const std::string &path, IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits, size_t stride)
+{
+    using namespace hipz;
+    zstd_check();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open index " + path);
+    struct stat st;
+    const uint64_t file_bytes = stat(path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+    try {
+        char magic[8];
+        uint64_t hdr[9];
+        if (fread(magic, 1, 8, f) != 8 || fread(hdr, 8, 9, f) != 9) throw std::runtime_error("index file: truncated");
+        if (memcmp(magic, MAGIC3, 8) != 0 || hdr[0] != k || hdr[1] != ref_k || hdr[2] != bf_bits)
+            throw std::runtime_error("index " + path + " was built with other -k/-r/-b");
+        // a corrupt length must not turn into a huge allocation: a filter holds fewer than 2^32 set bits (mg_bf_finalize), and no
+        // field can promise more bytes than zstd can have packed into the file
+        const uint64_t most = std::min<uint64_t>(bf_bits, 0xFFFFFFFEULL), inflated_cap = file_bytes * 4000 + (1u << 20);
+        const uint64_t nkeys = hdr[7], key_bytes = hdr[8];
+        for (int i = 0; i < 2; ++i)
+            if (hdr[3 + 2 * i] > 1 || hdr[4 + 2 * i] > most || hdr[4 + 2 * i] * 10 > inflated_cap) throw std::runtime_error("index " + path + " is corrupt (filter header)");
+        if (key_bytes == 0 || key_bytes > stride || nkeys > 0xFFFFFFFEULL || nkeys * (key_bytes + 4) > inflated_cap)
+            throw std::runtime_error("index " + path + " is corrupt (key table)");
+        for (int i = 0; i < 2; ++i) {
+            p.filt[i].mode = hdr[3 + 2 * i];
+            p.filt[i].pos.resize(hdr[4 + 2 * i]);
+            p.filt[i].cnt.resize(hdr[4 + 2 * i]);
+            get_section(f, p.filt[i].pos.data(), p.filt[i].pos.size() * 8, file_bytes, path);
+            get_section(f, p.filt[i].cnt.data(), p.filt[i].cnt.size() * 2, file_bytes, path);
+        }
+        std::vector<char> keys(nkeys * key_bytes);
+        get_section(f, keys.data(), keys.size(), file_bytes, path);
+        p.stride = stride;
+        p.rows.assign(nkeys * stride, 0);
+        p.vals.resize(nkeys);
+        parallel_for((nkeys + 65535) / 65536, [&](size_t c) {
+            for (uint64_t i = c * 65536, e = std::min<uint64_t>(nkeys, (c + 1) * 65536); i < e; ++i) {
+                memcpy(&p.rows[i * stride], &keys[i * key_bytes], key_bytes);
+                p.rows[i * stride + std::min<uint64_t>(key_bytes, stride - 1)] = 0; // (whatever the file says, a key ends inside its row)
+            }
+        });
+        get_section(f, p.vals.data(), p.vals.size() * 4, file_bytes, path);
+    } catch (...) {
+        fclose(f);
+        throw;
+    }
+    fclose(f);
 }
 
 inline void load_index_hipz(const std::string &path, IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits, size_t stride)
 {
     using namespace hipz;
-    gzFile f = gzopen(path.c_str(), "rb");
+    {
+        char magic[8] = {0};
+        FILE *probe = fopen(path.c_str(), "rb");
+        const bool v3 = probe && fread(magic, 1, 8, probe) == 8 && memcmp(magic, MAGIC3, 8) == 0;
+        if (probe) fclose(probe);
+        if (v3) return load_index_hipz3(path, p, k, ref_k, bf_bits, stride);
+    }
+    gzFile f = gzopen(path.c_str(), "rb"); // version 2: one gzip stream
     if (!f) throw std::runtime_error("cannot open index " + path);
     struct stat st;
     const uint64_t file_bytes = stat(path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;

@@ -71,3 +71,46 @@ def test_wrong_size_and_truncation_are_refused(tmp_path):
     open(zst, "wb").write(data[:len(data) // 2])
     r = run(1 << 20)
     assert r.returncode != 0 and "ERROR" in r.stderr
+
+
+def test_compact_container_versions_and_corruption(tmp_path):
+    """the compact container, version 3 (sections of independently compressed chunks): a flipped byte or a cut file is an error,
+    never a crash or a silent index; a version 2 file (one gzip stream, what earlier builds wrote) is still read"""
+    import gzip
+    import struct
+    bits = 1 << 22
+    ctx, bf, kmap = _index(bits, 3000, 11)
+    vcf = str(tmp_path / "p.vcf")
+    zst, hipz = vcf + ".c43.k35.malvax.zst", vcf + ".c43.k35.malvax.hipz"
+    index_file.write_index(zst, ctx, bf, kmap)
+    env = dict(os.environ, MALVA_GENO_BF_BITS=str(bits))
+    run = lambda fmt: subprocess.run([BIN, "index-convert", "-k", "35", "-r", "43", "x.fa", vcf, fmt], env=env, capture_output=True, text=True, timeout=600)
+    assert run("hipz").returncode == 0
+    good = open(hipz, "rb").read()
+    assert good[:8] == b"MGHIPX3\n"
+    os.remove(zst)
+    for at in (len(good) // 3, len(good) - 9, 40):                    # inside a chunk, near the end, inside the header
+        bad = bytearray(good)
+        bad[at] ^= 0x5A
+        open(hipz, "wb").write(bytes(bad))
+        r = run("zst")
+        assert r.returncode != 0 and "ERROR" in r.stderr, at
+    open(hipz, "wb").write(good[:len(good) * 2 // 3])
+    assert run("zst").returncode != 0
+    # version 2, written here from the published layout: MAGIC, k, ref_k, bits, 2 x (mode, n, pos[], cnt[]), n_keys, stride, rows, vals
+    stride = 136
+    items = sorted(kmap.items())
+    with gzip.open(hipz, "wb", compresslevel=1) as f:
+        f.write(b"MGHIPX2\n" + struct.pack("<3Q", 35, 43, bits))
+        for src in (ctx, bf):
+            pos = src.set_positions()
+            f.write(struct.pack("<2Q", 1, pos.size) + pos.astype("<u8").tobytes() + src.counts().astype("<u2").tobytes())
+        f.write(struct.pack("<2Q", len(items), stride))
+        f.write(b"".join(k_.ljust(stride, b"\0") for k_, _ in items))
+        f.write(np.array([v for _, v in items], dtype="<i4").tobytes())
+    r = run("zst")
+    assert r.returncode == 0, r.stderr
+    filters, keys = index_file.read_index(zst)
+    assert keys == dict(kmap.items())
+    for (mode, size, pos, counts), src in zip(filters, (ctx, bf)):
+        assert np.array_equal(pos, src.set_positions()) and np.array_equal(counts, src.counts())
