@@ -574,19 +574,159 @@ inline void split(std::string_view s, char sep, std::vector<std::string_view> &o
 }
 
 // The record model of variant.hpp:43-62, minus what only printing needs elsewhere.
+// A vector whose first N elements live inside the object.  A panel record's per-record containers are tiny -- one or two ALT
+// alleles, two or three frequencies and coverages, a handful of genotypes unless the panel is a large one -- and as std::vectors
+// they cost five allocations per record on the decoding thread and five frees on whichever thread drops the record: at a million
+// records a second the allocator, not the parsing, was what the host loop waited for.
+template <class T, size_t N> class SmallVec {
+    T *p_;
+    size_t n_ = 0, cap_ = N;
+    alignas(T) unsigned char buf_[N * sizeof(T)];
+    T *inline_buf() { return reinterpret_cast<T *>(buf_); }
+    bool is_inline() const { return p_ == reinterpret_cast<const T *>(buf_); }
+    void grow(size_t want)
+    {
+        size_t cap = cap_;
+        while (cap < want) cap *= 2;
+        T *q = static_cast<T *>(::operator new(cap * sizeof(T)));
+        for (size_t i = 0; i < n_; ++i) {
+            new (q + i) T(std::move(p_[i]));
+            p_[i].~T();
+        }
+        if (!is_inline()) ::operator delete(p_);
+        p_ = q;
+        cap_ = cap;
+    }
+    void take(SmallVec &&o)
+    {
+        if (o.is_inline()) {
+            p_ = inline_buf();
+            cap_ = N;
+            n_ = o.n_;
+            for (size_t i = 0; i < n_; ++i) {
+                new (p_ + i) T(std::move(o.p_[i]));
+                o.p_[i].~T();
+            }
+        } else {
+            p_ = o.p_;
+            cap_ = o.cap_;
+            n_ = o.n_;
+            o.p_ = o.inline_buf();
+            o.cap_ = N;
+        }
+        o.n_ = 0;
+    }
+
+  public:
+    typedef T value_type;
+    SmallVec() : p_(inline_buf()) {}
+    SmallVec(const SmallVec &o) : p_(inline_buf())
+    {
+        reserve(o.n_);
+        for (size_t i = 0; i < o.n_; ++i) new (p_ + i) T(o.p_[i]);
+        n_ = o.n_;
+    }
+    SmallVec(SmallVec &&o) noexcept : p_(inline_buf()) { take(std::move(o)); }
+    SmallVec &operator=(const SmallVec &o)
+    {
+        if (this != &o) {
+            clear();
+            reserve(o.n_);
+            for (size_t i = 0; i < o.n_; ++i) new (p_ + i) T(o.p_[i]);
+            n_ = o.n_;
+        }
+        return *this;
+    }
+    SmallVec &operator=(SmallVec &&o) noexcept
+    {
+        if (this != &o) {
+            clear();
+            if (!is_inline()) ::operator delete(p_);
+            take(std::move(o));
+        }
+        return *this;
+    }
+    ~SmallVec()
+    {
+        clear();
+        if (!is_inline()) ::operator delete(p_);
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    T *begin() { return p_; }
+    T *end() { return p_ + n_; }
+    const T *begin() const { return p_; }
+    const T *end() const { return p_ + n_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    T &at(size_t i)
+    {
+        if (i >= n_) throw std::out_of_range("SmallVec::at");
+        return p_[i];
+    }
+    const T &at(size_t i) const
+    {
+        if (i >= n_) throw std::out_of_range("SmallVec::at");
+        return p_[i];
+    }
+    T &back() { return p_[n_ - 1]; }
+    const T &back() const { return p_[n_ - 1]; }
+    void reserve(size_t want)
+    {
+        if (want > cap_) grow(want);
+    }
+    void clear()
+    {
+        for (size_t i = 0; i < n_; ++i) p_[i].~T();
+        n_ = 0;
+    }
+    void push_back(const T &v)
+    {
+        reserve(n_ + 1);
+        new (p_ + n_++) T(v);
+    }
+    void push_back(T &&v)
+    {
+        reserve(n_ + 1);
+        new (p_ + n_++) T(std::move(v));
+    }
+    template <class... A> T &emplace_back(A &&...a)
+    {
+        reserve(n_ + 1);
+        new (p_ + n_) T(std::forward<A>(a)...);
+        return p_[n_++];
+    }
+    void resize(size_t n)
+    {
+        reserve(n);
+        for (size_t i = n; i < n_; ++i) p_[i].~T();
+        for (size_t i = n_; i < n; ++i) new (p_ + i) T();
+        n_ = n;
+    }
+    void assign(size_t n, const T &v)
+    {
+        clear();
+        reserve(n);
+        for (size_t i = 0; i < n; ++i) new (p_ + i) T(v);
+        n_ = n;
+    }
+};
+
 struct Variant {
     std::string seq_name;
     int ref_pos = 0; // 0-based
     std::string idx;
     std::string ref_sub;
-    std::vector<std::string> alts; // symbolic <...> alleles dropped (variant.hpp:79-88)
+    SmallVec<std::string, 2> alts; // symbolic <...> alleles dropped (variant.hpp:79-88)
     float quality = NAN;
-    std::vector<std::pair<int, int>> genotypes; // per kept sample
-    std::vector<uint8_t> phasing;
+    SmallVec<std::pair<int, int>, 4> genotypes; // per kept sample
+    SmallVec<uint8_t, 8> phasing;
     int ref_size = 0, min_size = 0, max_size = 0;
     bool has_alts = true, is_present = true;
-    std::vector<float> frequencies;
-    std::vector<uint32_t> coverages;
+    SmallVec<float, 4> frequencies;
+    SmallVec<uint32_t, 4> coverages;
     // VcfReader::defer_genotypes: the sample columns are not decoded by the reader; the record says where they are (a span of
     // the block of text it was cut from, kept alive by the pointer) and the device decodes them (mg_decode_gt_text), after
     // which sp_* hold the kept samples whose genotype word is not sp_default -- the record loop's sparse layout
