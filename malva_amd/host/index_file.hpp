@@ -2,7 +2,7 @@
 //
 // Two containers, one payload (context_bf, bf, ref_bf in that order):
 //
-//   <vcf>.c<ref_k>.k<k>.malvax.zst   the reference's own: ONE zstd stream (level 5, zstdstream.h:52) holding, for each
+//   <vcf>.c<ref_k>.k<k>.malvax.zst   the reference's own: ONE zstd stream (the reference writes level 5, zstdstream.h:52) holding, for each
 //       Bloom filter, what BF::operator>> writes (bloom_filter.hpp:127-136): bool _mode, size_t _size, then the
 //       sdsl-lite v2.1.1 serialisation of bit_vector and of int_vector<16> -- each a u64 length IN BITS followed by
 //       the data as whole 64-bit words (sdsl int_vector<t_width>::serialize with t_width > 0 writes no width byte) --
@@ -65,7 +65,10 @@ class ZstdWriter {
         if (!f_) throw std::runtime_error("cannot write " + path);
         c_ = ZSTD_createCCtx();
         if (!c_) throw std::runtime_error("zstd: no context");
-        ZSTD_CCtx_setParameter(c_, ZSTD_c_compressionLevel, 5); // zstd::cstream::defaultLevel
+        // Level 1, not the reference's 5 (zstdstream.h:52): any level decodes the same way, the file is no larger on this data (a few
+        // million isolated non-zero bytes in gigabytes of zeros), and level 5's match search costs 3x the time per set bit
+        // (2e7 set bits in 8 GB: 10.6 s against 3.6 s).
+        ZSTD_CCtx_setParameter(c_, ZSTD_c_compressionLevel, 1);
         ZSTD_CCtx_setParameter(c_, ZSTD_c_nbWorkers, 4);        // same frame format; ignored by a single-threaded libzstd
     }
     ~ZstdWriter()
@@ -176,13 +179,14 @@ inline void write_bf_sdsl(ZstdWriter &w, const IndexPayload::Filter &f, uint64_t
     w.put_value<uint64_t>(size_bits);     // size_t _size
     w.put_value<uint64_t>(size_bits);     // bit_vector: length in bits, then ceil(size/64) words
     const uint64_t n_words = (size_bits + 63) / 64, chunk = 1ULL << 23; // 64 MiB of words at a time
-    std::vector<uint64_t> words;
+    std::vector<uint64_t> words(std::min(chunk, n_words), 0); // zeroed once; after each piece only the words that got a bit are cleared again
     size_t i = 0;
     for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
         const uint64_t nw = std::min(chunk, n_words - w0);
-        words.assign(nw, 0);
+        const size_t first = i;
         for (; i < f.pos.size() && f.pos[i] < (w0 + nw) * 64; ++i) words[(f.pos[i] >> 6) - w0] |= 1ULL << (f.pos[i] & 63);
         w.put(words.data(), nw * 8);
+        for (size_t j = first; j < i; ++j) words[(f.pos[j] >> 6) - w0] = 0;
     }
     // int_vector<16>: length in bits, then whole words.  In write mode the reference's _counts is empty.
     const uint64_t n = f.mode ? f.cnt.size() : 0;
@@ -234,13 +238,23 @@ inline void save_index_zst(const std::string &path, const IndexPayload &p, uint6
     write_bf_sdsl(w, p.filt[1], bf_bits);
     const uint64_t n = p.vals.size(); // KMAP::operator>>, kmap.hpp:52-64
     w.put_value<uint64_t>(n);
+    std::vector<char> buf; // (the compressor is fed megabytes at a time: three calls per key cost 4 s per 1e7 keys)
+    buf.reserve((8u << 20) + 4096);
     for (uint64_t i = 0; i < n; ++i) {
         const char *key = &p.rows[i * p.stride];
         const uint64_t len = strnlen(key, p.stride);
-        w.put_value<uint64_t>(len);
-        w.put(key, len);
-        w.put_value<int32_t>(p.vals[i]);
+        const int32_t val = p.vals[i];
+        const size_t at = buf.size();
+        buf.resize(at + 8 + len + 4);
+        memcpy(&buf[at], &len, 8);
+        memcpy(&buf[at + 8], key, len);
+        memcpy(&buf[at + 8 + len], &val, 4);
+        if (buf.size() >= (8u << 20)) {
+            w.put(buf.data(), buf.size());
+            buf.clear();
+        }
     }
+    if (!buf.empty()) w.put(buf.data(), buf.size());
     w.finish();
 }
 
