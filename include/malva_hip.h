@@ -213,7 +213,8 @@ int mg_cut_blocks(mg_ctx *ctx, size_t n_vars, const int32_t *pos, const uint32_t
  * across blocks (blk_var_off); pos is the 0-based position in the block's contig, which starts at
  * blk_ref_base in the uploaded reference and is blk_ref_len long; canon[slot] = first allele index of
  * the variant with the same text (variant.hpp:228); gt[v * n_samples + s] = a1 | a2 << 7 | phased << 14
- * for the kept panel samples (variant.hpp:158-211).  cov_out as in mg_lookup_cover, one slot per
+ * for the kept panel samples (variant.hpp:158-211); a1 and a2 are below the record's allele count (the reference
+ * reads out of bounds otherwise; the library does not check: its caller's reader does).  cov_out as in mg_lookup_cover, one slot per
  * (variant, allele).  overflow_out[v] = 1 where a fixed device capacity (16 chains per side, 32 members per
  * chain side, 14 unphased members, 127 alleles, k <= 64) or a window clipped by a contig end was hit: redo
  * that variant's block through the host enumerator + mg_lookup_cover. */
