@@ -734,7 +734,8 @@ def main():
                 "overflow_records": n_ovf, "parity_sample": par, "cpu_variants_per_s": cpu and cpu["variants_per_s"], "config": rec["config"]["workload"]}
             lj.close()
         out["general_blocks_c5"] = leg
-    if world > 1 and args.workload == "c3" and not args.no_strong_c4 and not args.rehearse_on_one_gpu:
+    # (under --rehearse-on-one-gpu the leg runs only at explicitly reduced sizes: N whole-genome indexes do not share one GPU)
+    if world > 1 and args.workload == "c3" and not args.no_strong_c4 and (not args.rehearse_on_one_gpu or args.strong_c4_kmers < 1e9):
         # north_star's whole-genome claim on the same ranks: the 3e9-row table cut N ways against the 8e7-SNP index
         ref1 = None
         p1 = os.path.join(ROOT, "profiles", "r03_bench_c4_whole_1gpu.json")
@@ -752,7 +753,8 @@ def main():
                 srec = record(sj, el, st, 1, skt, None)
                 out["strong_c4"] = {k_: srec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_blocks")}
                 out["strong_c4"]["overflow_records"] = n_ovf
-                if ref1:
+                same_job = (args.strong_c4_kmers, args.strong_c4_variants) == (3e9, 8e7) and not args.rehearse_on_one_gpu
+                if ref1 and same_job:      # (a reduced or rehearsed leg has no one-GPU line to be compared with)
                     out["strong_c4"]["one_gpu_reference"] = {"file": os.path.relpath(p1, ROOT), "ms_per_step": ref1["ms_per_step"],
                                                              "same_panel_recipe": "r03" in os.path.basename(p1)}
                     out["strong_c4"]["speedup_vs_one_gpu"] = ref1["ms_per_step"] / srec["ms_per_step"]
