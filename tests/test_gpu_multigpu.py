@@ -205,7 +205,8 @@ def test_context_before_torch_import_then_shared_stream(tmp_path):
     assert r.returncode == 0 and "ORDER_OK" in r.stdout, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("workload,extra", [("c3", ["--kmers", "2e6", "--variants", "2e4"]), ("c5", ["--kmers", "1e6", "--clusters", "3e3"])])
+@pytest.mark.parametrize("workload,extra", [("c3", ["--kmers", "2e6", "--variants", "2e4", "--strong-c4-kmers", "4e6", "--strong-c4-variants", "3e5"]),
+                                            ("c5", ["--kmers", "1e6", "--clusters", "3e3"])])
 def test_bench_self_launch_two_ranks_on_one_gpu(workload, extra):
     """plain `python bench.py --gpus 2` (no launcher): the ranks are started by bench.py itself; on a one-GPU box they share
     the device and reduce over gloo (--rehearse-on-one-gpu).  ONE JSON line comes out, for two ranks, with the table rows and
@@ -225,3 +226,8 @@ def test_bench_self_launch_two_ranks_on_one_gpu(workload, extra):
     assert d["config"]["kmers_total"] == 2 * d["config"]["kmers_per_gpu"]
     assert d["config"]["variants_genotyped_per_gpu"] < d["config"]["panel_variants"]
     assert d["overflow_records"] == 0
+    if workload == "c3":       # the whole-genome leg every N > 1 line of the default workload carries, here at a reduced size
+        s4 = d["strong_c4"]
+        assert "error" not in s4, s4
+        assert s4["n_gpus"] == 2 and s4["scaling"] == "strong" and s4["overflow_records"] == 0 and s4["kernels_ms"]["general_records"] > 1000
+        assert "speedup_vs_one_gpu" not in s4
