@@ -80,7 +80,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[3], s_misc[8], s_blk[13], s_gt[10], s_scan;
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[4], s_misc[8], s_blk[13], s_gt[10], s_scan;
     void *h_gt_stage = nullptr;                       // pinned staging for mg_decode_gt_text's text (a pageable source is copied by the runtime in small synchronous pieces)
     size_t h_gt_stage_cap = 0;
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
@@ -98,6 +98,7 @@ struct mg_ctx {
     bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
     u32 rec_epoch = 1;
     int blocks_round_log2 = 24;                // see blocks_setup
+    int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
@@ -659,6 +660,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "map_dense")) c->map_dense = value != 0;
     else if (!strcmp(name, "use_packed_pool")) c->use_packed_pool = value != 0;
     else if (!strcmp(name, "use_snp_chains")) c->use_snp_chains = value != 0;
+    else if (!strcmp(name, "use_hit_entries")) c->use_hit_entries = value != 0;
     else if (!strcmp(name, "blocks_round_log2")) {
         if (value < 10 || value > 24) return fail(c, MG_ERR_ARG, "blocks_round_log2: 10..24");
         c->blocks_round_log2 = (int)value;
@@ -722,6 +724,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "map_dense")) *value = c->map_dense;
     else if (!strcmp(name, "use_packed_pool")) *value = c->use_packed_pool;
     else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
+    else if (!strcmp(name, "use_hit_entries")) *value = c->use_hit_entries;
     else if (!strcmp(name, "blocks_round_log2")) *value = c->blocks_round_log2;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
     else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
@@ -1270,7 +1273,12 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
     for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
-    const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    if (c->use_hit_entries && c->map.cap_log2 <= 30) { // (record * 2 + entry in 32 bits)
+        void *pa;
+        TRY(scratch(c, c->s_hit[3], cap * 8, &pa));
+        hits.aux = (u64 *)pa;
+    }
     c->stats_valid = false;
     // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
     BinSet bins{};
@@ -1385,7 +1393,12 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
     for (int i = 0; i < 6; ++i) TRY(scratch(c, *sc[i], cap * (i % 3 == 2 ? 4 : 8), &p[i]));
-    const RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    RowList open{(u64 *)p[0], (u64 *)p[1], (u32 *)p[2]}, hits{(u64 *)p[3], (u64 *)p[4], (u32 *)p[5]};
+    if (c->use_hit_entries && c->map.cap_log2 <= 30) { // (record * 2 + entry in 32 bits)
+        void *pa;
+        TRY(scratch(c, c->s_hit[3], cap * 8, &pa));
+        hits.aux = (u64 *)pa;
+    }
     TicketSet tks{};
     if (tickets) TRY(ticket_layout(c, cap, row_bits, &tks));
     c->stats_valid = false;

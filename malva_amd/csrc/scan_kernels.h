@@ -221,14 +221,16 @@ __global__ void __launch_bounds__(TPB) ref_scan_packed_kernel(const u64 *__restr
 struct RowList {
     u64 *hi, *lo;
     u32 *cnt;
+    u64 *aux = nullptr; // the hit list only: what the probe kernel knew of the row's filter entry (counter index | record * 2 + entry << 32)
 };
 template <int CAP> struct BlockStage {
     u64 *hi, *lo; // [CAP]
     u32 *cnt;     // [CAP]
     u32 *n;       // entries staged
     unsigned long long *base;
+    u64 *aux = nullptr; // [CAP], staged beside the rows where the list takes it
     // every lane of the wave must call this (it ballots)
-    __device__ __forceinline__ void push(bool take, U128 m, u32 count)
+    __device__ __forceinline__ void push(bool take, U128 m, u32 count, u64 extra = 0)
     {
         const u64 mask = __ballot(take);
         if (!mask) return;
@@ -241,6 +243,7 @@ template <int CAP> struct BlockStage {
             lo[q] = m.lo;
             hi[q] = m.hi;
             cnt[q] = count;
+            if (aux) aux[q] = extra;
         }
     }
     // every thread of the workgroup must call this; flushes when more than `keep` entries are staged
@@ -258,6 +261,7 @@ template <int CAP> struct BlockStage {
                     g.lo[b + j] = lo[j];
                 }
                 g.cnt[b + j] = cnt[j];
+                if (aux && g.aux) g.aux[b + j] = aux[j];
             }
             __syncthreads();
             if (threadIdx.x == 0) *n = 0;
@@ -972,7 +976,8 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
     __shared__ u32 sh_cnt[CAP];
     __shared__ u32 sh_n;
     __shared__ unsigned long long sh_base;
-    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base};
+    __shared__ u64 sh_aux[CAP];
+    BlockStage<CAP> st{sh_hi, sh_lo, sh_cnt, &sh_n, &sh_base, hits.aux ? sh_aux : (u64 *)nullptr};
     __shared__ u32 sh_lut[256];
     ascii_lut_fill(sh_lut);
     if (threadIdx.x == 0) sh_n = 0;
@@ -986,6 +991,7 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         bool hit = false;
         U128 m{0, 0};
         u32 count = 0;
+        u64 extra = 0;
         if (j < n_open) {
             count = open.cnt[j];
             if (rows12) { // ticket form over compact rows: the list holds row numbers, a row is 12 contiguous bytes (one line, now and then two)
@@ -1009,15 +1015,16 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
             long long id, rank; // one record answers both: exact-map key?  bit idx of bf set?
-            u64 slot = 0;
-            bucket_probe_coop(map, c, h, idx, live, &id, &rank, &slot); // (whole waves: the records are fetched four lanes to a record)
+            u64 slot = 0, ent = 0;
+            bucket_probe_coop(map, c, h, idx, live, &id, &rank, &slot, &ent); // (whole waves: the records are fetched four lanes to a record)
             if (id >= 0) {
                 atomicAdd(&map.vals[id], count); // ref_bf.increment (main.cpp:495)
                 if (map.epoch) rec_add_val(&map.slots[slot], map.epoch, count); // ... and the record's copy, on the line just read
             }
             hit = rank >= 0;
+            extra = (u64)(u32)rank | ent << 32; // (the hit kernel need not find the entry again)
         }
-        st.push(hit, m, count);
+        st.push(hit, m, count, extra);
         st.flush_if_above(CAP - TPB, hits, &counters[1]);
     }
     st.flush_if_above(0, hits, &counters[1]);
@@ -1040,6 +1047,15 @@ __global__ void __launch_bounds__(TPB) scan_hits_kernel(int k_rt, int r_rt, BFVi
         const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
         // (the centre k-mer's slot and its record are computed and requested before the context bit is looked at:
         // both random reads are in flight together)
+        if (hits.aux) { // the probe kernel left the entry with the row: no second hash, no second walk to the record
+            const bool in_ctx = live && bf_bit_via_set(ctx, cidx);        // context_bf.test_key (main.cpp:496)
+            if (live && !in_ctx) {
+                const u64 x = hits.aux[j];
+                atomicAdd(&bf.counts[(u32)x], hits.cnt[j]);               // bf.increment (main.cpp:498)
+                if (map.epoch) rec_add_bf(&map.slots[(x >> 32) >> 1], (int)((x >> 32) & 1), map.epoch, hits.cnt[j]);
+            }
+            continue;
+        }
         const u64 idx = mod_size(xxh3_packed_k<KC>(canon_sub(m, l, r, off, k), k), bf.mod);
         const bool in_ctx = live && bf_bit_via_set(ctx, cidx);            // context_bf.test_key (main.cpp:496)
         u64 ent = 0;
