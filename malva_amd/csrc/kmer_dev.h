@@ -338,6 +338,7 @@ struct MapView {
     u32 cap_log2;
     u32 klen;  // every key held here is exactly this long (other lengths live in the host overflow list)
     u32 epoch; // != 0: the records' counter copies of this epoch are current (single GPU, every increment since the reset made by the scan)
+    u32 lazy;  // (epoch != 0 only) the scan adds to the records' copies ALONE: vals[] / counts[] catch up when somebody asks for them (rec_collect_kernel)
     u64 home_mul; // see map_home
 };
 // the scan's side of the copies: add `c` to the record's counter of the current epoch (a word of an older epoch restarts at zero)
@@ -348,6 +349,28 @@ __device__ __forceinline__ void rec_add_val(MapSlot *rec, u32 epoch, u32 c)
         const u32 cur = (u32)(old >> 32) == epoch ? (u32)old : 0u;
         const unsigned long long nw = (unsigned long long)epoch << 32 | (u32)(cur + c);
         const unsigned long long prev = atomicCAS(&rec->cval, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+// (`old`: what the caller last read of the word -- the first compare-and-swap needs no load of its own)
+__device__ __forceinline__ void rec_add_val_from(MapSlot *rec, u32 epoch, u32 c, unsigned long long old)
+{
+    for (;;) {
+        const u32 cur = (u32)(old >> 32) == epoch ? (u32)old : 0u;
+        const unsigned long long nw = (unsigned long long)epoch << 32 | (u32)(cur + c);
+        const unsigned long long prev = atomicCAS(&rec->cval, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+__device__ __forceinline__ void rec_add_bf_from(MapSlot *rec, int j, u32 epoch, u32 c, unsigned long long old)
+{
+    for (;;) {
+        const u32 cur = (u32)(old >> 32) == epoch ? (u32)old : 0u;
+        const u32 half = ((cur >> (16 * j)) + c) & 0xFFFFu;
+        const unsigned long long nw = (unsigned long long)epoch << 32 | ((cur & ~(0xFFFFu << (16 * j))) | half << (16 * j));
+        const unsigned long long prev = atomicCAS(&rec->cbf, old, nw);
         if (prev == old) return;
         old = prev;
     }
@@ -484,6 +507,38 @@ __device__ __forceinline__ void records_load_coop(const MapView &m, u64 s, bool 
     *a = ra;
     *b = rb;
     *c = rc;
+}
+// the same, whole records: the fourth 16 bytes (the record's counter copies, cval | cbf) come with the others -- the lane that sat idle
+// in each group of four fetches them -- so that a scan kernel can compare-and-swap a copy without reading it first
+__device__ __forceinline__ void records_load_coop4(const MapView &m, u64 s, bool active, uint4 *a, uint4 *b, uint4 *c, uint4 *d)
+{
+    const int lane = threadIdx.x & 63;
+    const int part = lane & 3, q = lane >> 2;
+    uint4 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { // all four rounds' loads are requested before any is used
+        const int src = 16 * t + q; // the lane whose record this lane helps fetch in round t
+        const u32 lo = (u32)__shfl((int)(u32)s, src, 64), hi = (u32)__shfl((int)(u32)(s >> 32), src, 64);
+        const bool act = __shfl((int)active, src, 64) != 0;
+        v[t] = uint4{0u, 0u, 0u, 0u};
+        if (act) v[t] = reinterpret_cast<const uint4 *>(&m.slots[(u64)lo | ((u64)hi << 32)])[part];
+    }
+    uint4 ra{0u, 0u, 0u, 0u}, rb = ra, rc = ra, rd = ra;
+    const int mine = 4 * (lane & 15); // as an owner: my record's parts sit in lanes mine .. mine + 3 of round lane / 16
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint4 p0 = shfl_u4(v[t], mine), p1 = shfl_u4(v[t], mine + 1), p2 = shfl_u4(v[t], mine + 2), p3 = shfl_u4(v[t], mine + 3);
+        if ((lane >> 4) == t) {
+            ra = p0;
+            rb = p1;
+            rc = p2;
+            rd = p3;
+        }
+    }
+    *a = ra;
+    *b = rb;
+    *c = rc;
+    *d = rd;
 }
 // bucket_probe with the home records fetched cooperatively (every lane of the wave calls it; `active` = the lane has a row)
 // map_slot / bf_ent (may be NULL): the record that held the key, and record * 2 + entry of the filter bit -- where the scan keeps the counters' copies

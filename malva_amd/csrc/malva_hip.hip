@@ -95,6 +95,12 @@ struct mg_ctx {
     // drops rec_ok on entry unless it is one of those that cannot change a counter behind the copies' back (DeviceGuard, KEEP).
     int use_record_counters = 1;
     mutable bool rec_ok = false;
+    // lazy vectors: scans of the sub-slice form add to the records' copies alone while those are current (MapView::lazy); whoever
+    // needs vals[] / counts[] afterwards -- an export, a per-k-mer call, an exchange, anything that ends the copies' validity --
+    // first brings them up to date (vectors_current: one pass over the record table).  vec_zero: the vectors are known to be all
+    // zero (mg_counters_reset then has nothing to clear: 0.7 GB per step at whole-genome scale)
+    int lazy_vectors = 1;
+    mutable bool vec_stale = false, vec_zero = false;
     bool rec_off = false;                      // the counter vector has been handed out (mg_counters_view): whoever holds it may write it
     u32 rec_epoch = 1;
     int blocks_round_log2 = 24;                // see blocks_setup
@@ -113,7 +119,9 @@ struct mg_ctx {
     size_t ref_len = 0;
     u64 *d_ref2 = nullptr;   // the same reference as 2-bit codes (ref_pack_kernel) ...
     u32 *d_refbad = nullptr; // ... and one bit per base: not ACGT
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // scan timing (mg_scan_stats): four events per launch group (chunk) of the most recent scan, the first SCAN_EV_CHUNKS of them
+    std::vector<hipEvent_t> ev;
+    std::vector<u64> ev_rows; // rows of each timed chunk
     bool stats_valid = false;
     u32 *joined = nullptr; // when set: one allocation holding [bf counters | map counters] (mg_counters_view)
     int use_summary = 1;
@@ -139,6 +147,18 @@ struct mg_ctx {
                               // 16 MiB gate 3.6 ms two-level direct / 4.8 tickets; 32 MiB 7.7 / 6.2; 256 MiB 9.3 / 7.3 (profiles/r02_c4share_forms.txt)
     Scratch s_tk[2];
     unsigned long long *d_tk_meta = nullptr; // spill count, then u32 [TK_MAXP][BIN_SEGS] segment fills
+    // the sub-slice form (scan_sub_sort_kernel + scan_sub_gate_kernel): tickets filed under LDS-sized pieces of the gate
+    int use_sub = 1;          // gates of 2^sub_min_log2 bits and more (takes precedence over the ticket form; 0: A/B)
+    int sub_min_log2 = 28;    // smallest fine gate (log2 bits) that takes it
+    int sub_words_log2 = SB_WORDS_LOG2; // gate words per sub-slice (tests shrink it to put many bins into a small gate)
+    int sub_bins_log2 = 10;   // the gate is sized (at finalize) to split into at most 2^sub_bins_log2 sub-slices (<= SB_MAXB).  Measured at one GPU's share of
+                              // C4: 2,048 pieces (a 256 MiB gate, ~0.5 % false positives) leave pass one in runs of 8 tickets = 64 B and cost its stores and pass
+                              // two 0.5 ms per 2^27 rows more than 1,024 pieces (128 MiB, ~4 %) cost the probe kernel (0.23 ms)
+    int sub_split = 4;        // workgroups of the probe kernel per region of open rows
+    int sub_grid = 0;         // pass one's grid (0: one workgroup per CU)
+    int n_cus = 0;            // CUs of the device (found at first use)
+    Scratch s_sb[4];          // tickets, spill list, open tickets, meta block (spill count, region counts, segment fills)
+    int last_subs = 0;        // bins the most recent scan filed tickets under (0: it did not take this form)
     int bin_ring = 0, bin_rows = 4; // A/B: staging ring per bin (0 = as large as LDS allows), rows per thread of the binning kernel
     u64 bin_cap = 0;       // rows per bin segment; 0 = 1.5x an even share of the chunk (tests set it small to reach the spill path)
     int last_bins = 0;     // bins used by the most recent scan (0: direct form)
@@ -284,6 +304,7 @@ MapView view(const mg_ctx *c)
     v.klen = c->k;
     v.home_mul = c->map_ordered ? ~0ULL / c->bf[MG_BF_ALT].mod.size : 0x9E3779B97F4A7C15ULL;
     v.epoch = c->rec_ok && records_wanted(c) ? c->rec_epoch : 0;
+    v.lazy = v.epoch && c->lazy_vectors ? 1u : 0u;
     return v;
 }
 
@@ -510,14 +531,30 @@ int fill_geno_params(mg_ctx *c, float error_rate, int max_cov, int haploid, Geno
 
 // Every entry point may be called from any host thread: make the context's device current for the calling thread
 // (HIP's current device is per thread; a thread that never called hipSetDevice sits on device 0).
-constexpr bool KEEP = true; // for DeviceGuard: this entry point leaves the counters alone, or changes them together with the records' copies
+// for DeviceGuard.  KEEP: this entry point leaves the counters alone, or changes them together with the records' copies (it may READ the
+// vectors: they are brought up to date first).  LAZY: the same, and it never looks at vals[] / counts[] while the copies are current
+// (the scans, the record loop's device forms, the bookkeeping calls): lazy vectors stay lazy.
+constexpr int KEEP = 1, LAZY = 2;
+// vals[] / counts[] from the records' copies, where scans have added to the copies alone
+void vectors_current(const mg_ctx *c)
+{
+    if (!c->vec_stale) return;
+    c->vec_stale = false;
+    c->vec_zero = false;
+    if (!c->map.slots || !c->rec_ok) return; // (cannot happen: lazy scans need current copies, and nothing drops them without coming through here)
+    MapView m = view(c);
+    m.epoch = c->rec_epoch;
+    hipLaunchKernelGGL(rec_collect_kernel, dim3((unsigned)std::min<u64>(nblocks(1ULL << m.cap_log2), 1u << 20)), dim3(TPB), 0, c->stream, m,
+                       c->bf[MG_BF_ALT].mode ? c->bf[MG_BF_ALT].counts : (u32 *)nullptr, c->rec_epoch);
+}
 struct DeviceGuard {
     int prev = -1;
-    explicit DeviceGuard(const mg_ctx *c, bool keeps_record_counters = false)
+    explicit DeviceGuard(const mg_ctx *c, int keeps_record_counters = 0)
     {
-        if (c && !keeps_record_counters) c->rec_ok = false;
         int cur = -1;
         if (c && hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
+        if (c && keeps_record_counters != LAZY) vectors_current(c);
+        if (c && !keeps_record_counters) c->rec_ok = false, c->vec_zero = false;
     }
     ~DeviceGuard()
     {
@@ -610,6 +647,7 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipFree(c->d_bin_meta);
     hipFree(c->d_tk_meta);
     for (auto &q : c->s_tk) hipFree(q.p);
+    for (auto &q : c->s_sb) hipFree(q.p);
     for (auto &s : c->s_hit) hipFree(s.p);
     for (auto &s : c->s_misc) hipFree(s.p);
     for (auto &s : c->s_blk) hipFree(s.p);
@@ -633,7 +671,7 @@ MG_EXPORT const char *mg_last_error(const mg_ctx *c) { return c ? c->err.c_str()
 
 MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -641,7 +679,7 @@ MG_EXPORT int mg_set_stream(mg_ctx *c, void *s)
 }
 MG_EXPORT int mg_synchronize(mg_ctx *c)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MG_OK;
@@ -680,6 +718,15 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_packed_ref_scan")) c->use_packed_ref_scan = value != 0;
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
+    else if (!strcmp(name, "use_sub")) c->use_sub = value != 0;
+    else if (!strcmp(name, "lazy_vectors")) c->lazy_vectors = value != 0;
+    else if (!strcmp(name, "sub_min_log2")) c->sub_min_log2 = (int)value;
+    else if (!strcmp(name, "sub_words_log2")) {
+        if (value < 0 || value > SB_WORDS_LOG2) return fail(c, MG_ERR_ARG, "sub_words_log2 must be 0..%d", SB_WORDS_LOG2);
+        c->sub_words_log2 = (int)value;
+    } else if (!strcmp(name, "sub_bins_log2")) c->sub_bins_log2 = (int)std::max<int64_t>(1, std::min<int64_t>(10, value));
+    else if (!strcmp(name, "sub_split")) c->sub_split = (int)std::max<int64_t>(1, std::min<int64_t>(64, value));
+    else if (!strcmp(name, "sub_grid")) c->sub_grid = (int)std::max<int64_t>(0, std::min<int64_t>(4096, value));
     else if (!strcmp(name, "ticket_min_log2")) c->ticket_min_log2 = (int)value;
     else if (!strcmp(name, "scan_chunk_log2")) c->chunk_log2 = (int)std::min<int64_t>(27, std::max<int64_t>(10, value));
     else if (!strcmp(name, "ticket_gate_grid")) c->tkg_grid = value > 0 ? (int)std::max<int64_t>(8, std::min<int64_t>(4096, value / 8 * 8)) : 0;
@@ -715,7 +762,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
 
 MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c || !name || !value) return MG_ERR_ARG;
     if (!strcmp(name, "use_summary")) *value = c->use_summary;
     else if (!strcmp(name, "use_pregate")) *value = c->use_pregate;
@@ -738,13 +785,17 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "pregate_k")) *value = c->bf[MG_BF_ALT].pregate && pregate_on(c) ? c->pre_k : 0;
     else if (!strcmp(name, "scan_bins")) *value = c->last_bins;
     else if (!strcmp(name, "scan_tickets")) *value = c->last_tickets;
+    else if (!strcmp(name, "scan_subs")) *value = c->last_subs;
+    else if (!strcmp(name, "use_sub")) *value = c->use_sub;
+    else if (!strcmp(name, "lazy_vectors")) *value = c->lazy_vectors;
+    else if (!strcmp(name, "vectors_stale")) *value = c->vec_stale;
     else if (!strcmp(name, "ticket_gate_grid")) *value = c->tkg_grid;
     else if (!strcmp(name, "use_tickets")) *value = c->use_tickets;
     else if (!strcmp(name, "scan_spilled")) { // rows of the last chunk that took the spill list
         unsigned long long t = 0;
-        if (c->last_bins || c->last_tickets) {
+        if (c->last_bins || c->last_tickets || c->last_subs) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, hipMemcpy(&t, c->last_tickets ? c->d_tk_meta : c->d_bin_meta, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&t, c->last_subs ? c->s_sb[3].p : c->last_tickets ? (void *)c->d_tk_meta : (void *)c->d_bin_meta, 8, hipMemcpyDeviceToHost));
         }
         *value = (int64_t)t;
     }
@@ -823,6 +874,9 @@ MG_EXPORT int mg_bf_finalize(mg_ctx *c, int which)
         int want = 25;
         while (want < 34 && (1ULL << want) < 12 * entries) ++want;
         while (want > 6 && (1ULL << want) > b.size) --want;
+        // an index that takes the sub-slice form (tickets filed under LDS-sized pieces of the gate) keeps its gate within
+        // 2^sub_bins_log2 <= SB_MAXB pieces: 256 MiB at full-size pieces
+        if (c->use_summary && c->use_sub && want >= c->sub_min_log2) want = std::min(want, c->sub_words_log2 + 6 + c->sub_bins_log2);
         // coarse gate: the bits per entry that minimise its false-positive rate at this load (ln 2 * bits / entries)
         int pk = entries ? (int)std::lround(0.6931 * (double)(1ULL << c->pregate_log2) / (double)entries) : 4;
         pk = pk < 1 ? 1 : pk > 4 ? 4 : pk;
@@ -873,7 +927,7 @@ MG_EXPORT int mg_bf_get_count(mg_ctx *c, int which, const char *rows, size_t str
 }
 MG_EXPORT int mg_bf_info(mg_ctx *c, int which, uint64_t *size_bits, uint64_t *n_set, int *mode)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     TRY(check_which(c, which));
     if (size_bits) *size_bits = c->bf[which].size;
     if (n_set) *n_set = c->bf[which].nset;
@@ -986,7 +1040,7 @@ int map_dump(mg_ctx *c, std::vector<u64> *klo, std::vector<u64> *khi, std::vecto
 
 MG_EXPORT int mg_map_size(mg_ctx *c, uint64_t *n_keys)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c || !n_keys) return MG_ERR_ARG;
     std::vector<u64> a, b;
     std::vector<u32> ids;
@@ -1105,11 +1159,12 @@ namespace {
 int records_current(mg_ctx *c)
 {
     if (!records_wanted(c)) {
+        vectors_current(c);
         c->rec_ok = false;
         return MG_OK;
     }
     if (c->rec_ok || !c->map.slots) return MG_OK;
-    ++c->rec_epoch;
+    if (++c->rec_epoch == 0) c->rec_epoch = 1; // (0 means "no copies"; the pass below rewrites every record that holds anything, so no older epoch survives it)
     MapView m = view(c);
     hipLaunchKernelGGL(rec_publish_kernel, dim3((unsigned)std::min<u64>(nblocks(1ULL << m.cap_log2), 1u << 20)), dim3(TPB), 0, c->stream, m,
                        (const u32 *)(c->bf[MG_BF_ALT].mode ? c->bf[MG_BF_ALT].counts : nullptr), c->rec_epoch);
@@ -1175,6 +1230,127 @@ int ticket_layout(mg_ctx *c, u64 cap, u32 row_bits, TicketSet *out)
     *out = tks;
     return MG_OK;
 }
+// ---- the sub-slice form's host side ---------------------------------------------------------------------------------------
+constexpr int SCAN_EV_CHUNKS = 64; // launch groups of one scan whose kernels are timed (mg_scan_stats)
+int device_cus(mg_ctx *c)
+{
+    if (!c->n_cus) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) cus = 256;
+        c->n_cus = cus;
+    }
+    return c->n_cus;
+}
+u64 sub_bins(const mg_ctx *c) // LDS-sized pieces (2^sub_words_log2 words) the fine gate splits into
+{
+    const u64 nwords = (c->bf[MG_BF_ALT].n_gate_bits + 63) / 64;
+    return (nwords + (1ULL << c->sub_words_log2) - 1) >> c->sub_words_log2;
+}
+// does this index take the sub-slice form?  *row_bits as in ticket_form
+bool sub_form(mg_ctx *c, u32 *row_bits)
+{
+    const BFState &alt = c->bf[MG_BF_ALT];
+    u32 idx_bits = 1;
+    while (idx_bits < 64 && (alt.size - 1) >> idx_bits) ++idx_bits;
+    *row_bits = std::min<u32>(27, 64 - idx_bits);
+    const u64 NB = sub_bins(c);
+    return c->use_summary && c->use_sub && alt.gate && c->gate_log2 >= c->sub_min_log2 && NB >= 2 && NB <= (u64)SB_MAXB && idx_bits <= 44 &&
+           c->sub_words_log2 >= 0 && c->sub_words_log2 <= SB_WORDS_LOG2;
+}
+// what one launch group of the sub-slice form works in: pass one / two's segments and regions, the probe kernel's hit regions
+struct SubPlan {
+    SubSet ss{};
+    u32 split = 1;
+};
+// segments, regions and meta block for launch groups of up to `cap` rows
+int sub_layout(mg_ctx *c, u64 cap, u32 row_bits, SubPlan *plan)
+{
+    SubSet *out = &plan->ss;
+    const BFState &alt = c->bf[MG_BF_ALT];
+    SubSet ss{};
+    const u64 NB = sub_bins(c);
+    const int cus = device_cus(c);
+    ss.nbins = (u32)NB;
+    ss.words_log2 = (u32)c->sub_words_log2;
+    ss.bin_shift = alt.gate_shift + 6 + ss.words_log2;
+    ss.row_bits = row_bits;
+    ss.n_gate_words = (alt.n_gate_bits + 63) / 64;
+    const u64 tiles = (cap + SB_TILE - 1) / SB_TILE;
+    ss.nseg = (u32)std::min<u64>(tiles, (u64)(c->sub_grid > 0 ? c->sub_grid : cus));
+    const u64 wg_rows = (tiles + ss.nseg - 1) / ss.nseg * SB_TILE; // a workgroup takes whole tiles
+    ss.segcap = c->bin_cap ? c->bin_cap : ((wg_rows / NB) * 3 / 2 + 64 + 15) / 16 * 16; // 1.5x an even share, whole 128-byte lines
+    ss.parts = (u32)std::max<u64>(1, std::min<u64>(std::min<u64>(8, ss.nseg), (u64)cus / NB)); // bins fewer than CUs: several workgroups share one
+    const u64 spp = (ss.nseg + ss.parts - 1) / ss.parts, units = NB * ss.parts;
+    ss.ucap = spp * ss.segcap;
+    plan->split = (u32)std::max(1, c->sub_split);
+    void *q[4];
+    TRY(scratch(c, c->s_sb[0], NB * ss.nseg * ss.segcap * 8, &q[0]));
+    TRY(scratch(c, c->s_sb[1], cap * 8, &q[1]));
+    TRY(scratch(c, c->s_sb[2], (units * ss.ucap + cap) * 8, &q[2]));
+    const size_t head = (8 + (units + 1) * 4 + 15) / 16 * 16;
+    TRY(scratch(c, c->s_sb[3], head + NB * ss.nseg * 4, &q[3]));
+    ss.tickets = (u64 *)q[0];
+    ss.spill = (u64 *)q[1];
+    ss.out_tk = (u64 *)q[2];
+    ss.spill_count = (unsigned long long *)q[3];
+    ss.out_counts = (u32 *)((char *)q[3] + 8);
+    ss.counts = (u32 *)((char *)q[3] + head);
+    ss.ablate = (u32)c->scan_ablate >> 8; // (timing-only diagnostic of pass one: scan_ablate 256)
+    *out = ss;
+    return MG_OK;
+}
+// bytes of the meta block's head that every launch group starts from zero: the spill count and the regions' counts
+size_t sub_meta_head(const SubSet &ss) { return 8 + ((size_t)ss.nbins * ss.parts + 1) * 4; }
+// the four events of launch group `chunk` of the running scan (created on first use); nullptr beyond SCAN_EV_CHUNKS
+hipEvent_t *scan_events(mg_ctx *c, u64 chunk, u64 rows)
+{
+    if (chunk >= (u64)SCAN_EV_CHUNKS) return nullptr;
+    while (c->ev.size() < 4 * (chunk + 1)) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev.push_back(e);
+    }
+    if (c->ev_rows.size() <= chunk) c->ev_rows.resize(chunk + 1);
+    c->ev_rows[chunk] = rows;
+    return c->ev.data() + 4 * chunk;
+}
+template <int KC, int RC>
+void launch_sub_passes(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *rows12, u64 n, const SubSet &layout)
+{
+    SubSet ss = layout;
+    ss.nseg = (u32)std::min<u64>((n + SB_TILE - 1) / SB_TILE, layout.nseg); // (regions and segments stay as laid out: a smaller grid fills fewer of them)
+    const BFView alt = view(c, MG_BF_ALT);
+if (rows12) hipLaunchKernelGGL((scan_sub_sort_kernel<KC, RC, true>), dim3(ss.nseg), dim3(SB_TPB), 0, c->stream, d_hi, d_lo, rows12, n, (int)c->k, (int)c->ref_k, alt, ss);
+    else hipLaunchKernelGGL((scan_sub_sort_kernel<KC, RC, false>), dim3(ss.nseg), dim3(SB_TPB), 0, c->stream, d_hi, d_lo, rows12, n, (int)c->k, (int)c->ref_k, alt, ss);
+    const unsigned units = ss.nbins * ss.parts;
+    const unsigned grid = std::min<unsigned>(units, (unsigned)device_cus(c));
+    if (c->gate_k == 4) hipLaunchKernelGGL(scan_sub_gate_kernel<4>, dim3(grid), dim3(SB_TPB), 0, c->stream, alt, ss);
+    else hipLaunchKernelGGL(scan_sub_gate_kernel<0>, dim3(grid), dim3(SB_TPB), 0, c->stream, alt, ss);
+    hipLaunchKernelGGL(sub_total_kernel, dim3(1), dim3(SB_TPB), 0, c->stream, (const u32 *)ss.out_counts, units + 1, c->d_hit_count);
+}
+SubOpen sub_open(const SubPlan *plan)
+{
+    SubOpen r{};
+    const SubSet *ss = &plan->ss;
+    r.counts = ss->out_counts;
+    r.tickets = ss->out_tk;
+    r.ucap = ss->ucap;
+    r.n_units = ss->nbins * ss->parts + 1;
+    r.split = plan->split;
+    r.row_bits = ss->row_bits;
+    return r;
+}
+// the probe kernel of the sub-slice form (which is its hit pass too) over one launch group (ev: its four events, or NULL)
+template <int KC, int RC>
+void launch_sub_tail(mg_ctx *c, const SubPlan *plan, hipEvent_t *ev, const u32 *d_cnt, const u64 *d_hi, const u64 *d_lo, const u32 *rows12)
+{
+    const SubOpen so = sub_open(plan);
+    const unsigned pgrid = std::min<unsigned>(so.n_units * so.split, 2 * (unsigned)c->probe_grid);
+    hipLaunchKernelGGL((scan_sub_probe_kernel<KC, RC>), dim3(pgrid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), so,
+                       c->d_hit_count, d_cnt, d_hi, d_lo, rows12);
+    if (ev) hipEventRecord(ev[2], c->stream);
+    if (ev) hipEventRecord(ev[3], c->stream);
+}
 template <int KC, int RC, int ROWS, int VAR>
 void launch_filter_var(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open)
 {
@@ -1213,11 +1389,16 @@ void launch_ticket_passes(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32
         hipLaunchKernelGGL(scan_ticket_gate_kernel<0>, dim3(c->tkg_grid), dim3(TKG_TPB), 0, c->stream, view(c, MG_BF_ALT), ts, open.cnt, c->d_hit_count);
 }
 template <int KC, int RC>
-void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, bool timed,
-                       const BinSet *bins, const TicketSet *tickets)
+void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d_cnt, u64 n, RowList open, RowList hits, hipEvent_t *ev,
+                       const BinSet *bins, const TicketSet *tickets, const SubPlan *subs)
 {
-    if (timed) hipEventRecord(c->ev[0], c->stream);
-    if (tickets) { // whole-genome index: tickets filed by gate slice, then the gate slice by slice out of L2
+    if (ev) hipEventRecord(ev[0], c->stream);
+    if (subs) { // whole-genome index: tickets filed by LDS-sized sub-slice of the gate, then each sub-slice answered out of LDS
+        launch_sub_passes<KC, RC>(c, d_hi, d_lo, nullptr, n, subs->ss);
+        if (ev) hipEventRecord(ev[1], c->stream);
+        launch_sub_tail<KC, RC>(c, subs, ev, d_cnt, d_hi, d_lo, nullptr); // regions of surviving tickets: the record first, the table row where the record asks for it
+        return;
+    } else if (tickets) { // the same with 2 MiB slices walked out of L2
         launch_ticket_passes<KC, RC>(c, d_hi, d_lo, nullptr, n, *tickets, open);
     } else if (bins) { // large index: coarse gate + binning, then the fine gate slice by slice
         BinSet bs = *bins; // the last chunk may need fewer workgroups than segments were laid out for
@@ -1237,22 +1418,21 @@ void launch_scan_chunk(mg_ctx *c, const u64 *d_hi, const u64 *d_lo, const u32 *d
         case 4: launch_filter_rows<KC, RC, 4>(c, d_hi, d_lo, d_cnt, n, open); break;
         default: launch_filter_rows<KC, RC, 2>(c, d_hi, d_lo, d_cnt, n, open); break;
         }
-    if (timed) hipEventRecord(c->ev[1], c->stream);
+    if (ev) hipEventRecord(ev[1], c->stream);
     // the list lengths live on the device; fixed grids walk them with a stride, so no host round trip
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
-    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
-                       view(c), open, hits, c->d_hit_count, bins && !tickets ? (const u32 *)nullptr : d_cnt, tickets ? d_hi : (const u64 *)nullptr, tickets ? d_lo : (const u64 *)nullptr,
-                       (const u32 *)nullptr);
-    if (timed) hipEventRecord(c->ev[2], c->stream);
+    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits, c->d_hit_count,
+                       bins && !tickets ? (const u32 *)nullptr : d_cnt, tickets ? d_hi : (const u64 *)nullptr, tickets ? d_lo : (const u64 *)nullptr, (const u32 *)nullptr);
+    if (ev) hipEventRecord(ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
-    if (timed) hipEventRecord(c->ev[3], c->stream);
+    if (ev) hipEventRecord(ev[3], c->stream);
 }
 } // namespace
 
 MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     if (c->ref_k > MG_MAX_PACKED_K)
@@ -1266,9 +1446,10 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     const BFState &alt = c->bf[MG_BF_ALT];
     const u32 word_shift = (u32)(c->pregate_log2 - 1 - 6); // slices of half the L2-resident size: 2 MiB
     u32 row_bits = 27;
-    const bool tickets = ticket_form(c, &row_bits);
+    const bool subs = sub_form(c, &row_bits);
+    const bool tickets = !subs && ticket_form(c, &row_bits);
     const u64 TP = ticket_slices(c);
-    const u64 chunk = 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2); // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
+    const u64 chunk = 1ULL << std::min<u32>(tickets || subs ? row_bits : 27, (u32)c->chunk_log2); // rows per launch group (bounds the two lists' worst-case size; a ticket holds the row number)
     const u64 cap = n < chunk ? n : chunk; // worst case (gate disabled): every row is listed
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
@@ -1283,8 +1464,10 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
     // partitioned second level: two-level gate in use and the fine gate splits into 2..BIN_MAXP slices of half the coarse gate's size
     BinSet bins{};
     TicketSet tks{};
+    SubPlan sbs{};
     if (tickets) TRY(ticket_layout(c, cap, row_bits, &tks));
-    const u64 P = !tickets && alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
+    if (subs) TRY(sub_layout(c, cap, row_bits, &sbs));
+    const u64 P = !tickets && !subs && alt.pregate && pregate_on(c) ? (((alt.n_gate_bits + 63) / 64 + (1ULL << word_shift) - 1) >> word_shift) : 0;
     const bool partition = c->use_summary && c->use_pregate && c->use_partition && P >= 2 && P <= BIN_MAXP;
     if (partition) {
         bins.nbins = (u32)P;
@@ -1312,14 +1495,20 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
         if (partition) HIP_TRY(c, hipMemsetAsync(c->d_bin_meta, 0, 8, c->stream));
         if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, TK_META_HEAD, c->stream));
+        if (subs) HIP_TRY(c, hipMemsetAsync(sbs.ss.spill_count, 0, sub_meta_head(sbs.ss), c->stream));
+        hipEvent_t *ev = scan_events(c, r0 / chunk, nr);
         // the reference's defaults (k35 r43, argument_parser.hpp:57-58) and config C5 (k35 r63) get fixed-length hashing
-        if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
-        else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
-        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, r0 == 0, partition ? &bins : nullptr, tickets ? &tks : nullptr);
+        if (c->k == 35 && c->ref_k == 43) launch_scan_chunk<35, 43>(c, ph, pl, pc, nr, open, hits, ev, partition ? &bins : nullptr, tickets ? &tks : nullptr, subs ? &sbs : nullptr);
+        else if (c->k == 35 && c->ref_k == 63) launch_scan_chunk<35, 63>(c, ph, pl, pc, nr, open, hits, ev, partition ? &bins : nullptr, tickets ? &tks : nullptr, subs ? &sbs : nullptr);
+        else launch_scan_chunk<0, 0>(c, ph, pl, pc, nr, open, hits, ev, partition ? &bins : nullptr, tickets ? &tks : nullptr, subs ? &sbs : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
+    c->ev_rows.resize(std::min<u64>((n + chunk - 1) / chunk, (u64)SCAN_EV_CHUNKS));
     c->last_bins = partition ? (int)P : 0;
     c->last_tickets = tickets ? (int)TP : 0;
+    c->last_subs = subs ? (int)sbs.ss.nbins : 0;
+    if (subs && view(c).lazy) c->vec_stale = true; // (the records' copies are ahead of the vectors now)
+    else c->vec_zero = false;
     c->stats_valid = true;
     return MG_OK;
 }
@@ -1327,24 +1516,29 @@ MG_EXPORT int mg_kmc_scan_device(mg_ctx *c, const void *d_hi, const void *d_lo, 
 // ---- compact (12-byte) table rows --------------------------------------------------------------------------------
 namespace {
 template <int KC, int RC>
-void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowList hits, bool timed, const TicketSet *tickets)
+void launch_rows12_chunk(mg_ctx *c, const uint4 *rows, u64 n, RowList open, RowList hits, hipEvent_t *ev, const TicketSet *tickets, const SubPlan *subs)
 {
-    if (timed) hipEventRecord(c->ev[0], c->stream);
-    if (tickets) // whole-genome index: tickets filed by gate slice, then the gate slice by slice out of L2; the open list holds row numbers
+    if (ev) hipEventRecord(ev[0], c->stream);
+    if (subs) { // whole-genome index: tickets filed by LDS-sized sub-slice of the gate, each sub-slice then answered out of LDS; regions of tickets
+        launch_sub_passes<KC, RC>(c, nullptr, nullptr, (const u32 *)rows, n, subs->ss);
+        if (ev) hipEventRecord(ev[1], c->stream);
+        launch_sub_tail<KC, RC>(c, subs, ev, nullptr, nullptr, nullptr, (const u32 *)rows);
+        return;
+    } else if (tickets) // the same with 2 MiB slices walked out of L2; the open list holds row numbers
         launch_ticket_passes<KC, RC>(c, nullptr, nullptr, (const u32 *)rows, n, *tickets, open);
     else {
         const unsigned fgrid = (unsigned)std::min<u64>(((n + 1) / 2 + TPB - 1) / TPB, (u64)c->scan_grid);
         hipLaunchKernelGGL((scan_filter12_kernel<KC, RC>), dim3(fgrid), dim3(TPB), 0, c->stream, (const u32 *)rows, n, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT),
                            open, c->d_hit_count, c->scan_ablate);
     }
-    if (timed) hipEventRecord(c->ev[1], c->stream);
+    if (ev) hipEventRecord(ev[1], c->stream);
     const unsigned grid = (unsigned)std::min<u64>(nblocks(n), (u64)c->probe_grid);
-    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits,
-                       c->d_hit_count, (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr, tickets ? (const u32 *)rows : (const u32 *)nullptr);
-    if (timed) hipEventRecord(c->ev[2], c->stream);
+    hipLaunchKernelGGL((scan_probe_kernel<KC, RC>), dim3(grid), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k, view(c, MG_BF_ALT), view(c), open, hits, c->d_hit_count,
+                       (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr, tickets ? (const u32 *)rows : (const u32 *)nullptr);
+    if (ev) hipEventRecord(ev[2], c->stream);
     hipLaunchKernelGGL((scan_hits_kernel<KC, RC>), dim3(std::min(grid, (unsigned)c->hits_grid)), dim3(TPB), 0, c->stream, (int)c->k, (int)c->ref_k,
                        view(c, MG_BF_ALT), view(c, MG_BF_CTX), view(c), hits, c->d_hit_count);
-    if (timed) hipEventRecord(c->ev[3], c->stream);
+    if (ev) hipEventRecord(ev[3], c->stream);
 }
 int rows12_ok(mg_ctx *c)
 {
@@ -1358,7 +1552,7 @@ MG_EXPORT size_t mg_kmc_rows_bytes(size_t n) { return (n + 3) / 4 * 4 * 12; }
 
 MG_EXPORT int mg_kmc_pack_rows_device(mg_ctx *c, const void *d_hi, const void *d_lo, const void *d_cnt, size_t n, void *d_rows_out)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     TRY(rows12_ok(c));
     if (n == 0) return MG_OK;
@@ -1377,7 +1571,7 @@ MG_EXPORT int mg_kmc_pack_rows_device(mg_ctx *c, const void *d_hi, const void *d
 
 MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode || !c->bf[1].mode) return fail(c, MG_ERR_STATE, "mg_kmc_scan needs both filters finalised");
     TRY(rows12_ok(c));
@@ -1387,8 +1581,9 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
     TRY(ctx_set_ready(c));
     TRY(records_current(c));
     u32 row_bits = 27;
-    const bool tickets = ticket_form(c, &row_bits);
-    const u64 chunk = std::max<u64>(4, 1ULL << std::min<u32>(tickets ? row_bits : 27, (u32)c->chunk_log2)); // (a multiple of 4 rows: chunks start on whole quads)
+    const bool subs = sub_form(c, &row_bits);
+    const bool tickets = !subs && ticket_form(c, &row_bits);
+    const u64 chunk = std::max<u64>(4, 1ULL << std::min<u32>(tickets || subs ? row_bits : 27, (u32)c->chunk_log2)); // (a multiple of 4 rows: chunks start on whole quads)
     const u64 cap = n < chunk ? n : chunk;
     void *p[6];
     Scratch *sc[6] = {&c->s_open[0], &c->s_open[1], &c->s_open[2], &c->s_hit[0], &c->s_hit[1], &c->s_hit[2]};
@@ -1400,7 +1595,9 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
         hits.aux = (u64 *)pa;
     }
     TicketSet tks{};
+    SubPlan sbs{};
     if (tickets) TRY(ticket_layout(c, cap, row_bits, &tks));
+    if (subs) TRY(sub_layout(c, cap, row_bits, &sbs));
     c->stats_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 32, c->stream));
     for (u64 r0 = 0; r0 < n; r0 += chunk) {
@@ -1408,11 +1605,17 @@ MG_EXPORT int mg_kmc_scan_rows_device(mg_ctx *c, const void *d_rows, size_t n)
         const uint4 *pr = (const uint4 *)d_rows + r0 / 4 * 3;
         if (r0) HIP_TRY(c, hipMemsetAsync(c->d_hit_count, 0, 16, c->stream));
         if (tickets) HIP_TRY(c, hipMemsetAsync(c->d_tk_meta, 0, TK_META_HEAD, c->stream));
-        if (c->k == 35 && c->ref_k == 43) launch_rows12_chunk<35, 43>(c, pr, nr, open, hits, r0 == 0, tickets ? &tks : nullptr);
-        else launch_rows12_chunk<0, 0>(c, pr, nr, open, hits, r0 == 0, tickets ? &tks : nullptr);
+        if (subs) HIP_TRY(c, hipMemsetAsync(sbs.ss.spill_count, 0, sub_meta_head(sbs.ss), c->stream));
+        hipEvent_t *ev = scan_events(c, r0 / chunk, nr);
+        if (c->k == 35 && c->ref_k == 43) launch_rows12_chunk<35, 43>(c, pr, nr, open, hits, ev, tickets ? &tks : nullptr, subs ? &sbs : nullptr);
+        else launch_rows12_chunk<0, 0>(c, pr, nr, open, hits, ev, tickets ? &tks : nullptr, subs ? &sbs : nullptr);
         HIP_TRY(c, hipGetLastError());
     }
+    c->ev_rows.resize(std::min<u64>((n + chunk - 1) / chunk, (u64)SCAN_EV_CHUNKS));
     c->last_bins = 0;
+    c->last_subs = subs ? (int)sbs.ss.nbins : 0;
+    if (subs && view(c).lazy) c->vec_stale = true; // (the records' copies are ahead of the vectors now)
+    else c->vec_zero = false;
     c->last_tickets = tickets ? (int)ticket_slices(c) : 0;
     c->stats_valid = true;
     return MG_OK;
@@ -1590,14 +1793,26 @@ MG_EXPORT int mg_kmc_decode_records(mg_ctx *c, const void *records, size_t n, ui
 
 MG_EXPORT int mg_scan_stats(mg_ctx *c, float *ms_out, uint64_t *n_hits)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
-    if (!c->stats_valid) return fail(c, MG_ERR_STATE, "no scan has run");
-    HIP_TRY(c, hipEventSynchronize(c->ev[3]));
+    if (!c->stats_valid || c->ev_rows.empty()) return fail(c, MG_ERR_STATE, "no scan has run");
+    // per launch group (chunk) of the most recent scan, AVERAGED over its chunks by rows: the sums of the three phases over all
+    // timed chunks, scaled to the rows of the first (largest) one -- what a rocprofv3 --stats average of the same kernels gives
+    // when every chunk is full, and the same rate when the last one is not
+    const size_t nc = c->ev_rows.size();
+    HIP_TRY(c, hipEventSynchronize(c->ev[4 * nc - 1]));
     if (ms_out) {
-        HIP_TRY(c, hipEventElapsedTime(&ms_out[0], c->ev[0], c->ev[1]));
-        HIP_TRY(c, hipEventElapsedTime(&ms_out[1], c->ev[1], c->ev[2]));
-        HIP_TRY(c, hipEventElapsedTime(&ms_out[2], c->ev[2], c->ev[3]));
+        double sum[3] = {0, 0, 0};
+        u64 rows = 0;
+        for (size_t q = 0; q < nc; ++q) {
+            for (int i = 0; i < 3; ++i) {
+                float ms = 0;
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * q + i], c->ev[4 * q + i + 1]));
+                sum[i] += ms;
+            }
+            rows += c->ev_rows[q];
+        }
+        for (int i = 0; i < 3; ++i) ms_out[i] = (float)(sum[i] * (double)c->ev_rows[0] / (double)(rows ? rows : 1));
     }
     if (n_hits) {
         unsigned long long t[4] = {0, 0, 0, 0};
@@ -1631,7 +1846,7 @@ MG_EXPORT int mg_debug_packed_index(mg_ctx *c, int which, const uint64_t *hi, co
 
 MG_EXPORT int mg_counters_size(mg_ctx *c, uint64_t *n_bf, uint64_t *n_map)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     if (!c->bf[0].mode) return fail(c, MG_ERR_STATE, "`bf` not finalised");
     if (n_bf) *n_bf = c->bf[0].nset;
@@ -1696,13 +1911,23 @@ MG_EXPORT int mg_counters_import_device(mg_ctx *c, const void *d_in)
 }
 MG_EXPORT int mg_counters_reset(mg_ctx *c)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
-    if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
-    if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
+    if (!c->vec_zero) { // (vectors that nothing has written since the last reset -- lazy scans only -- are still all zero)
+        if (c->bf[0].mode && c->bf[0].nset) HIP_TRY(c, hipMemsetAsync(c->bf[0].counts, 0, c->bf[0].nset * 4, c->stream));
+        if (c->map.rows_total) HIP_TRY(c, hipMemsetAsync(c->map.vals, 0, c->map.rows_total * 4, c->stream));
+    }
+    c->vec_zero = !c->joined && !c->rec_off; // (a vector that has been handed out may be written behind the library's back)
+    c->vec_stale = false;                    // (whatever the records were ahead by is gone with their epoch)
     for (auto &kv : c->map.irregular) kv.second = 0;
-    ++c->rec_epoch; // every record's copy is now of an older epoch: it reads as zero, like the vectors just cleared
-    c->rec_ok = true;
+    // every record's copy is now of an older epoch: it reads as zero, like the vectors just cleared.  At the wrap of the 32-bit
+    // epoch the copies written 2^32 resets ago would read as current again: the next scan republishes every record instead
+    // (records_current rewrites all of them from the vectors, which are zero)
+    if (++c->rec_epoch == 0) {
+        c->rec_epoch = 1;
+        c->rec_ok = false;
+    } else
+        c->rec_ok = records_wanted(c) && c->map.slots != nullptr;
     return MG_OK;
 }
 
@@ -2022,7 +2247,7 @@ MG_EXPORT int mg_lookup_cover(mg_ctx *c, const char *rows, size_t stride, size_t
 MG_EXPORT int mg_genotype_device(mg_ctx *c, const void *d_cov, const void *d_freq, const void *d_var_allele_off, size_t n_vars, float error_rate,
                                  int max_cov, int haploid, void *d_gt1, void *d_gt2, void *d_gq, void *d_status, void *d_probs, const void *d_var_gt_off)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     if (n_vars == 0) return MG_OK;
     if (!d_cov || !d_freq || !d_var_allele_off || !d_gt1 || !d_gt2 || !d_gq || !d_status) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -2261,7 +2486,7 @@ template <int MODE> int blocks_tier3(BlocksRun &R, bool compact, u32 *d_cov, u8 
 // block cutting for a batch of kept records in file order (main.cpp:341, 547; var_block.hpp:77-80), on the device
 MG_EXPORT int mg_cut_blocks_device(mg_ctx *c, const mg_panel_dev *p, void *d_blk_var_off_out, void *d_var_block_out, void *d_n_blocks_out)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     TRY(check_panel(c, p, false));
     if (!d_n_blocks_out) return fail(c, MG_ERR_ARG, "NULL argument");
@@ -2312,7 +2537,7 @@ MG_EXPORT int mg_cut_blocks(mg_ctx *c, size_t n_vars, const int32_t *pos, const 
 MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const void *d_blk_var_off, const void *d_var_block, const void *d_n_blocks, int haploid,
                                      void *d_cov_out, void *d_overflow_out)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c) return MG_ERR_ARG;
     TRY(check_panel(c, p, true));
     if (p->n_vars == 0) return MG_OK;
@@ -2354,7 +2579,7 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
 // timing and counts of the most recent mg_cover_blocks_device (waits for it)
 MG_EXPORT int mg_blocks_stats(mg_ctx *c, float *ms_out, uint64_t *counts_out)
 {
-    const DeviceGuard on_device(c, KEEP);
+    const DeviceGuard on_device(c, LAZY);
     if (!c || !ms_out || !counts_out) return MG_ERR_ARG;
     if (!c->blocks_stats_valid) return fail(c, MG_ERR_STATE, "no mg_cover_blocks_device yet");
     HIP_TRY(c, hipEventSynchronize(c->ev_b[3]));

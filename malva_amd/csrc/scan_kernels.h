@@ -964,6 +964,250 @@ __global__ void __launch_bounds__(TKG_TPB) scan_ticket_gate_kernel(BFView bf, Ti
     flush_if_above(0);
 }
 
+// ---- sub-slices: the gate pass answered out of LDS --------------------------------------------------------------------
+// The ticket form's second pass reads one random 8-byte word of an L2-resident slice per ticket, and an XCD's L2 serves
+// about 14 such reads per clock whatever surrounds them: 0.5 ms per 2^27 tickets for the gather alone, 0.93 ms measured.
+// An LDS read costs a twentieth of that.  So this form files the tickets under SUB-SLICES of the gate small enough for one
+// workgroup's LDS (2^14 words = 128 KiB; up to 1,024 of them = a 128 MiB gate) and pass two becomes a stream: a workgroup
+// copies its sub-slice into LDS once, walks that bin's tickets (8 B each, sequential) and answers every one from LDS.
+// Filing under a thousand bins needs long tiles to leave in runs: pass one sorts 16,384 rows at a time (all of a CU's
+// LDS, one 1,024-thread workgroup per CU), 16 tickets = one 128-byte line per bin and tile on average.  Survivors are
+// listed per (bin, part) region -- one workgroup owns it, so an LDS counter places them and no global atomic is involved
+// -- and the probe kernel walks the regions.
+// Measured on one GPU's share of C4 (3.75e8 rows, 8e7-SNP index; profiles/r04_c4share_forms.txt), per 2^27 rows: pass one
+// 0.97 ms (0.75 of it hashing: without its stores it takes 0.79), pass two 0.36, against 0.88 + 0.95 for the ticket form.
+// Built on top and dropped, each measured: 2,048 sub-slices (a 256 MiB gate: a quarter of the false positives, but runs
+// of 8 tickets = 64 B: stores and pass two +0.5 ms, the probe kernel -0.23); the next tile's rows requested before the
+// sorted tile's stores, so that the hashing would run beside the stores instead of behind them (24-48 more live registers:
+// the kernel spills at the 128 a 1,024-thread workgroup may use and its hashing takes 1.0 ms instead of 0.79; the same
+// with the tickets waiting in LDS instead of registers: 1.03); two tickets per 16-byte store (no gain: the stores are
+// bound by HBM's write rate, 1.07 GB in 0.22 ms, not by their issue).
+constexpr int SB_TPB = 1024;                 // threads per workgroup, both passes (one workgroup per CU: LDS)
+constexpr int SB_ROWS = 16;                  // rows per thread and tile
+constexpr int SB_TILE = SB_TPB * SB_ROWS;    // 16,384 rows: the sorted tile is 128 KiB
+constexpr int SB_MAXB = SB_TPB;              // bins: one thread per bin in the prefix sum
+constexpr int SB_WORDS_LOG2 = 14;            // largest sub-slice: 2^14 gate words = 128 KiB
+constexpr int SBG_U = 10;                    // pass two: ticket loads in flight per lane (640 tickets per wave and step)
+struct SubSet {
+    u64 *tickets;               // [nbins][nseg] segments of `segcap` tickets
+    u32 *counts;                // [nbins][nseg]
+    u64 *spill;                 // tickets that did not fit their segment
+    unsigned long long *spill_count;
+    u64 segcap;
+    u32 nbins, nseg;            // nseg = pass one's grid
+    u32 bin_shift;              // bin = idx >> bin_shift (gate_shift + 6 + words_log2)
+    u32 words_log2;             // gate words per sub-slice (<= SB_WORDS_LOG2)
+    u32 row_bits;               // ticket = idx << row_bits | row
+    u32 parts;                  // workgroups of pass two that share one bin (its segments are split between them)
+    u64 *out_tk;                // [nbins * parts] regions of `ucap` surviving tickets, then the region of the spill list's survivors
+    u32 *out_counts;            // [nbins * parts + 1]
+    u64 ucap;
+    u64 n_gate_words;
+    u32 ablate;                 // timing-only diagnostic of pass one (results are wrong when non-zero): 1 = tickets not stored
+};
+
+// Pass one.  Five barriers per tile of 16,384 rows: counts complete / wave sums / places known, next counts cleared /
+// tile sorted / tile stored.  R12: the table is compact 12-byte rows (rows12), else the SoA arrays (hi, lo).
+template <int KC, int RC, bool R12>
+__global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ rows12, u64 n,
+                                                                int k_rt, int r_rt, BFView bf, SubSet ss)
+{
+    __shared__ u64 sh_sorted[SB_TILE];
+    __shared__ u32 sh_hist[2][SB_MAXB], sh_off[SB_MAXB], sh_pos[SB_MAXB], sh_wsum[SB_TPB / 64];
+    __shared__ u32 sh_lut[256];
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ascii_lut_fill(sh_lut);
+    sh_hist[0][threadIdx.x] = sh_hist[1][threadIdx.x] = sh_pos[threadIdx.x] = 0; // (SB_TPB == SB_MAXB)
+    __syncthreads();
+    u32 parity = 0;
+    typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
+    const bool vec_ok = !R12 && ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
+    const u32 segcap = (u32)ss.segcap;
+    for (u64 base = (u64)blockIdx.x * SB_TILE; base < n; base += (u64)gridDim.x * SB_TILE) {
+        u64 tk[SB_ROWS];
+        u32 binrank[SB_ROWS]; // bin << 16 | rank inside the bin (a tile holds 16,384 rows), ~0u = no row
+#pragma unroll
+        for (int g = 0; g < SB_ROWS / 2; ++g) { // two adjacent rows per load group
+            const u64 i = base + (u64)g * 2 * SB_TPB + 2 * (u64)threadIdx.x;
+            U128 m[2];
+            bool live[2];
+            if constexpr (R12) { // 24 contiguous bytes: rows i and i + 1 (i is even; the buffer is padded to whole quads of rows)
+                typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
+                u32 w[6] = {0, 0, 0, 0, 0, 0};
+                if (i < n) {
+                    const v2u32 *src = (const v2u32 *)rows12 + 3 * (i / 2);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const v2u32 v = __builtin_nontemporal_load(src + q);
+                        w[2 * q] = v.x;
+                        w[2 * q + 1] = v.y;
+                    }
+                }
+                const u32 kmask_hi = (1u << ((2 * r - 64) & 31)) - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    m[j] = U128{w[3 * j] | (u64)w[3 * j + 1] << 32, (u64)(w[3 * j + 2] & kmask_hi)};
+                    live[j] = i + j < n;
+                }
+            } else if (vec_ok && i + 1 < n) {
+                const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
+                const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
+                m[0] = U128{l2.x, h2.x};
+                m[1] = U128{l2.y, h2.y};
+                live[0] = live[1] = true;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    live[j] = i + j < n;
+                    m[j].lo = live[j] ? __builtin_nontemporal_load(lo + i + j) : 0;
+                    m[j].hi = live[j] ? __builtin_nontemporal_load(hi + i + j) : 0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+                const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
+                tk[2 * g + j] = (idx << ss.row_bits) | (i + j);
+                const u32 bin = (u32)(idx >> ss.bin_shift);
+                binrank[2 * g + j] = live[j] ? (bin << 16) | atomicAdd(&sh_hist[parity][bin], 1u) : ~0u;
+            }
+        }
+        __syncthreads(); // 1: the tile's counts are complete (and the previous tile has left the sorted array)
+        const u32 mine = sh_hist[parity][threadIdx.x]; // this tile's tickets of bin threadIdx.x (bins beyond nbins stay empty)
+        u32 incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) sh_wsum[wave] = incl;
+        __syncthreads(); // 2
+        u32 before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < SB_TPB / 64; ++w) {
+            const u32 s = sh_wsum[w];
+            before += w < wave ? s : 0u;
+            total += s;
+        }
+        sh_off[threadIdx.x] = before + incl - mine;
+        sh_hist[parity ^ 1][threadIdx.x] = 0; // the next tile's counts
+        __syncthreads(); // 3: every bin's place in the tile is known
+#pragma unroll
+        for (int j = 0; j < SB_ROWS; ++j)
+            if (binrank[j] != ~0u) sh_sorted[sh_off[binrank[j] >> 16] + (binrank[j] & 0xFFFFu)] = tk[j];
+        __syncthreads(); // 4: the tile is sorted
+        if (!(ss.ablate & 1))
+            for (u32 e = threadIdx.x; e < total; e += SB_TPB) { // runs of consecutive tickets, one per bin, into the workgroup's segments
+                const u64 t = sh_sorted[e];
+                const u32 b = (u32)((t >> ss.row_bits) >> ss.bin_shift);
+                const u32 at = sh_pos[b] + (e - sh_off[b]);
+                if (at < segcap) ss.tickets[((unsigned long long)b * ss.nseg + blockIdx.x) * ss.segcap + at] = t;
+                else ss.spill[atomicAdd(ss.spill_count, 1ULL)] = t; // the segment is full (skewed input): rare
+            }
+        __syncthreads(); // 5: everybody has read the segments' fills
+        if (!(ss.ablate & 1)) sh_pos[threadIdx.x] = min(sh_pos[threadIdx.x] + mine, segcap);
+        parity ^= 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < ss.nbins) ss.counts[threadIdx.x * ss.nseg + blockIdx.x] = sh_pos[threadIdx.x];
+}
+
+// Pass two.  Unit u = (bin, part): the workgroup copies the bin's sub-slice of the gate into LDS, then its waves take the
+// part's segments one by one -- a segment's tickets requested together, ten loads per lane -- and answer every ticket
+// from LDS.  Survivors go to the unit's own region as row numbers, placed by a counter in LDS.  The spill list (tickets of
+// any bin) is answered from the gate in global memory at the end.  GK: the gate's bits per entry at compile time (0 = view).
+template <int GK>
+__global__ void __launch_bounds__(SB_TPB) scan_sub_gate_kernel(BFView bf, SubSet ss)
+{
+    __shared__ u64 sh_gate[1 << SB_WORDS_LOG2];
+    __shared__ u32 sh_out;
+    const u32 gate_k = GK > 0 ? (u32)GK : bf.gate_k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 wmask = (1u << ss.words_log2) - 1;
+    const u32 units = ss.nbins * ss.parts;
+    const u32 spp = (ss.nseg + ss.parts - 1) / ss.parts; // segments per part
+    for (u32 unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const u32 bin = unit / ss.parts, part = unit % ss.parts;
+        const u32 s0 = part * spp, s1 = min(ss.nseg, s0 + spp);
+        const u64 w0 = (u64)bin << ss.words_log2;
+        const u32 nw = (u32)min((u64)1 << ss.words_log2, ss.n_gate_words > w0 ? ss.n_gate_words - w0 : (u64)0);
+        for (u32 i = threadIdx.x; i < nw; i += SB_TPB) sh_gate[i] = bf.gate[w0 + i];
+        if (threadIdx.x == 0) sh_out = 0;
+        __syncthreads();
+        u64 *const out = ss.out_tk + (u64)unit * ss.ucap;
+        for (u32 s = s0 + wave; s < s1; s += SB_TPB / 64) {
+            const u32 cnt = __builtin_amdgcn_readfirstlane(ss.counts[bin * ss.nseg + s]);
+            const u64 *seg = ss.tickets + ((u64)bin * ss.nseg + s) * ss.segcap;
+            for (u32 q0 = 0; q0 < cnt; q0 += 64 * SBG_U) {
+                u64 t[SBG_U];
+                bool live[SBG_U];
+#pragma unroll
+                for (int u = 0; u < SBG_U; ++u) { // (no predicate on the load itself: the compiler counts outstanding loads)
+                    const u32 q = q0 + u * 64 + lane;
+                    live[u] = q < cnt;
+                    t[u] = __builtin_nontemporal_load(seg + (live[u] ? q : 0u));
+                }
+#pragma unroll
+                for (int u = 0; u < SBG_U; ++u) {
+                    const u64 idx = t[u] >> ss.row_bits;
+                    const u64 word = sh_gate[(u32)(idx >> (bf.gate_shift + 6)) & wmask];
+                    const u64 gm = gate_mask_sk(idx, bf.gate_shift, gate_k);
+                    const bool take = live[u] && (word & gm) == gm;
+                    const u64 mask = __ballot(take);
+                    if (mask) {
+                        const int leader = __ffsll((unsigned long long)mask) - 1;
+                        u32 b = 0;
+                        if (lane == leader) b = atomicAdd(&sh_out, (u32)__popcll(mask));
+                        b = __shfl(b, leader, 64);
+                        if (take) out[b + __popcll(mask & ((1ULL << lane) - 1))] = t[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) ss.out_counts[unit] = sh_out;
+        __syncthreads(); // (the next unit rewrites the sub-slice and the counter)
+    }
+    { // the spill list: one dense run, an even share per workgroup; any bin, so the gate in global memory answers
+        const u64 ns = *ss.spill_count, chunk = (ns + gridDim.x - 1) / gridDim.x;
+        const u64 b0 = ns < chunk * blockIdx.x ? ns : chunk * blockIdx.x, b1 = ns < b0 + chunk ? ns : b0 + chunk;
+        u64 *const out = ss.out_tk + (u64)units * ss.ucap;
+        for (u64 base = b0; base < b1; base += SB_TPB) {
+            const u64 q = base + threadIdx.x;
+            const bool live = q < b1;
+            const u64 t = live ? ss.spill[q] : 0;
+            const u64 idx = t >> ss.row_bits;
+            const u64 word = live ? bf.gate[gate_word(bf, idx)] : 0;
+            const u64 gm = gate_mask_sk(idx, bf.gate_shift, gate_k);
+            const bool take = live && (word & gm) == gm;
+            const u64 mask = __ballot(take);
+            if (mask) {
+                const int leader = __ffsll((unsigned long long)mask) - 1;
+                u32 b = 0;
+                if (lane == leader) b = atomicAdd(&ss.out_counts[units], (u32)__popcll(mask));
+                b = __shfl(b, leader, 64);
+                if (take) out[b + __popcll(mask & ((1ULL << lane) - 1))] = t;
+            }
+        }
+    }
+}
+// the open rows of a chunk, for mg_scan_stats: the sum of the units' counts
+__global__ void __launch_bounds__(SB_TPB) sub_total_kernel(const u32 *__restrict__ counts, u32 n, unsigned long long *counters)
+{
+    __shared__ unsigned long long sh[SB_TPB / 64];
+    unsigned long long v = 0;
+    for (u32 i = threadIdx.x; i < n; i += SB_TPB) v += counts[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < SB_TPB / 64; ++w) t += sh[w];
+        counters[0] = t;
+    }
+}
+
 // (Probe and hit pass fused in one kernel -- no second list, no re-hash -- was measured: 0.276 ms against 0.100 +
 // 0.050 ms; a third of the lanes running a second XXH3 while the others idle costs more than the list.)
 template <int KC, int RC>
@@ -984,16 +1228,14 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
     __syncthreads();
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
-    const u64 n_open = counters[0];
-    const u64 step = (u64)gridDim.x * TPB;
-    for (u64 base = (u64)blockIdx.x * TPB; base < n_open; base += step) {
-        const u64 j = base + threadIdx.x;
+    // one tile of TPB open rows: `live` = this thread has one, `count` = what the list holds for it (the row's count, or
+    // its number in the table), j = its place in the flat open list (the forms whose list carries the rows).  Every thread
+    // of the workgroup calls it (barriers inside).
+    auto tile = [&](bool live, u32 count, u64 j) {
         bool hit = false;
         U128 m{0, 0};
-        u32 count = 0;
         u64 extra = 0;
-        if (j < n_open) {
-            count = open.cnt[j];
+        if (live) {
             if (rows12) { // ticket form over compact rows: the list holds row numbers, a row is 12 contiguous bytes (one line, now and then two)
                 typedef u32 __attribute__((ext_vector_type(3), aligned(4))) row12_t; // ONE load instruction (global_load_dwordx3): one translation per row
                 const row12_t wv = __builtin_nontemporal_load((const row12_t *)(rows12 + 3 * (u64)count));
@@ -1010,7 +1252,6 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
             }
         }
         {
-            const bool live = j < n_open;
             const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
             const u64 h = xxh3_packed_k<KC>(c, k, sh_lut);
             const u64 idx = mod_size(h, bf.mod);
@@ -1026,8 +1267,120 @@ __global__ void __launch_bounds__(TPB) scan_probe_kernel(int k_rt, int r_rt, BFV
         }
         st.push(hit, m, count, extra);
         st.flush_if_above(CAP - TPB, hits, &counters[1]);
+    };
+    const u64 n_open = counters[0];
+    const u64 step = (u64)gridDim.x * TPB;
+    for (u64 base = (u64)blockIdx.x * TPB; base < n_open; base += step) {
+        const u64 j = base + threadIdx.x;
+        tile(j < n_open, j < n_open ? open.cnt[j] : 0u, j);
     }
     st.flush_if_above(0, hits, &counters[1]);
+}
+
+// The sub-slice form's probe AND hit pass.  Its open list holds TICKETS (filter slot | row number), region by region, so
+// the record -- which is addressed by the slot alone -- is fetched FIRST and whole (64 bytes: key, the filter's two
+// entries, the record's copies of its counters), and the table row only where the record says it can matter: it holds a
+// key (which may be this row's k-mer), or the slot is a set bit of `bf`.  A row that got here by a false positive of the
+// gate finds an empty record five times in six and ends after ONE random line instead of two; the slot came with the
+// ticket and a key is compared as it is, so the centre k-mer is never hashed again.  A row whose slot IS a set bit goes on
+// at once -- ref_k-mer hashed, context filter asked, counter and its copy in the record added to -- on the record's line
+// while it is still near, with the copy's old word already in hand for the compare-and-swap: no hit list, no second fetch
+// of row or record.  Where the records' copies are the counters of record (MapView::lazy: one GPU, a large index) the adds to
+// vals[] / counts[] -- a random line each, of vectors nobody reads before the record loop has read the copies -- are left out.  (Earlier forms fused the two passes and lost, DESIGN_NOTES: every lane then hashed the centre k-mer
+// too and the vector pipe was the bound; here the kernel waits on memory and the ref_k-mer hash of one lane in five runs
+// in its shadow.)  Nothing synchronises: workgroup w takes every `split`-th group of four tiles of region w / split, each
+// of its waves one tile of the four; a lane that has to walk on, or retry a compare-and-swap, holds up its own wave only.
+struct SubOpen {
+    const u32 *counts = nullptr; // tickets in each region
+    const u64 *tickets = nullptr;
+    u64 ucap = 0;                // region u starts at tickets + u * ucap
+    u32 n_units = 0, split = 1, row_bits = 27;
+};
+constexpr int SUBP_WAVES = TPB / 64;
+template <int KC, int RC>
+__global__ void __launch_bounds__(TPB) scan_sub_probe_kernel(int k_rt, int r_rt, BFView bf, BFView ctx, MapView map, SubOpen sub, unsigned long long *counters,
+                                                             const u32 *__restrict__ cnt_table, const u64 *__restrict__ row_hi, const u64 *__restrict__ row_lo,
+                                                             const u32 *__restrict__ rows12)
+{
+    __shared__ u32 sh_hits;
+    if (threadIdx.x == 0) sh_hits = 0;
+    __syncthreads();
+    const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
+    const int off = (r - k) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 row_mask = (1ULL << sub.row_bits) - 1, smask = (1ULL << map.cap_log2) - 1;
+    U128 m{0, 0}, key{0, 0};
+    u32 count = 0, n_hits = 0;
+    auto fetch_row = [&](u32 row) { // the table row (ref_k-mer, count) and its canonical centre k-mer
+        if (rows12) { // 12 contiguous bytes: ONE load instruction (global_load_dwordx3)
+            typedef u32 __attribute__((ext_vector_type(3), aligned(4))) row12_t;
+            const row12_t wv = __builtin_nontemporal_load((const row12_t *)(rows12 + 3 * (u64)row));
+            const u32 kbits_hi = (u32)(2 * r - 64) & 31; // (33 <= ref_k <= 44 here)
+            m = U128{wv.x | (u64)wv.y << 32, (u64)(wv.z & ((1u << kbits_hi) - 1))};
+            count = wv.z >> kbits_hi;
+        } else {
+            m = U128{__builtin_nontemporal_load(row_lo + row), __builtin_nontemporal_load(row_hi + row)};
+            count = __builtin_nontemporal_load(cnt_table + row);
+        }
+        key = canon_sub(m, mform_to_lform(m, r), r, off, k);
+    };
+    for (u32 w = blockIdx.x; w < sub.n_units * sub.split; w += gridDim.x) {
+        const u32 unit = w / sub.split, sl = w % sub.split;
+        const u32 cnt = sub.counts[unit];
+        const u64 *tks = sub.tickets + (u64)unit * sub.ucap;
+        for (u32 base = (sl * SUBP_WAVES + wave) * 64; base < cnt; base += sub.split * TPB) { // (wave-uniform bounds)
+            const u32 j = base + lane;
+            const bool live = j < cnt;
+            const u64 t = live ? __builtin_nontemporal_load(tks + j) : 0;
+            const u64 idx = t >> sub.row_bits, want = idx + 1;
+            u64 s = map_home(map, idx);
+            uint4 a, b, c, d;
+            records_load_coop4(map, s, live, &a, &b, &c, &d); // (whole waves: the records are fetched four lanes to a record)
+            bool map_open = live && a.x != 0, bf_open = live, have_row = false;
+            for (;;) {
+                if (bf_open) { // bit idx of bf: an entry of the record, or of one further on while both entries are taken by other bits
+                    const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+                    const int e = b0 == want ? 0 : b1 == want ? 1 : -1;
+                    if (e >= 0) {
+                        bf_open = false;
+                        ++n_hits;
+                        if (!have_row) fetch_row((u32)(t & row_mask)), have_row = true;
+                        const U128 cc = canon_sub(m, mform_to_lform(m, r), r, 0, r);
+                        const u64 cidx = mod_size(xxh3_packed_k<RC>(cc, r), ctx.mod);
+                        if (!bf_bit_via_set(ctx, cidx)) {                     // context_bf.test_key (main.cpp:496)
+                            if (!map.lazy) atomicAdd(&bf.counts[e ? b.w : b.z], count); // bf.increment (main.cpp:498)
+                            if (map.epoch) rec_add_bf_from(&map.slots[s], e, map.epoch, count, d.z | (unsigned long long)d.w << 32); // ... and its copy in the record
+                        }
+                    } else if (b0 == 0 || b1 == 0)
+                        bf_open = false;
+                }
+                if (map_open) { // a key lives here: the row's k-mer decides whether it is this one
+                    if (!have_row) fetch_row((u32)(t & row_mask)), have_row = true;
+                    if (a.x == 0) map_open = false;
+                    else if (a.z == (u32)key.lo && a.w == (u32)(key.lo >> 32) && b.x == (u32)key.hi && b.y == (u32)(key.hi >> 32)) {
+                        map_open = false;
+                        if (!map.lazy) atomicAdd(&map.vals[a.y], count); // ref_bf.increment (main.cpp:495)
+                        if (map.epoch) rec_add_val_from(&map.slots[s], map.epoch, count, d.x | (unsigned long long)d.y << 32); // ... and the record's copy, on the line just read
+                    }
+                }
+                if (!map_open && !bf_open) break;
+                s = (s + 1) & smask; // (one lane in five goes on to the next record: nearly always the same page)
+                const uint4 *p = reinterpret_cast<const uint4 *>(&map.slots[s]);
+                a = p[0];
+                b = p[1];
+                c = p[2];
+                d = p[3];
+            }
+        }
+    }
+    // mg_scan_stats: the rows whose slot was a set bit of bf (counters[1]: this launch group, [2]: the whole call)
+    for (int o = 32; o > 0; o >>= 1) n_hits += __shfl_down(n_hits, o, 64);
+    if (lane == 0 && n_hits) atomicAdd(&sh_hits, n_hits);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh_hits) {
+        atomicAdd(&counters[1], (unsigned long long)sh_hits);
+        atomicAdd(&counters[2], (unsigned long long)sh_hits);
+    }
 }
 
 template <int KC, int RC>

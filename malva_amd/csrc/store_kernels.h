@@ -381,6 +381,29 @@ __global__ void __launch_bounds__(TPB) widen_u16_kernel(const uint16_t *in, u32 
 }
 
 
+// The other direction (vectors_current): the vectors set from the records' copies, after scans that added to the copies alone
+// (MapView::lazy).  Every counter a lookup, an export or an exchange can ask for belongs to exactly one record -- vals[id] to
+// the record of its key, counts[rank] to the record entry of its set bit -- so one pass over the table writes them all; a copy
+// of an older epoch is zero.  The filter's counters come back as the reference's u16 cells (the vector's upper halves, which
+// only ever matter modulo 2^16, restart at zero).
+__global__ void __launch_bounds__(TPB) rec_collect_kernel(MapView m, u32 *__restrict__ counts, u32 epoch)
+{
+    const u64 n = 1ULL << m.cap_log2;
+    for (u64 s = (u64)blockIdx.x * TPB + threadIdx.x; s < n; s += (u64)gridDim.x * TPB) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(&m.slots[s]);
+        const uint4 a = p[0], b = p[1], c = p[2];
+        const u64 b0 = c.x | (u64)c.y << 32, b1 = c.z | (u64)c.w << 32;
+        if (a.x < 2 && !b0) continue; // an empty record
+        const uint4 d = p[3]; // {cval, cbf}
+        if (a.x >= 2) m.vals[a.y] = d.y == epoch ? d.x : 0u;
+        if (counts) {
+            const u32 both = d.w == epoch ? d.z : 0u;
+            if (b0) counts[b.z] = both & 0xFFFFu;
+            if (b1) counts[b.w] = both >> 16;
+        }
+    }
+}
+
 // Every record's counter copies set from the vectors (MapSlot::cval / cbf, epoch `epoch`): see records_current.
 __global__ void __launch_bounds__(TPB) rec_publish_kernel(MapView m, const u32 *__restrict__ counts, u32 epoch)
 {

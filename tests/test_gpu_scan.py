@@ -95,6 +95,30 @@ def test_scan_ticket_form(k, ref_k, bits, gate_log2, slices, bin_cap):
                options=[("pregate_log2", 10), ("gate_log2", gate_log2), ("use_tickets", 1), ("ticket_min_log2", 11), ("scan_bin_cap", bin_cap)])
 
 
+@pytest.mark.parametrize("k,ref_k,bits,gate_log2,words_log2,bin_cap", [(35, 43, 1 << 33, 14, 3, 0), (35, 43, 1 << 17, 14, 3, 0), (35, 63, 1 << 20, 13, 2, 0),
+                                                                       (31, 41, (1 << 18) + 77, 14, 3, 0),   # the last sub-slice is a partial one
+                                                                       (35, 43, 1 << 33, 16, 0, 0),          # 1,024 bins: the most the form takes
+                                                                       (35, 43, 1 << 33, 12, 5, 0),          # 2 bins shared by several workgroups each
+                                                                       (35, 43, 1 << 33, 14, 3, 16), (35, 43, 1 << 17, 13, 2, 16)])
+def test_scan_sub_slice_form(k, ref_k, bits, gate_log2, words_log2, bin_cap):
+    """whole-genome-sized indexes file an 8-byte ticket per table row under an LDS-sized sub-slice of the fine gate
+    (scan_sub_sort_kernel), then one workgroup per sub-slice copies it into LDS and answers that bin's tickets from there
+    (scan_sub_gate_kernel); the probe kernel walks the per-bin regions of surviving row numbers.  Forced here on small gates:
+    sub-slices of 2^words_log2 words.  bin_cap > 0 shrinks the segments so that most tickets take the spill list (answered from
+    the gate in global memory).  Counters must equal the oracle's, as in every other form."""
+    shift = 6
+    while ((bits + (1 << shift) - 1) >> shift) > (1 << gate_log2):
+        shift += 1
+    words = (((bits + (1 << shift) - 1) >> shift) + 63) // 64
+    n_bins = (words + (1 << words_log2) - 1) >> words_log2
+
+    def check(ctx):
+        assert ctx.get_option("scan_subs") == n_bins >= 2 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_tickets") == 0
+        assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
+    _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
+               options=[("gate_log2", gate_log2), ("use_sub", 1), ("sub_min_log2", 11), ("sub_words_log2", words_log2), ("scan_bin_cap", bin_cap)])
+
+
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17), (11, 19), (16, 24), (9, 9)])   # below 17 the hash takes XXH3's short-input branches
 def test_scan_generic_k(k, ref_k):
     _scan_case(k, ref_k, (1 << 18) + 77, 1500, 60000, 100 + k)
@@ -244,7 +268,39 @@ def test_scan_compact_rows_ticket_form(k, ref_k, n_rows, bits, gate_log2, bin_ca
         assert map_values_by_key(ctx) == dict(omap.items())
 
 
-@pytest.mark.parametrize("form,chunk_log2", [("direct", 14), ("tickets", 13), ("tickets", 15), ("compact", 12), ("compact-tickets", 14), ("partition", 15)])
+@pytest.mark.parametrize("k,ref_k,n_rows,bits,gate_log2,words_log2,bin_cap", [(35, 43, 150003, 1 << 33, 14, 3, 0), (35, 43, 120001, 1 << 17, 11, 1, 0),
+                                                                             (31, 41, 60002, (1 << 18) + 77, 12, 2, 0), (35, 43, 150003, 1 << 33, 16, 0, 16),
+                                                                             (33, 44, 4, 1 << 20, 12, 2, 0), (35, 43, 16385, 1 << 20, 12, 2, 0)])
+def test_scan_compact_rows_sub_slice_form(k, ref_k, n_rows, bits, gate_log2, words_log2, bin_cap):
+    """the sub-slice form over 12-byte rows (what bench.py's whole-genome workload runs): pass one reads the packed rows, the
+    regions hold row numbers, the probe kernel fetches the 12 bytes of each.  Forced on small gates; counters equal the oracle's."""
+    import torch
+    panel = synth.snp_panel(3000, 90 + k)
+    hi, lo, cnt = synth.kmer_table(panel, n_rows, k, ref_k, 91)
+    cnt[:] = 1 + (cnt * 37) % ((1 << (96 - 2 * ref_k)) - 1)
+    with Context(k, ref_k, bits) as ctx:
+        for name, value in [("gate_log2", gate_log2), ("use_sub", 1), ("sub_min_log2", 11), ("sub_words_log2", words_log2), ("scan_bin_cap", bin_cap)]:
+            ctx.set_option(name, value)
+        obf, octx, omap = build_index_pair(ctx, panel, k, ref_k, bits)
+        ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+        dev = torch.device("cuda", 0)
+        d_hi, d_lo = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (hi, lo))
+        d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+        d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.kmc_pack_rows_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), n_rows, d_rows.data_ptr())
+        ctx.kmc_scan_rows_device(d_rows.data_ptr(), n_rows)
+        ctx.synchronize()
+        assert ctx.get_option("scan_subs") >= 2
+        assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
+        assert np.array_equal(ctx.bf_export(BF_ALT)[3], obf.counts())
+        assert map_values_by_key(ctx) == dict(omap.items())
+        f, p_, h, n_open, n_hits = ctx.scan_stats()
+        assert n_open > 0 and f >= 0
+
+
+@pytest.mark.parametrize("form,chunk_log2", [("direct", 14), ("tickets", 13), ("tickets", 15), ("compact", 12), ("compact-tickets", 14), ("partition", 15),
+                                             ("subs", 15), ("compact-subs", 14), ("compact-subs", 16)])
 def test_scan_in_many_chunks(form, chunk_log2):
     """A table longer than one launch group (2^27 rows) is scanned chunk by chunk, lists and list counters reused.  Launch
     groups of 2^12..2^15 rows put 5 to 37 chunks into a 150,003-row table (the last one partial): every counter equals the
@@ -258,6 +314,8 @@ def test_scan_in_many_chunks(form, chunk_log2):
         options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 1), ("ticket_min_log2", 11)]
     if form == "partition":
         options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 0)]
+    if "subs" in form:
+        options += [("gate_log2", 14), ("use_sub", 1), ("sub_min_log2", 11), ("sub_words_log2", 3)]
     panel = synth.snp_panel(3000, 201)
     hi, lo, cnt = synth.kmer_table(panel, n_rows, k, ref_k, 202)
     with Context(k, ref_k, bits) as ctx:
@@ -285,6 +343,8 @@ def test_scan_in_many_chunks(form, chunk_log2):
             assert ctx.get_option("scan_tickets") >= 2
         if form == "partition":
             assert ctx.get_option("scan_bins") >= 2
+        if "subs" in form:
+            assert ctx.get_option("scan_subs") == 32
 
 
 @pytest.mark.parametrize("k,ref_k", [(35, 43), (35, 63), (31, 42), (21, 29), (64, 64), (17, 18), (33, 64)])

@@ -32,10 +32,14 @@ panel = synth.snp_panel(n_vars, 4242, spacing=40)
 plant = min(n_vars, n_rows // 5 * 2 // 15)          # 7.5 windows per planted variant on average -> 20 % of the rows
 tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
 print("[c4] panel + table: %.0f s, %d site rows (%.1f %%)" % (time.time() - t0, tab.n_site, 100.0 * tab.n_site / n_rows), file=sys.stderr)
-forms = {"tickets": [("use_tickets", 1)],
+forms = {"subs": [("use_sub", 1)], "subs_nostore": [("use_sub", 1), ("scan_ablate", 256)],
+         "subs_split2": [("use_sub", 1), ("sub_split", 2)], "subs_split8": [("use_sub", 1), ("sub_split", 8)],
+         "subs_norec": [("use_sub", 1), ("use_record_counters", 0)], "subs_probe1k": [("use_sub", 1), ("probe_grid", 1024)], "subs_probe4k": [("use_sub", 1), ("probe_grid", 4096)],
+         "subs_hits4k": [("use_sub", 1), ("hits_grid", 4096)],
+         "tickets": [("use_sub", 0), ("use_tickets", 1)],
          # timing only (wrong results): pass one without its ticket stores / without sorting the tile either
-         "tickets_nostore": [("use_tickets", 1), ("scan_ablate", 256)], "tickets_nosort": [("use_tickets", 1), ("scan_ablate", 512)],
-         "legacy": [("use_tickets", 0)], "direct": [("use_tickets", 0), ("use_partition", 0)],
+         "tickets_nostore": [("use_sub", 0), ("use_tickets", 1), ("scan_ablate", 256)], "tickets_nosort": [("use_sub", 0), ("use_tickets", 1), ("scan_ablate", 512)],
+         "legacy": [("use_sub", 0), ("use_tickets", 0)], "direct": [("use_sub", 0), ("use_tickets", 0), ("use_partition", 0)],
          # smaller fine gates (more false positives, but inside the 256 MiB Infinity Cache): gate_log2 is fixed before the inserts
          "gate30": [("use_pregate", 0), ("gate_log2", 30)], "gate29": [("use_pregate", 0), ("gate_log2", 29)],
          "gate30k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 30)], "gate29k2": [("use_pregate", 0), ("gate_k", 2), ("gate_log2", 29)],
@@ -66,9 +70,9 @@ for form in args.forms.split(","):
         f, p, h, n_open, n_hit = ctx.scan_stats()
         first = min(n_rows, 1 << 27)
         print(json.dumps({"form": form, "layout": args.layout, "variants": n_vars, "rows": n_rows, "b": args.b, "gate_log2": ctx.get_option("gate_log2"),
-                          "pregate_k": ctx.get_option("pregate_k"), "scan_tickets": ctx.get_option("scan_tickets"), "gate_grid": ctx.get_option("ticket_gate_grid"), "scan_bins": ctx.get_option("scan_bins"),
+                          "pregate_k": ctx.get_option("pregate_k"), "scan_tickets": ctx.get_option("scan_tickets"), "scan_subs": ctx.get_option("scan_subs"), "gate_grid": ctx.get_option("ticket_gate_grid"), "scan_bins": ctx.get_option("scan_bins"),
                           "spilled": ctx.get_option("scan_spilled"), "scan_ms_whole_table": round(min(ms[1:]), 3),
-                          "first_chunk_rows": first, "first_chunk_ms": {"filter": round(f, 3), "probe": round(p, 3), "hits": round(h, 3)},
+                          "chunk_rows": first, "chunk_ms_avg": {"filter": round(f, 3), "probe": round(p, 3), "hits": round(h, 3)},
                           "filter_frac_of_8TBs": round(44 * first / (f * 1e-3) / 8e12, 3),
                           "scan_frac_of_8TBs": round(44 * n_rows / (min(ms[1:]) * 1e-3) / 8e12, 3),
                           "open_rows_last_chunk": n_open, "bf_hit_rows": n_hit, "index_build_s": round(build_s, 1)}), flush=True)
