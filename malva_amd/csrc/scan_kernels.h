@@ -1022,56 +1022,56 @@ __global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__rest
     sh_hist[0][threadIdx.x] = sh_hist[1][threadIdx.x] = sh_pos[threadIdx.x] = 0; // (SB_TPB == SB_MAXB)
     __syncthreads();
     u32 parity = 0;
-    typedef unsigned long long __attribute__((ext_vector_type(2))) v2u64;
-    const bool vec_ok = !R12 && ((((uintptr_t)hi | (uintptr_t)lo) & 15) == 0);
     const u32 segcap = (u32)ss.segcap;
     for (u64 base = (u64)blockIdx.x * SB_TILE; base < n; base += (u64)gridDim.x * SB_TILE) {
         u64 tk[SB_ROWS];
         u32 binrank[SB_ROWS]; // bin << 16 | rank inside the bin (a tile holds 16,384 rows), ~0u = no row
-#pragma unroll
-        for (int g = 0; g < SB_ROWS / 2; ++g) { // two adjacent rows per load group
-            const u64 i = base + (u64)g * 2 * SB_TPB + 2 * (u64)threadIdx.x;
-            U128 m[2];
-            bool live[2];
-            if constexpr (R12) { // 24 contiguous bytes: rows i and i + 1 (i is even; the buffer is padded to whole quads of rows)
+        // Two adjacent rows (a "pair") per load group, hashed as they arrive -- with the loads of the pairs AHEAD already
+        // requested: left to itself the compiler sinks every pair's loads to their use (fewest live registers), and a wave
+        // then sits out one whole memory latency per pair, eight per tile, with three other waves on its SIMD to cover it.
+        constexpr int RAW = R12 ? 6 : 8, AHEAD = 3;
+        u32 raw[SB_ROWS / 2][RAW];
+        auto request = [&](int g) { // (no predicate on a load: a pair beyond the table reads the last pair again and is dropped by its row number)
+            u32 (&w)[RAW] = raw[g];
+            u64 i = base + (u64)g * 2 * SB_TPB + 2 * (u64)threadIdx.x; // rows i and i + 1 (i is even)
+            const u64 last = (n - 1) & ~1ULL;
+            i = i < last ? i : last;
+            if constexpr (R12) { // 24 contiguous bytes (the buffer is padded to whole quads of rows)
                 typedef unsigned int __attribute__((ext_vector_type(2))) v2u32;
-                u32 w[6] = {0, 0, 0, 0, 0, 0};
-                if (i < n) {
-                    const v2u32 *src = (const v2u32 *)rows12 + 3 * (i / 2);
+                const v2u32 *src = (const v2u32 *)rows12 + 3 * (i / 2);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const v2u32 v = __builtin_nontemporal_load(src + q);
-                        w[2 * q] = v.x;
-                        w[2 * q + 1] = v.y;
-                    }
+                for (int q = 0; q < 3; ++q) {
+                    const v2u32 v = __builtin_nontemporal_load(src + q);
+                    w[2 * q] = v.x;
+                    w[2 * q + 1] = v.y;
                 }
-                const u32 kmask_hi = (1u << ((2 * r - 64) & 31)) - 1;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    m[j] = U128{w[3 * j] | (u64)w[3 * j + 1] << 32, (u64)(w[3 * j + 2] & kmask_hi)};
-                    live[j] = i + j < n;
-                }
-            } else if (vec_ok && i + 1 < n) {
-                const v2u64 l2 = __builtin_nontemporal_load((const v2u64 *)(lo + i));
-                const v2u64 h2 = __builtin_nontemporal_load((const v2u64 *)(hi + i));
-                m[0] = U128{l2.x, h2.x};
-                m[1] = U128{l2.y, h2.y};
-                live[0] = live[1] = true;
             } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    live[j] = i + j < n;
-                    m[j].lo = live[j] ? __builtin_nontemporal_load(lo + i + j) : 0;
-                    m[j].hi = live[j] ? __builtin_nontemporal_load(hi + i + j) : 0;
-                }
+                const u64 i1 = i + 1 < n ? i + 1 : i;
+                const u64 l0 = __builtin_nontemporal_load(lo + i), h0 = __builtin_nontemporal_load(hi + i);
+                const u64 l1 = __builtin_nontemporal_load(lo + i1), h1 = __builtin_nontemporal_load(hi + i1);
+                w[0] = (u32)l0, w[1] = (u32)(l0 >> 32), w[2] = (u32)h0, w[3] = (u32)(h0 >> 32);
+                w[4] = (u32)l1, w[5] = (u32)(l1 >> 32), w[6] = (u32)h1, w[7] = (u32)(h1 >> 32);
             }
+        };
+#pragma unroll
+        for (int g = 0; g < AHEAD; ++g) request(g);
+        const u32 kmask_hi = (1u << ((2 * r - 64) & 31)) - 1; // compact rows: bits of the k-mer in the third dword, the count above them
+#pragma unroll
+        for (int g = 0; g < SB_ROWS / 2; ++g) {
+            if (g + AHEAD < SB_ROWS / 2) request(g + AHEAD);
+            asm volatile("" ::: "memory"); // (the requests stay in front of this pair's arithmetic)
+            const u64 i = base + (u64)g * 2 * SB_TPB + 2 * (u64)threadIdx.x;
+            const u32 (&w)[RAW] = raw[g];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const U128 c = canon_sub(m[j], mform_to_lform(m[j], r), r, off, k);
+                U128 m;
+                if constexpr (R12) m = U128{w[3 * j] | (u64)w[3 * j + 1] << 32, (u64)(w[3 * j + 2] & kmask_hi)};
+                else m = U128{w[4 * j] | (u64)w[4 * j + 1] << 32, w[4 * j + 2] | (u64)w[4 * j + 3] << 32};
+                const U128 c = canon_sub(m, mform_to_lform(m, r), r, off, k);
                 const u64 idx = mod_size(xxh3_packed_k<KC>(c, k, sh_lut), bf.mod);
                 tk[2 * g + j] = (idx << ss.row_bits) | (i + j);
                 const u32 bin = (u32)(idx >> ss.bin_shift);
-                binrank[2 * g + j] = live[j] ? (bin << 16) | atomicAdd(&sh_hist[parity][bin], 1u) : ~0u;
+                binrank[2 * g + j] = i + j < n ? (bin << 16) | atomicAdd(&sh_hist[parity][bin], 1u) : ~0u;
             }
         }
         __syncthreads(); // 1: the tile's counts are complete (and the previous tile has left the sorted array)
