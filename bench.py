@@ -79,6 +79,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-variants", type=float, default=2e5)
     ap.add_argument("--sustained-s", type=float, default=2.0, help="length of the sustained leg (back-to-back steps after the timed region; 0 = skip)")
     ap.add_argument("--no-strong-c4", action="store_true", help="N > 1, default workload: skip the strong_c4 leg")
+    ap.add_argument("--no-c4-leg", action="store_true", help="N = 1, default workload: skip the whole-genome leg (c4_whole in the JSON line)")
+    ap.add_argument("--c4-leg-kmers", type=float, default=3e9)
+    ap.add_argument("--c4-leg-variants", type=float, default=8e7)
+    ap.add_argument("--c4-parity-records", type=float, default=5e5, help="records per slice of the whole-genome parity check (three slices: head, middle, tail; 0 = skip)")
+    ap.add_argument("--c4-parity-rows", type=float, default=8e6, help="rows of each slice's own k-mer table (its donor's windows + random rows)")
     ap.add_argument("--no-c5-leg", action="store_true", help="N = 1, default workload: skip the reduced C5 leg (general_blocks_c5 in the JSON line)")
     ap.add_argument("--c5-leg-clusters", type=float, default=6e4, help="clusters of the reduced C5 leg (6e4 ~ 2.1e5 records)")
     ap.add_argument("--c5-leg-kmers", type=float, default=2e7)
@@ -93,6 +98,7 @@ def parse_args(argv=None):
     ap.add_argument("--scan-ablate", type=int, default=0, help="profiling only (results invalid): filter-kernel ablation mask")
     ap.add_argument("--launch-check", action="store_true",
                     help="print this rank's launch environment as one JSON line and exit before anything touches a GPU (tests of the self-launch)")
+    ap.add_argument("--launch-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests of the self-launch: this rank exits 3 at once, the others would wait a minute
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and reduce over gloo: exercises the multi-rank code path on a 1-GPU box (numbers meaningless)")
     args = ap.parse_args(argv)
@@ -117,9 +123,32 @@ def self_launch(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    # all ranks are watched together: the first one that fails takes the others down with it (they would otherwise sit in a
+    # barrier or a collective until the backend's timeout), and the launcher returns its code
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
+            if rc:      # give the terminated ranks a moment, then make sure
+                deadline = time.time() + 10
+                while live and time.time() < deadline:
+                    live = [q for q in live if q.poll() is None]
+                    time.sleep(0.05)
+                for q in live:
+                    q.kill()
+                for q in live:
+                    q.wait()
+                live = []
     return rc
 
 
@@ -133,6 +162,24 @@ class Job:
 
     def __init__(self, workload, args, rank, world, local, torch, dist, haploid=False, kmers=None, variants=None, b=None, strong=None, clusters=None,
                  plant_records=None):
+        # Building a job is local work (panel, index, table) followed, for N > 1, by collectives (the exchange's bring-up).  A rank
+        # that fails in the local part must not leave its peers waiting in those: every rank reports, and all give up together.
+        err = None
+        try:
+            self._build(workload, args, rank, world, local, torch, dist, haploid, kmers, variants, b, strong, clusters, plant_records)
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+        if world > 1:
+            t = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cpu" if args.rehearse_on_one_gpu else torch.device("cuda", local))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()) and err is None:
+                err = RuntimeError("another rank could not build the %s job" % workload)
+        if err is not None:
+            raise err
+        if world > 1:
+            self._bring_up_exchange()
+
+    def _build(self, workload, args, rank, world, local, torch, dist, haploid, kmers, variants, b, strong, clusters, plant_records):
         from malva_amd import BF_ALT, BF_CTX, Context, synth
         from malva_amd.dist import alias_int32, shard_range
         self.workload, self.args, self.rank, self.world, self.torch, self.dist = workload, args, rank, world, torch, dist
@@ -245,6 +292,11 @@ class Job:
             self.d_goff = dev_i64((3 * np.arange(self.n_vars + 1)).astype(np.uint64))       # biallelic diploid: 3 genotypes per variant
             self.d_probs = torch.zeros(3 * self.n_vars, dtype=torch.float64, device=dev)   # normalised likelihoods (GTS) + workspace
             self.n_genotypes = 3 * self.n_vars
+            # the record loop of the step is the GENERAL resident path (block cut on the device, panel GT gathered by the lone tier,
+            # likelihoods): the same records as a FlatPanel.  The fused lone-variant entry (mg_call_isolated_device, fed masks the host
+            # precomputed) stays as a named extra: kernels_ms.record_loop_isolated
+            from malva_amd.resident import ResidentPanel
+            self.rp = ResidentPanel(synth.flat_from_snp_panel(sub), dev, haploid=False)
         else:
             from malva_amd.resident import ResidentPanel
             cuts = self.panel.split_points(world)
@@ -283,8 +335,6 @@ class Job:
         self.exchange = "none"
         self.native = False
         self.packed_steps = []
-        if world > 1:
-            self._bring_up_exchange()
 
     def _bring_up_exchange(self):
         args, rank, world, torch, dist, ctx, dev = self.args, self.rank, self.world, self.torch, self.dist, self.ctx, self.dev
@@ -322,15 +372,16 @@ class Job:
         else:
             self.ctx.kmc_scan_device(self.d_hi.data_ptr(), self.d_lo.data_ptr(), self.d_cnt.data_ptr(), n)
 
-    def call(self, n=None):
-        """the record loop on this rank's records (the first n of them)"""
-        if self.flat:
-            self.rp.call_step(self.ctx)
-        else:
-            n = self.n_vars if n is None else n
-            self.ctx.call_isolated_device(n, self.d_pos.data_ptr(), self.d_vo.data_ptr(), self.d_ao.data_ptr(), self.d_pool.data_ptr(), self.d_freq.data_ptr(),
-                                          self.d_pm.data_ptr(), self.d_fl.data_ptr(), 0.001, 200, False, self.d_cov.data_ptr(), self.d_g1.data_ptr(),
-                                          self.d_g2.data_ptr(), self.d_gq.data_ptr(), self.d_st.data_ptr(), self.d_probs.data_ptr(), self.d_goff.data_ptr())
+    def call(self):
+        """the record loop on this rank's records: mg_cut_blocks_device -> mg_cover_blocks_device -> mg_genotype_device"""
+        self.rp.call_step(self.ctx)
+
+    def call_isolated(self, n=None):
+        """c3 only: the fused lone-variant entry on the first n records"""
+        n = self.n_vars if n is None else n
+        self.ctx.call_isolated_device(n, self.d_pos.data_ptr(), self.d_vo.data_ptr(), self.d_ao.data_ptr(), self.d_pool.data_ptr(), self.d_freq.data_ptr(),
+                                      self.d_pm.data_ptr(), self.d_fl.data_ptr(), 0.001, 200, False, self.d_cov.data_ptr(), self.d_g1.data_ptr(),
+                                      self.d_g2.data_ptr(), self.d_gq.data_ptr(), self.d_st.data_ptr(), self.d_probs.data_ptr(), self.d_goff.data_ptr())
 
     def step(self):
         from malva_amd.dist import allreduce_counters_, allreduce_counters_packed_
@@ -400,44 +451,45 @@ class Job:
     def kernel_times(self, reps):
         """per-kernel durations outside the timed region, same launches: HIP events on the launch stream"""
         torch, ctx = self.torch, self.ctx
-        scan_ms, call_ms, cut_ms, geno_ms, blk = [], [], [], [], []
+        scan_ms, call_ms, cut_ms, geno_ms, blk, iso_ms = [], [], [], [], [], []
         for _ in range(reps):
             ctx.counters_reset()
             self.scan(self.n_rows)
             scan_ms.append(ctx.scan_stats())
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-            if self.flat:
-                self.rp.cut(ctx)
-                ev[1].record()
-                self.rp.cover(ctx)
-                ev[2].record()
-                self.rp.genotype(ctx)
-                ev[3].record()
-                ev[3].synchronize()
-                cut_ms.append(ev[0].elapsed_time(ev[1]))
-                geno_ms.append(ev[2].elapsed_time(ev[3]))
-                blk.append(ctx.blocks_stats())
-            else:
-                self.call()
-                ev[3].record()
-                ev[3].synchronize()
+            self.rp.cut(ctx)
+            ev[1].record()
+            self.rp.cover(ctx)
+            ev[2].record()
+            self.rp.genotype(ctx)
+            ev[3].record()
+            ev[3].synchronize()
+            cut_ms.append(ev[0].elapsed_time(ev[1]))
+            geno_ms.append(ev[2].elapsed_time(ev[3]))
+            blk.append(ctx.blocks_stats())
             call_ms.append(ev[0].elapsed_time(ev[3]))
+            if not self.flat:       # the fused lone-variant entry on the same counters (it ends the records' copies' validity: last)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.call_isolated()
+                e1.record()
+                e1.synchronize()
+                iso_ms.append(e0.elapsed_time(e1))
         out = {"scan_filter": float(np.mean([m[0] for m in scan_ms])), "scan_probe": float(np.mean([m[1] for m in scan_ms])),
                "scan_hits": float(np.mean([m[2] for m in scan_ms])), "record_loop": float(np.mean(call_ms)),
                "gate_open_rows": int(scan_ms[-1][3]), "bf_hit_rows": int(scan_ms[-1][4])}
-        if self.flat:
-            out.update({"cut_blocks": float(np.mean(cut_ms)), "tier1_lone": float(np.mean([b[0] for b in blk])),
-                        "tier2_flat": float(np.mean([b[1] for b in blk])), "tier3_workgroup": float(np.mean([b[2] for b in blk])),
-                        "genotype": float(np.mean(geno_ms)), "general_records": blk[-1][3], "lone_signature_kmers": blk[-1][4],
-                        "general_signature_kmers": blk[-1][5], "tier3_records": blk[-1][6]})
+        out.update({"cut_blocks": float(np.mean(cut_ms)), "tier1_lone": float(np.mean([b[0] for b in blk])),
+                    "tier2_flat": float(np.mean([b[1] for b in blk])), "tier3_workgroup": float(np.mean([b[2] for b in blk])),
+                    "genotype": float(np.mean(geno_ms)), "general_records": blk[-1][3], "lone_signature_kmers": blk[-1][4],
+                    "general_signature_kmers": blk[-1][5], "tier3_records": blk[-1][6]})
+        if iso_ms:
+            out["record_loop_isolated"] = float(np.mean(iso_ms))
         return out
 
     def results(self):
-        if self.flat:
-            r = self.rp.results()
-            return r["g1"], r["g2"], r["gq"], int(r["overflow"].sum())
-        return self.d_g1.cpu().numpy(), self.d_g2.cpu().numpy(), self.d_gq.cpu().numpy(), 0
+        r = self.rp.results()
+        return r["g1"], r["g2"], r["gq"], int(r["overflow"].sum())
 
     def close(self):
         self.ctx.close()
@@ -503,11 +555,17 @@ def cpu_leg(job, log_rank):
         ocov, og1, og2, ogq = ocapi.call_isolated(obf, omap, job.panel.genome, sub.pos[:nv], sub.allele_off[:2 * nv + 1], sub.var_allele_off[:nv + 1],
                                                   sub.pool[:2 * nv], sub.freq[:2 * nv], sub.present_mask[:nv], sub.flags[:nv], K, 0.001, 200, False)
         cpu_geno_s = time.perf_counter() - t0
-        job.call(nv)
+        from malva_amd.resident import ResidentPanel
+        hp = ResidentPanel(synth.flat_from_snp_panel(synth.head(sub, nv)), job.dev, haploid=False)      # the general resident path, as the step runs it
+        hp.call_step(ctx)
+        r = hp.results()
+        parity["gt_gq_cov_equal"] = bool(np.array_equal(r["g1"], og1) and np.array_equal(r["g2"], og2) and np.array_equal(r["gq"], ogq)
+                                         and np.array_equal(r["cov"], ocov) and not r["overflow"].any())
+        job.call_isolated(nv)                                                                          # and the fused lone-variant entry
         torch.cuda.synchronize()
-        parity["gt_gq_cov_equal"] = bool(np.array_equal(job.d_g1[:nv].cpu().numpy(), og1) and np.array_equal(job.d_g2[:nv].cpu().numpy(), og2)
-                                         and np.array_equal(job.d_gq[:nv].cpu().numpy(), ogq)
-                                         and np.array_equal(job.d_cov[:2 * nv].cpu().numpy().view(np.uint32), ocov))
+        parity["isolated_entry_equal"] = bool(np.array_equal(job.d_g1[:nv].cpu().numpy(), og1) and np.array_equal(job.d_g2[:nv].cpu().numpy(), og2)
+                                              and np.array_equal(job.d_gq[:nv].cpu().numpy(), ogq)
+                                              and np.array_equal(job.d_cov[:2 * nv].cpu().numpy().view(np.uint32), ocov))
         what = "%d variants through its loop-B restatement (lone variants)" % nv
     else:
         nv = sub.split_points(max(1, sub.n // max(nv, 1)))[1] if nv < sub.n else sub.n      # a whole number of blocks
@@ -549,6 +607,82 @@ def cpu_leg(job, log_rank):
     return base, parity
 
 
+def c4_slice_parity(job, log_rank):
+    """Parity of the whole-genome job at its full index: three slices of the panel (head, middle, tail -- whole blocks; the
+    middle and tail lie beyond position 2^24, where are_near runs in float) through the oracle.  The oracle cannot build the
+    8e7-record index or scan 3e9 rows in the time a bench has, and does not have to: `bf` and `context_bf` are the device's
+    bits imported whole (their parity is the index tests' business), the exact map holds the slice's own keys (the oracle's
+    enumeration of the slice), and both sides scan the slice's OWN k-mer table -- the donor's windows around every record of
+    the slice plus random rows -- from zeroed counters, through the form of the scan the step uses.  Compared: every bf
+    counter, and cut / coverage / GT / GQ of every record of the slice."""
+    from malva_amd import BF_ALT, BF_CTX, synth
+    from malva_amd.resident import ResidentPanel
+    from oracle import capi as ocapi
+    args, ctx, K, R, torch, p = job.args, job.ctx, job.K, job.R, job.torch, job.panel
+    want = int(args.c4_parity_records)
+    if want <= 0:
+        return None
+    t_all = time.perf_counter()
+    log(log_rank, "c4 parity: importing the device-built filter bits into the oracle ...")
+    obf, octx = ocapi.BF(job.bf_bits), ocapi.BF(job.bf_bits)
+    _, _, words, _ = ctx.bf_export(BF_ALT)
+    obf.load_words(words)
+    _, _, words, _ = ctx.bf_export(BF_CTX)
+    octx.load_words(words)
+    del words
+    obf.switch_mode(); octx.switch_mode()
+    cuts = sorted(set(p.split_points(max(3, p.n // max(want, 1)))))      # (whole blocks; a cut that found no block boundary nearby repeats its neighbour)
+    picks = sorted({0, (len(cuts) - 1) // 2, len(cuts) - 2})
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    res = {"slices": [], "all_equal": True, "records": 0, "rows": 0}
+    cpu_s = 0.0
+    for q in picks:
+        a, b = cuts[q], cuts[q + 1]
+        sl = p.slice(a, b)
+        t0 = time.perf_counter()
+        off, bc = ocapi.cut_blocks(sl.pos, sl.ref_size, sl.min_size, sl.contig_id, K)
+        omap, sink = ocapi.KMAP(), ocapi.BF(1 << 16)
+        ocapi.index_blocks(sink, omap, p.genome, p.contig_base[bc], p.contig_len[bc], off, sl.pos, sl.ref_size, sl.min_size, sl.present, sl.var_allele_off, sl.allele_off,
+                           sl.pool, sl.canon, sl.gt, sl.n_samples, job.haploid, K)
+        cpu_s += time.perf_counter() - t0
+        nr = int(args.c4_parity_rows)
+        tb = synth.device_table_flat(sl, nr, K, R, 4242 + q, job.dev, plant_records=sl.n)
+        ctx.counters_reset()
+        if job.compact:
+            d_rows = torch.zeros(ctx.kmc_rows_bytes(nr) // 4, dtype=torch.int32, device=job.dev)
+            ctx.kmc_pack_rows_device(tb["d_hi"].data_ptr(), tb["d_lo"].data_ptr(), tb["d_cnt"].data_ptr(), nr, d_rows.data_ptr())
+            ctx.kmc_scan_rows_device(d_rows.data_ptr(), nr)
+        else:
+            ctx.kmc_scan_device(tb["d_hi"].data_ptr(), tb["d_lo"].data_ptr(), tb["d_cnt"].data_ptr(), nr)
+        form = "sub-slice form, %d pieces" % ctx.get_option("scan_subs") if ctx.get_option("scan_subs") else "ticket form" if ctx.get_option("scan_tickets") else "direct form"
+        rp = ResidentPanel(sl, job.dev, haploid=job.haploid)
+        rp.call_step(ctx)                      # (reads the records' copies: the vectors stay lazy until the export below)
+        r = rp.results()
+        hi = tb["d_hi"].cpu().numpy().view(np.uint64); lo = tb["d_lo"].cpu().numpy().view(np.uint64); cnt = tb["d_cnt"].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        obf.counts()[:] = 0
+        ocapi.kmc_scan_packed_mt(octx, obf, omap, hi, lo, cnt, K, R, cores)
+        ocov = ocapi.cover_blocks(obf, omap, p.genome, p.contig_base[bc], p.contig_len[bc], off, sl.pos, sl.ref_size, sl.min_size, sl.present, sl.var_allele_off,
+                                  sl.allele_off, sl.pool, sl.canon, sl.gt, sl.n_samples, job.haploid, K)
+        og1, og2, ogq = ocapi.genotype_panel(ocov, sl.freq, sl.var_allele_off, 0.001, 200, job.haploid)
+        cpu_s += time.perf_counter() - t0
+        _, _, _, counts = ctx.bf_export(BF_ALT)
+        eq = {"bf_counters_equal": bool(np.array_equal(counts, obf.counts())), "cuts_equal": bool(np.array_equal(r["blk_var_off"], off)),
+              "cov_equal": bool(np.array_equal(r["cov"], ocov)), "gt_gq_equal": bool(np.array_equal(r["g1"], og1) and np.array_equal(r["g2"], og2) and np.array_equal(r["gq"], ogq)),
+              "no_overflow": not bool(r["overflow"].any())}
+        ok = all(eq.values())
+        res["slices"].append({"records": [int(a), int(b)], "max_pos": int(sl.pos.max()), "beyond_2_24": bool(sl.pos.max() > (1 << 24)), "rows": nr, "site_rows": int(tb["n_site"]),
+                              "covered_alleles": int((ocov > 0).sum()), "non_reference_calls": int(((og1 > 0) | (og2 > 0)).sum()), "scan_form": form, **eq})
+        res["all_equal"] = res["all_equal"] and ok
+        res["records"] += int(b - a)
+        res["rows"] += nr
+        del tb, rp
+    res["oracle_cpu_s"] = cpu_s
+    res["seconds"] = time.perf_counter() - t_all
+    ctx.counters_reset()
+    return res
+
+
 def traffic_of(job):
     """HBM bytes per launch of the filter kernel cannot be counted from inside this process: it comes from the rocprofv3 PMC
     passes of tools/profile_gpu.sh on this same command, committed with the profile it was derived from"""
@@ -566,12 +700,17 @@ def record(job, elapsed, steps, warmup, kt, sustained):
     args, ctx, K, R, world = job.args, job.ctx, job.K, job.R, job.world
     total_kmers = job.total_rows * steps
     total_vars = job.n_vars_total * steps
-    rows_per_launch = min(job.n_rows, 1 << 27)      # the scan walks the table in chunks of 2^27 rows; the first is timed
+    rows_per_launch = min(job.n_rows, 1 << 27)      # the scan walks the table in launch groups of 2^27 rows; mg_scan_stats times every one of them and
+                                                    # gives the durations per group of this many rows, averaged over all groups (= rocprofv3's per-kernel averages)
+    n_groups = (job.n_rows + (1 << 27) - 1) >> 27
     filt, scan_sum = kt["scan_filter"], kt["scan_filter"] + kt["scan_probe"] + kt["scan_hits"]
     ach_filter = SCAN_BYTES_PER_KMER * rows_per_launch / (filt * 1e-3) / 1e9
     ach_scan = SCAN_BYTES_PER_KMER * rows_per_launch / (scan_sum * 1e-3) / 1e9
     spec = "%d,%d" % (K, R) if (K, R) in ((35, 43), (35, 63)) else "0,0"
-    if ctx.get_option("scan_tickets"):
+    if ctx.get_option("scan_subs"):
+        fname = "scan_sub_sort_kernel<%s> + scan_sub_gate_kernel (sub-slice form, %d pieces of the gate; the two passes summed)" % (spec, ctx.get_option("scan_subs"))
+        sname = "scan_sub_sort + scan_sub_gate + scan_sub_probe (probe and hit pass in one kernel)"
+    elif ctx.get_option("scan_tickets"):
         fname = "scan_ticket_sort_kernel<%s> + scan_ticket_gate_kernel (ticket form, %d gate slices; the two passes summed)" % (spec, ctx.get_option("scan_tickets"))
         sname = "scan_ticket_sort + scan_ticket_gate + scan_probe + scan_hits"
     elif ctx.get_option("scan_bins"):
@@ -584,15 +723,22 @@ def record(job, elapsed, steps, warmup, kt, sustained):
     # the three kernels' counted HBM bytes (profiles/traffic_scan_c3.json: FETCH_SIZE / WRITE_SIZE passes at HEAD), when this IS that workload
     scan_traffic, scan_tsrc = None, None
     t3 = os.path.join(ROOT, "profiles", "traffic_scan_c3.json")
-    if job.compact and os.path.exists(t3) and not job.args.scan_ablate and not ctx.get_option("scan_tickets") and not ctx.get_option("scan_bins"):
+    if job.compact and os.path.exists(t3) and not job.args.scan_ablate and not ctx.get_option("scan_tickets") and not ctx.get_option("scan_bins") and not ctx.get_option("scan_subs"):
         t = json.load(open(t3))
         if t.get("units_per_launch") == job.n_rows and t.get("bf_bits") == job.bf_bits and (K, R) == (35, 43):
             scan_traffic, scan_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_scan_c3.json (rocprofv3 PMC)"
+    t4 = os.path.join(ROOT, "profiles", "traffic_scan_c4.json")     # the whole-genome table: FETCH_SIZE / WRITE_SIZE passes over the sub-slice form's three kernels
+    if job.workload == "c4" and job.compact and os.path.exists(t4) and not job.args.scan_ablate and ctx.get_option("scan_subs"):
+        t = json.load(open(t4))
+        if t.get("rows") == job.n_rows and t.get("bf_bits") == job.bf_bits and t.get("panel_variants") == job.n_vars_total:
+            scan_traffic, scan_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_scan_c4.json (rocprofv3 PMC, per launch group of %d rows)" % t["units_per_launch"]
     # the whole H10 loop (filter + probe + hit kernels, summed): the fraction SURVEY 8(d)'s 44 B/k-mer budget is about
     roof_scan = {"kernel": sname, "bound": "hbm", "achieved": ach_scan, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_scan / HBM_PEAK_GBS,
                  "traffic": scan_traffic, "traffic_source": scan_tsrc, "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch,
                  "bytes_per_unit": SCAN_BYTES_PER_KMER, "units_per_launch": rows_per_launch, "avg_launch_ms": scan_sum,
-                 "note": "the three kernels of one scan chunk, back to back on one stream (roofline_filter: the filter kernel alone)"}
+                 "launch_groups": n_groups,
+                 "note": "the kernels of one scan launch group, back to back on one stream, averaged over the table's %d groups (roofline_filter: the passes "
+                         "in front of the probe kernel alone)" % n_groups}
     roof_filter = {"kernel": fname, "bound": "hbm", "achieved": ach_filter, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_filter / HBM_PEAK_GBS,
                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": SCAN_BYTES_PER_KMER * rows_per_launch,
                    "bytes_per_unit": SCAN_BYTES_PER_KMER, "units_per_launch": rows_per_launch, "avg_launch_ms": filt}
@@ -627,6 +773,9 @@ def record(job, elapsed, steps, warmup, kt, sustained):
         "roofline_filter": roof_filter,
         "kernels_ms": kt,
         "pack_rows_ms": job.pack_ms,
+        # the same step with the SoA -> 12-byte-row conversion counted in (no pipeline stage produces compact rows today: see DESIGN.md)
+        "ms_per_step_incl_pack": (1e3 * elapsed / steps + job.pack_ms) if job.pack_ms is not None else None,
+        "value_incl_pack": (job.total_rows / (elapsed / steps + job.pack_ms * 1e-3)) if job.pack_ms is not None else None,
         "index_build_s": job.index_s,
         "sustained": sustained,
     }
@@ -639,9 +788,11 @@ def record(job, elapsed, steps, warmup, kt, sustained):
                                   "frac": alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
                                   "bytes_per_unit": "64 + 36 K + 8 G (SURVEY 8(d))", "units_per_launch": job.n_vars, "signature_kmers": n_sig,
                                   "genotypes": job.n_genotypes, "avg_launch_ms": loop_ms, "variants_per_s_record_loop_alone": job.n_vars / (loop_ms * 1e-3)}
-        if loop_ms > scan_sum:     # the record loop is the larger part of this workload's step
+        if loop_ms > scan_sum * n_groups:     # the record loop is the larger part of this workload's step
             out["roofline"], out["roofline_scan"] = out["roofline_blocks"], roof_scan
     else:
+        out["roofline_blocks_c3"] = {"kernel": "cut_flags + flag_scatter + panel_lone<false> + genotype (the general resident record loop on isolated SNPs)",
+                                     "avg_launch_ms": kt["record_loop"], "isolated_entry_ms": kt.get("record_loop_isolated")}
         out["genotype_roofline"] = {"achieved": GENO_BYTES_PER_SNP * job.n_vars / (kt["record_loop"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": GENO_BYTES_PER_SNP * job.n_vars / (kt["record_loop"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_unit": GENO_BYTES_PER_SNP}
     return out
@@ -652,6 +803,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    if args.launch_fail_rank >= 0:
+        if int(os.environ.get("RANK", "0")) == args.launch_fail_rank:
+            sys.exit(3)
+        time.sleep(60)
+        return
     if args.launch_check:
         if int(os.environ.get("RANK", "0")) == 0:
             print(json.dumps({"launch_check": True, "world": int(os.environ.get("WORLD_SIZE", "1")), "master": os.environ.get("MASTER_ADDR"),
@@ -678,10 +834,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        import datetime
+        patience = datetime.timedelta(minutes=10)       # (a rank that died leaves the others in a collective: fail in minutes, not after the backends' half hour)
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=patience)
     # one explicit stream for the library's kernels AND torch's work on the aliased counters (a NULL handle would
     # mean the library's private stream: torch's default stream has handle 0)
     work_stream = torch.cuda.Stream(device=dev)
@@ -734,34 +892,57 @@ def main():
                 "overflow_records": n_ovf, "parity_sample": par, "cpu_variants_per_s": cpu and cpu["variants_per_s"], "config": rec["config"]["workload"]}
             lj.close()
         out["general_blocks_c5"] = leg
+    if world == 1 and args.workload == "c3" and not args.no_c4_leg and not args.scan_ablate:
+        # BASELINE config C4 (whole genome: 3e9 k-mers against the 8e7-record index, b=16) on this one GPU -- the per-GPU rate of
+        # the 8-GPU configuration too, whose index is replicated: step, kernel times, roofline of the scan and of the record
+        # loop, and parity of three slices of the panel at the full index
+        cj = Job("c4", args, rank, world, local, torch, dist, kmers=args.c4_leg_kmers, variants=args.c4_leg_variants, b=16, strong=True)
+        cst = max(2, min(args.steps, 5))
+        el = cj.timed(cst, 1)
+        ckt = cj.kernel_times(2)
+        _, _, _, n_ovf = cj.results()
+        crec = record(cj, el, cst, 1, ckt, None)
+        out["c4_whole"] = {k_: crec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "steps", "warmup", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_filter",
+                                                   "roofline_blocks", "pack_rows_ms", "ms_per_step_incl_pack", "index_build_s")}
+        out["c4_whole"]["roofline_scan"] = crec.get("roofline_scan", crec["roofline"])
+        out["c4_whole"]["overflow_records"] = n_ovf
+        out["c4_whole"]["parity_slices"] = c4_slice_parity(cj, rank) if args.cpu_sample > 0 else None
+        cj.close()
     # (under --rehearse-on-one-gpu the leg runs only at explicitly reduced sizes: N whole-genome indexes do not share one GPU)
     if world > 1 and args.workload == "c3" and not args.no_strong_c4 and (not args.rehearse_on_one_gpu or args.strong_c4_kmers < 1e9):
         # north_star's whole-genome claim on the same ranks: the 3e9-row table cut N ways against the 8e7-SNP index
-        ref1 = None
-        p1 = os.path.join(ROOT, "profiles", "r03_bench_c4_whole_1gpu.json")
-        if not os.path.exists(p1):
-            p1 = os.path.join(ROOT, "profiles", "r02_bench_c4_whole_1gpu.json")
-        if os.path.exists(p1):
-            ref1 = json.load(open(p1))
-        try:    # (a failure every rank meets alike -- memory, a refused size -- must not cost the line already measured)
+        def all_ok(ok):
+            """every rank abandons the leg together: a failure on one rank only (an out-of-memory, say) must not leave its peers inside a collective"""
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if args.rehearse_on_one_gpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        sj, err = None, None
+        try:
             sj = Job("c4", args, rank, world, local, torch, dist, kmers=args.strong_c4_kmers, variants=args.strong_c4_variants, b=16, strong=True)
-            el = sj.timed(max(2, min(args.steps, 5)), 1)
-            skt = sj.kernel_times(3)
-            _, _, _, n_ovf = sj.results()
-            if rank == 0:
-                st = max(2, min(args.steps, 5))
-                srec = record(sj, el, st, 1, skt, None)
-                out["strong_c4"] = {k_: srec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_blocks")}
-                out["strong_c4"]["overflow_records"] = n_ovf
-                same_job = (args.strong_c4_kmers, args.strong_c4_variants) == (3e9, 8e7) and not args.rehearse_on_one_gpu
-                if ref1 and same_job:      # (a reduced or rehearsed leg has no one-GPU line to be compared with)
-                    out["strong_c4"]["one_gpu_reference"] = {"file": os.path.relpath(p1, ROOT), "ms_per_step": ref1["ms_per_step"],
-                                                             "same_panel_recipe": "r03" in os.path.basename(p1)}
-                    out["strong_c4"]["speedup_vs_one_gpu"] = ref1["ms_per_step"] / srec["ms_per_step"]
-            sj.close()
         except Exception as e:      # noqa: BLE001 -- reported in the line, never silent
+            err = "%s: %s" % (type(e).__name__, e)
+        if all_ok(sj is not None):
+            st = max(2, min(args.steps, 5))
+            el = skt = n_ovf = None
+            try:
+                el = sj.timed(st, 1)        # (its collectives are matched on every rank: all of them got here)
+                skt = sj.kernel_times(3)
+                _, _, _, n_ovf = sj.results()
+            except Exception as e:      # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
             if rank == 0:
-                out["strong_c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                if err is None:
+                    srec = record(sj, el, st, 1, skt, None)
+                    out["strong_c4"] = {k_: srec[k_] for k_ in ("value", "variants_per_s", "ms_per_step", "n_gpus", "scaling", "config", "kernels_ms", "roofline", "roofline_blocks")}
+                    out["strong_c4"]["roofline_scan"] = srec.get("roofline_scan", srec["roofline"])
+                    out["strong_c4"]["overflow_records"] = n_ovf
+                    out["strong_c4"]["one_gpu_reference"] = "the c4_whole leg of this driver's N = 1 line (same job on one GPU); no speed-up is computed here"
+                else:
+                    out["strong_c4"] = {"error": err}
+        elif rank == 0:
+            out["strong_c4"] = {"error": err or "the job could not be built on some rank (see stderr)"}
+        if sj is not None:
+            sj.close()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

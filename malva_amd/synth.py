@@ -405,6 +405,23 @@ class FlatPanel:
         return cuts
 
 
+def flat_from_snp_panel(panel: "Panel") -> FlatPanel:
+    """An snp_panel (isolated biallelic SNPs on one sequence, what mg_call_isolated takes) as the FlatPanel of the general record
+    loop: one sequence, ref_size = min_size = 1, every record present, two phased samples 0|1 and 0|0 (both alleles present, as
+    the Panel's present_mask = 3 says).  Same records, same frequencies: the general path must give what the lone path gives."""
+    n = panel.n
+    gt = np.empty((n, 2), dtype=np.uint16)
+    gt[:, 0] = (1 << 7) | (1 << 14)       # 0|1
+    gt[:, 1] = 1 << 14                    # 0|0
+    vo = panel.var_allele_off.astype(np.uint32)
+    ao = panel.allele_off.astype(np.uint32)
+    canon = np.tile(np.array([0, 1], dtype=np.uint8), n)
+    return FlatPanel(genome=panel.genome, contig_names=["1"], contig_base=np.zeros(1, dtype=np.uint64), contig_len=np.array([panel.genome.size], dtype=np.uint32),
+                     contig_id=np.zeros(n, dtype=np.uint32), pos=panel.pos.astype(np.int32), ref_size=np.ones(n, dtype=np.uint32), min_size=np.ones(n, dtype=np.uint32),
+                     present=np.ones(n, dtype=np.uint8), var_allele_off=vo, allele_off=ao, pool=panel.pool, canon=canon, freq=panel.freq, gt=gt, n_samples=2,
+                     donor_gt=panel.donor_gt)
+
+
 def _canon_of(var_allele_off, allele_off, pool):
     """first allele of the variant with the same text, per slot (Variant::get_allele_index, variant.hpp:228-240); numpy, vectorised
     over the common case (all alleles of a variant differ in their first 8 bytes or length) with a loop for the rest"""

@@ -41,3 +41,13 @@ def test_workload_defaults():
     a = bench.parse_args([])
     assert (a.kmers, a.variants, a.b, a.r, a.gpus) == (1e8, 1e6, 4, 43, 1)
     assert bench.blocks_bytes(10, 20, 30) == 64 * 10 + 36 * 20 + 8 * 30
+
+
+def test_self_launch_ends_all_ranks_when_one_fails():
+    """a rank that exits non-zero takes the others down with it (they would sit in a collective until the backend's timeout)
+    and the launcher returns a non-zero code at once, not after the survivors' minute"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-fail-rank", "1"], capture_output=True, text=True, timeout=50, env=env)
+    assert r.returncode == 3 and time.time() - t0 < 30

@@ -110,6 +110,25 @@ def test_c3_full_size_1e8_rows_1e6_snps_b4():
         ctx.counters_reset(); _scan(ctx, tab, 0, n_rows // 2); first = _snap(counters)
         ctx.counters_reset(); _scan(ctx, tab, n_rows // 2, n_rows)
         assert torch.equal(first + counters, whole)
+        # the same table as compact 12-byte rows (what bench.py's headline scans: scan_filter12_kernel): identical counters from the
+        # whole table, linear, and its two halves (chunk starts are whole quads of rows) sum to the whole
+        d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.kmc_pack_rows_device(*tab.ptrs(), d_rows.data_ptr())
+
+        def scan12(a, b):
+            torch.cuda.synchronize()
+            ctx.kmc_scan_rows_device(d_rows.data_ptr() + 12 * a, b - a)
+            ctx.synchronize()
+        ctx.counters_reset(); scan12(0, n_rows)
+        assert torch.equal(counters, whole)
+        _check_expected(ctx, panel, tab, counters, n_bf)
+        scan12(0, n_rows)
+        assert torch.equal(counters, whole * 2)
+        ctx.counters_reset(); scan12(0, n_rows // 2); first = _snap(counters)
+        ctx.counters_reset(); scan12(n_rows // 2, n_rows)
+        assert torch.equal(first + counters, whole)
+        del d_rows
         # oracle: its own index (built by mo_add_kmers + mo_ref_scan, nothing imported from the device), a 5e6-row sample
         # of the same table, 2e5 variants genotyped
         ns, nv = 5_000_000, 200_000
@@ -144,21 +163,24 @@ def test_c3_full_size_1e8_rows_1e6_snps_b4():
         assert (g1 + g2 > 0).sum() > 1000
 
 
-@pytest.mark.parametrize("n_vars,expect", [(10_000_000, "tickets"), (10_000_000, "two-level"), (80_000_000, "tickets-compact"), (80_000_000, "saturated")])
+@pytest.mark.parametrize("n_vars,expect", [(10_000_000, "subs"), (10_000_000, "tickets"), (10_000_000, "two-level"), (80_000_000, "subs-compact"), (80_000_000, "saturated")])
 def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
     """one GPU's eighth of config C4 (3e9 k-mers / 8) against the replicated index; 38-40 nt spacing as SURVEY 8(d).
-    `tickets` is what the library picks by itself for gates of 32 MiB and more; the forms it replaced stay as options."""
+    `subs` (tickets filed under LDS-sized pieces of the gate) is what the library picks by itself for gates of 32 MiB and more;
+    the forms it replaced stay as options."""
     n_rows, bits, plant = 375_000_000, 16 << 33, 1_000_000
     panel = synth.snp_panel(n_vars, 4242, spacing=40)
     tab = DeviceTable(panel, n_rows, K, R, 9, plant_variants=plant)
     with Context(K, R, bits) as ctx:
-        if not expect.startswith("tickets"):
+        if not expect.startswith("subs"):
+            ctx.set_option("use_sub", 0)
+        if expect != "tickets":
             ctx.set_option("use_tickets", 0)
         build_device_index(ctx, panel, K)
         counters, n_bf, n_map = counters_tensor(ctx)
         assert n_map == n_vars
         d_rows = None
-        if expect == "tickets-compact":  # the table resident as 12-byte rows: what bench.py --strong scans at this size
+        if expect == "subs-compact":  # the table resident as 12-byte rows: what bench.py --strong scans at this size
             d_rows = torch.zeros(ctx.kmc_rows_bytes(n_rows) // 4, dtype=torch.int32, device="cuda:0")
             torch.cuda.synchronize()
             ctx.kmc_pack_rows_device(*tab.ptrs(), d_rows.data_ptr())
@@ -177,8 +199,10 @@ def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
             assert ctx.get_option("pregate_k") >= 1 and ctx.get_option("gate_log2") == 28 and ctx.get_option("scan_bins") == 16
         elif expect == "tickets":        # one 8-byte ticket per row filed under its 2 MiB gate slice
             assert ctx.get_option("gate_log2") == 28 and ctx.get_option("scan_tickets") == 16 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_spilled") == 0
-        elif expect == "tickets-compact":
-            assert ctx.get_option("gate_log2") == 31 and ctx.get_option("scan_tickets") == 128 and ctx.get_option("scan_spilled") == 0
+        elif expect == "subs":           # ... or under its 128 KiB piece of the gate, which is then answered out of LDS
+            assert ctx.get_option("gate_log2") == 28 and ctx.get_option("scan_subs") == 256 and ctx.get_option("scan_tickets") == 0 and ctx.get_option("scan_spilled") == 0
+        elif expect == "subs-compact":   # the gate of a whole-genome index is held to 1,024 pieces: 128 MiB
+            assert ctx.get_option("gate_log2") == 30 and ctx.get_option("scan_subs") == 1024 and ctx.get_option("scan_spilled") == 0
         else:                            # 1.6e8 entries saturate a 4 MiB coarse gate: decided at finalize, scans go straight to the 256 MiB gate
             assert ctx.get_option("pregate_k") == 0 and ctx.get_option("gate_log2") == 31 and ctx.get_option("scan_bins") == 0 and ctx.get_option("scan_tickets") == 0
         _check_expected(ctx, panel, tab, whole, n_bf, n_check=plant)

@@ -119,6 +119,25 @@ def test_scan_sub_slice_form(k, ref_k, bits, gate_log2, words_log2, bin_cap):
                options=[("gate_log2", gate_log2), ("use_sub", 1), ("sub_min_log2", 11), ("sub_words_log2", words_log2), ("scan_bin_cap", bin_cap)])
 
 
+@pytest.mark.parametrize("form", ["direct", "tickets", "partition"])
+@pytest.mark.parametrize("hit_entries", [0, 1])
+def test_scan_hit_list_with_and_without_the_filter_entries(form, hit_entries):
+    """The probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row (use_hit_entries = 1,
+    the default); without it -- what a record table beyond 2^30 records falls back to -- the hit kernel hashes the centre k-mer
+    again and walks to the entry itself.  Both, with the records' counter copies kept (use_record_counters = 2), in the direct,
+    ticket and partition forms: counters equal the oracle's."""
+    options = [("use_hit_entries", hit_entries), ("use_record_counters", 2)]
+    if form == "tickets":
+        options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 1), ("ticket_min_log2", 11)]
+    if form == "partition":
+        options += [("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14)]
+
+    def check(ctx):
+        assert ctx.get_option("use_hit_entries") == hit_entries
+        assert (ctx.get_option("scan_tickets") > 0) == (form == "tickets") and (ctx.get_option("scan_bins") > 0) == (form == "partition")
+    _scan_case(35, 43, 1 << 20, 3000, 150000, 37, after=check, options=options)
+
+
 @pytest.mark.parametrize("k,ref_k", [(31, 41), (35, 63), (21, 22), (33, 64), (17, 17), (11, 19), (16, 24), (9, 9)])   # below 17 the hash takes XXH3's short-input branches
 def test_scan_generic_k(k, ref_k):
     _scan_case(k, ref_k, (1 << 18) + 77, 1500, 60000, 100 + k)
