@@ -388,7 +388,14 @@ class Job:
         self.ctx.counters_reset()
         self.scan(self.n_rows)
         if self.world > 1 and self.native:
-            self.ctx.counters_allreduce()
+            # the exchange on its own stream (RCCL inside the library: 16-bit packed when no partial counter can carry), the
+            # record loop's block cut -- which needs no counters -- beside it, then the rest of the record loop behind it
+            self.ctx.counters_allreduce_begin()
+            self.rp.cut(self.ctx)
+            self.ctx.counters_allreduce_end()
+            self.rp.cover(self.ctx)
+            self.rp.genotype(self.ctx)
+            return
         elif self.world > 1:
             # a large vector is worth halving on the wire; for a small one the guard's extra round trip costs more
             if 4.0 * self.d_counters.numel() >= self.args.pack16_min_mb * (1 << 20):
@@ -485,6 +492,18 @@ class Job:
                     "general_signature_kmers": blk[-1][5], "tier3_records": blk[-1][6]})
         if iso_ms:
             out["record_loop_isolated"] = float(np.mean(iso_ms))
+        if self.world > 1 and self.native:      # the exchange by itself (collective + pack / unpack), and the counter-free work that ran beside it
+            ex = []
+            for _ in range(reps):
+                ctx.counters_reset()
+                self.scan(self.n_rows)
+                ctx.counters_allreduce_begin()
+                ctx.counters_allreduce_end()
+                ex.append(ctx.exchange_stats())
+            out["exchange_ms"] = float(np.mean([e[0] for e in ex]))
+            out["exchange_packed_16bit"] = bool(ex[-1][1])
+            out["overlapped_ms"] = out["cut_blocks"]
+            out["overlap_note"] = "what runs beside the exchange is the block cut alone: tier 1's lookups need the summed counters, and the general list tier 2 walks comes out of tier 1"
         return out
 
     def results(self):

@@ -186,6 +186,19 @@ int mg_comm_destroy(mg_ctx *ctx);
 int mg_comm_info(mg_ctx *ctx, int *rank, int *world, int *backend);
 int mg_counters_allreduce(mg_ctx *ctx);
 int mg_counters_allreduce_all(mg_ctx **ctxs, int n);
+/* Two refinements of the exchange, both inside the library:
+ *   the 16-bit packed form   two counters per 32-bit word on the links when that is exact, i.e. when no rank's partial counter
+ *       exceeds 65535 / world (checked first: a max over the vector, then over the ranks; the plain 32-bit sum runs otherwise).
+ *       Option exchange_pack: 0 never, 1 (default) for vectors of exchange_pack_min_mb (32) megabytes and more, 2 always.
+ *       The call then waits for the guard's answer on the host; mg_get_option("exchange_packed") tells which form ran.
+ *   _begin / _end   the same exchange on a stream of its own: _begin orders it behind what the context's stream holds (the
+ *       scan), _end makes the context's stream wait for it; in between the caller may enqueue what needs no counters (the
+ *       record loop's block cut, mg_cut_blocks_device), which then runs beside the collective.  main.cpp has neither: its
+ *       loop B starts when loop A has ended (main.cpp:500-522).
+ * mg_exchange_stats: duration of the context's most recent exchange (collective + pack / unpack, HIP events on its stream). */
+int mg_counters_allreduce_begin(mg_ctx *ctx);
+int mg_counters_allreduce_end(mg_ctx *ctx);
+int mg_exchange_stats(mg_ctx *ctx, float *ms_out, int *packed_out);
 
 /* ---- per-variant path ----------------------------------------------------- */
 

@@ -102,6 +102,9 @@ def lib():
         "mg_comm_info": [vp, vp, vp, vp],
         "mg_counters_allreduce": [vp],
         "mg_counters_allreduce_all": [C.POINTER(vp), it],
+        "mg_counters_allreduce_begin": [vp],
+        "mg_counters_allreduce_end": [vp],
+        "mg_exchange_stats": [vp, vp, vp],
         "mg_lookup_cover": [vp, vp, sz, sz, vp, vp, sz, vp, sz, vp],
         "mg_genotype": [vp, vp, vp, vp, sz, fl, it, it, vp, vp, vp, vp, vp, vp],
         "mg_cover_blocks": [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, u32, it, vp, vp],
@@ -150,7 +153,7 @@ EXPORTED = ["mg_create", "mg_destroy", "mg_last_error", "mg_set_stream", "mg_syn
             "mg_host_alloc", "mg_host_free", "mg_kmc_set_lut", "mg_kmc_scan_records", "mg_kmc_decode_records",
             "mg_counters_size", "mg_counters_export_device", "mg_counters_import_device", "mg_counters_reset", "mg_counters_view",
             "mg_comm_unique_id", "mg_comm_init", "mg_comm_init_all", "mg_comm_destroy", "mg_comm_info", "mg_counters_allreduce",
-            "mg_counters_allreduce_all", "mg_decode_gt_text", "mg_decode_gt_entries", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
+            "mg_counters_allreduce_all", "mg_counters_allreduce_begin", "mg_counters_allreduce_end", "mg_exchange_stats", "mg_decode_gt_text", "mg_decode_gt_entries", "mg_cut_blocks", "mg_cut_blocks_device", "mg_cover_blocks_device", "mg_index_blocks_device", "mg_genotype_device",
             "mg_index_isolated",
             "mg_lookup_cover", "mg_cover_blocks", "mg_index_blocks", "mg_cover_blocks_sparse", "mg_index_blocks_sparse", "mg_genotype", "mg_reference_upload", "mg_call_isolated", "mg_call_isolated_device",
             "mg_bf_export", "mg_bf_import", "mg_bf_export_sparse", "mg_bf_import_sparse", "mg_map_export", "mg_map_import", "mg_debug_bf_index",
@@ -521,6 +524,19 @@ class Context:
 
     def counters_allreduce(self):
         self._ck(self._L.mg_counters_allreduce(self.h))
+
+    def counters_allreduce_begin(self):
+        """the exchange on a stream of its own, behind what the context's stream holds; counter-free work may follow"""
+        self._ck(self._L.mg_counters_allreduce_begin(self.h))
+
+    def counters_allreduce_end(self):
+        self._ck(self._L.mg_counters_allreduce_end(self.h))
+
+    def exchange_stats(self):
+        """-> (ms of the most recent exchange, 1 if it ran in the 16-bit packed form)"""
+        ms, pk = C.c_float(0), C.c_int(0)
+        self._ck(self._L.mg_exchange_stats(self.h, C.byref(ms), C.byref(pk)))
+        return float(ms.value), int(pk.value)
 
     # per-variant path
     def lookup_cover(self, rows, is_ref, sig_kmer_off, allele_sig_off):

@@ -173,6 +173,16 @@ struct mg_ctx {
     int comm_rank = 0, comm_world = 0;
     std::vector<mg_ctx *> local_group;
     hipEvent_t ev_x = nullptr; // orders the local-group exchange between the contexts' streams
+    // the exchange's own stream (mg_counters_allreduce_begin / _end: what needs no counters runs on the context's stream meanwhile),
+    // its timing events, and the 16-bit packed form: two counters per word on the wire when no rank's partial counter can carry
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_xs[4] = {nullptr, nullptr, nullptr, nullptr}; // scan done / exchange done (ordering), exchange start / end (timing)
+    bool x_pending = false, x_timed = false;
+    int exchange_pack = 1;          // 0 never, 1 vectors of exchange_pack_min_mb and more, 2 always (when exact)
+    int exchange_pack_min_mb = 32;
+    int last_exchange_packed = 0;
+    u32 *d_xmax = nullptr;
+    Scratch s_pack;
     // host-fed scans (mg_kmc_scan, mg_kmc_scan_records): two staging slots, uploads on their own stream beside the scan
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -614,6 +624,11 @@ MG_EXPORT int mg_destroy(mg_ctx *c)
     hipDeviceSynchronize();
     comm_drop(c);
     if (c->ev_x) hipEventDestroy(c->ev_x);
+    for (auto &e : c->ev_xs)
+        if (e) hipEventDestroy(e);
+    if (c->xstream) hipStreamDestroy(c->xstream);
+    hipFree(c->d_xmax);
+    hipFree(c->s_pack.p);
     for (auto &e : c->ev_b)
         if (e) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
@@ -719,6 +734,8 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "use_sub")) c->use_sub = value != 0;
+    else if (!strcmp(name, "exchange_pack")) c->exchange_pack = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
+    else if (!strcmp(name, "exchange_pack_min_mb")) c->exchange_pack_min_mb = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "lazy_vectors")) c->lazy_vectors = value != 0;
     else if (!strcmp(name, "sub_min_log2")) c->sub_min_log2 = (int)value;
     else if (!strcmp(name, "sub_words_log2")) {
@@ -787,6 +804,8 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "scan_tickets")) *value = c->last_tickets;
     else if (!strcmp(name, "scan_subs")) *value = c->last_subs;
     else if (!strcmp(name, "use_sub")) *value = c->use_sub;
+    else if (!strcmp(name, "exchange_pack")) *value = c->exchange_pack;
+    else if (!strcmp(name, "exchange_packed")) *value = c->last_exchange_packed;
     else if (!strcmp(name, "lazy_vectors")) *value = c->lazy_vectors;
     else if (!strcmp(name, "vectors_stale")) *value = c->vec_stale;
     else if (!strcmp(name, "ticket_gate_grid")) *value = c->tkg_grid;
@@ -2002,6 +2021,59 @@ __global__ void __launch_bounds__(TPB) local_sum_kernel(LocalPtrs v, u64 n)
         for (int j = 0; j < v.n; ++j) v.p[j][i] = s;
     }
 }
+// ---- the 16-bit packed form of the exchange --------------------------------------------------------------------------------
+// Two counters travel in one 32-bit word (low and high half).  That is exact iff no half can carry into its neighbour, i.e.
+// iff every rank's every partial counter is <= 65535 / world: checked first (a max over the vector, then over the ranks), the
+// plain 32-bit sum runs otherwise.  Partial counters are small in practice: KMC lists each distinct k-mer once, so a counter
+// receives one count (<= 255) plus those of the few k-mers that share it.  Half the bytes on the links.
+__global__ void __launch_bounds__(TPB) vec_max_kernel(const u32 *__restrict__ v, u64 n, u32 *out)
+{
+    u32 m = 0;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += (u64)gridDim.x * TPB) m = max(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ void __launch_bounds__(TPB) pack16_kernel(const u32 *__restrict__ v, u64 n, u32 *__restrict__ packed)
+{
+    const u64 m = n / 2;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < m + (n & 1); i += (u64)gridDim.x * TPB)
+        packed[i] = i < m ? (v[2 * i] | v[2 * i + 1] << 16) : v[n - 1]; // (an odd last counter travels whole)
+}
+__global__ void __launch_bounds__(TPB) unpack16_kernel(u32 *__restrict__ v, u64 n, const u32 *__restrict__ packed)
+{
+    const u64 m = n / 2;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < m + (n & 1); i += (u64)gridDim.x * TPB) {
+        const u32 w = packed[i];
+        if (i < m) {
+            v[2 * i] = w & 0xFFFFu;
+            v[2 * i + 1] = w >> 16;
+        } else
+            v[n - 1] = w;
+    }
+}
+bool pack_wanted(const mg_ctx *c, u64 nn, int world)
+{
+    if (!c->exchange_pack || nn < 2 || world > 16) return false;
+    return c->exchange_pack == 2 || nn * 4 >= (u64)c->exchange_pack_min_mb << 20;
+}
+// this context's largest counter -> *c->d_xmax (device), on stream `st`
+int local_max(mg_ctx *c, u64 nn, hipStream_t st)
+{
+    if (!c->d_xmax) HIP_TRY(c, hipMalloc(&c->d_xmax, 8));
+    HIP_TRY(c, hipMemsetAsync(c->d_xmax, 0, 4, st));
+    hipLaunchKernelGGL(vec_max_kernel, dim3((unsigned)std::min<u64>(nblocks(nn), 2048u)), dim3(TPB), 0, st, (const u32 *)c->joined, nn, c->d_xmax);
+    HIP_TRY(c, hipGetLastError());
+    return MG_OK;
+}
+int pack_into_scratch(mg_ctx *c, u64 nn, hipStream_t st, u32 **out)
+{
+    void *p;
+    TRY(scratch(c, c->s_pack, (nn / 2 + 1) * 4, &p));
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)std::min<u64>(nblocks(nn / 2 + 1), 4096u)), dim3(TPB), 0, st, (const u32 *)c->joined, nn, (u32 *)p);
+    HIP_TRY(c, hipGetLastError());
+    *out = (u32 *)p;
+    return MG_OK;
+}
 int comm_drop(mg_ctx *c)
 {
     if (c->comm) {
@@ -2118,16 +2190,90 @@ MG_EXPORT int mg_comm_info(mg_ctx *c, int *rank, int *world, int *backend)
     return MG_OK;
 }
 
+namespace {
+// The exchange of one context's counters over its RCCL communicator, enqueued on `st`.  With the packed form the call waits
+// (the host has to see the ranks' largest partial counter to choose the form; every rank sees the same one).
+int exchange_rccl(mg_ctx *c, hipStream_t st)
+{
+    Rccl *R = rccl();
+    const u64 nn = c->bf[MG_BF_ALT].nset + c->map.rows_total;
+    c->last_exchange_packed = 0;
+    if (nn == 0) return MG_OK;
+    bool packed = false;
+    if (pack_wanted(c, nn, c->comm_world)) {
+        TRY(local_max(c, nn, st));
+        NCCL_TRY(c, R, R->AllReduce(c->d_xmax, c->d_xmax, 1, ncclUint32, ncclMax, c->comm, st));
+        u32 mx = 0;
+        HIP_TRY(c, hipMemcpyAsync(&mx, c->d_xmax, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        packed = mx <= 65535u / (u32)c->comm_world;
+    }
+    if (c->x_timed) HIP_TRY(c, hipEventRecord(c->ev_xs[2], st));
+    if (packed) {
+        u32 *pk;
+        TRY(pack_into_scratch(c, nn, st, &pk));
+        NCCL_TRY(c, R, R->AllReduce(pk, pk, nn / 2 + (nn & 1), ncclUint32, ncclSum, c->comm, st));
+        hipLaunchKernelGGL(unpack16_kernel, dim3((unsigned)std::min<u64>(nblocks(nn / 2 + 1), 4096u)), dim3(TPB), 0, st, c->joined, nn, (const u32 *)pk);
+        HIP_TRY(c, hipGetLastError());
+    } else
+        NCCL_TRY(c, R, R->AllReduce(c->joined, c->joined, nn, ncclUint32, ncclSum, c->comm, st));
+    if (c->x_timed) HIP_TRY(c, hipEventRecord(c->ev_xs[3], st));
+    c->last_exchange_packed = packed ? 1 : 0;
+    return MG_OK;
+}
+int exchange_ready(mg_ctx *c)
+{
+    if (!c->comm) return fail(c, MG_ERR_STATE, "no RCCL communicator (mg_comm_init first; contexts sharing a device use mg_counters_allreduce_all)");
+    TRY(ensure_joined(c));
+    for (int i = 0; i < 4; ++i)
+        if (!c->ev_xs[i]) HIP_TRY(c, i < 2 ? hipEventCreateWithFlags(&c->ev_xs[i], hipEventDisableTiming) : hipEventCreate(&c->ev_xs[i]));
+    c->x_timed = true;
+    return MG_OK;
+}
+} // namespace
+
 MG_EXPORT int mg_counters_allreduce(mg_ctx *c)
 {
     const DeviceGuard on_device(c);
     if (!c) return MG_ERR_ARG;
-    if (!c->comm) return fail(c, MG_ERR_STATE, "mg_counters_allreduce: no RCCL communicator (mg_comm_init first; contexts sharing a device use mg_counters_allreduce_all)");
-    TRY(ensure_joined(c));
-    Rccl *R = rccl();
-    const u64 nn = c->bf[MG_BF_ALT].nset + c->map.rows_total;
-    if (nn == 0) return MG_OK;
-    NCCL_TRY(c, R, R->AllReduce(c->joined, c->joined, nn, ncclUint32, ncclSum, c->comm, c->stream));
+    TRY(exchange_ready(c));
+    return exchange_rccl(c, c->stream);
+}
+// The same exchange on a stream of its own: _begin orders it behind everything the context's stream holds so far (the scan),
+// _end makes the context's stream wait for it.  In between the caller may enqueue what needs no counters -- the block cut of the
+// record loop (mg_cut_blocks_device) -- which then runs beside the collective instead of behind it.
+MG_EXPORT int mg_counters_allreduce_begin(mg_ctx *c)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (c->x_pending) return fail(c, MG_ERR_STATE, "mg_counters_allreduce_begin twice without mg_counters_allreduce_end");
+    TRY(exchange_ready(c));
+    if (!c->xstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventRecord(c->ev_xs[0], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->xstream, c->ev_xs[0], 0));
+    TRY(exchange_rccl(c, c->xstream));
+    HIP_TRY(c, hipEventRecord(c->ev_xs[1], c->xstream));
+    c->x_pending = true;
+    return MG_OK;
+}
+MG_EXPORT int mg_counters_allreduce_end(mg_ctx *c)
+{
+    const DeviceGuard on_device(c);
+    if (!c) return MG_ERR_ARG;
+    if (!c->x_pending) return fail(c, MG_ERR_STATE, "mg_counters_allreduce_end without mg_counters_allreduce_begin");
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_xs[1], 0));
+    c->x_pending = false;
+    return MG_OK;
+}
+// duration of the most recent exchange of this context (its collective with pack / unpack, without the guard's max), and its form
+MG_EXPORT int mg_exchange_stats(mg_ctx *c, float *ms_out, int *packed_out)
+{
+    const DeviceGuard on_device(c, LAZY);
+    if (!c) return MG_ERR_ARG;
+    if (!c->x_timed || !c->ev_xs[3]) return fail(c, MG_ERR_STATE, "no exchange has run");
+    HIP_TRY(c, hipEventSynchronize(c->ev_xs[3]));
+    if (ms_out) HIP_TRY(c, hipEventElapsedTime(ms_out, c->ev_xs[2], c->ev_xs[3]));
+    if (packed_out) *packed_out = c->last_exchange_packed;
     return MG_OK;
 }
 
@@ -2147,36 +2293,76 @@ MG_EXPORT int mg_counters_allreduce_all(mg_ctx **ctxs, int n)
                         i, (unsigned long long)ni, (unsigned long long)nn);
         nn = ni;
         if (ctxs[i]->comm_world != n) return fail(c0, MG_ERR_STATE, "context %d is not part of a %d-way group (mg_comm_init_all)", i, n);
+        ctxs[i]->last_exchange_packed = 0;
     }
     if (nn == 0) return MG_OK;
+    // the packed form's guard: every context's largest partial counter, seen by this one process (no collective needed)
+    bool packed = false;
+    if (pack_wanted(c0, nn, n)) {
+        u32 mx = 0;
+        for (int i = 0; i < n; ++i) {
+            const DeviceGuard g(ctxs[i]);
+            TRY(local_max(ctxs[i], nn, ctxs[i]->stream));
+        }
+        for (int i = 0; i < n; ++i) {
+            const DeviceGuard g(ctxs[i]);
+            u32 m1 = 0;
+            HIP_TRY(ctxs[i], hipMemcpyAsync(&m1, ctxs[i]->d_xmax, 4, hipMemcpyDeviceToHost, ctxs[i]->stream));
+            HIP_TRY(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+            mx = std::max(mx, m1);
+        }
+        packed = mx <= 65535u / (u32)n;
+    }
+    const u64 np = nn / 2 + (nn & 1);
     if (c0->comm) { // one rank per device, one process: a group of all-reduces, each on its context's stream
         Rccl *R = rccl();
         int prev = -1;
         hipGetDevice(&prev);
+        std::vector<u32 *> pk((size_t)n, nullptr);
+        if (packed)
+            for (int i = 0; i < n; ++i) {
+                hipSetDevice(ctxs[i]->device);
+                TRY(pack_into_scratch(ctxs[i], nn, ctxs[i]->stream, &pk[(size_t)i]));
+            }
         NCCL_TRY(c0, R, R->GroupStart());
         ncclResult_t bad = ncclSuccess;
         for (int i = 0; i < n && bad == ncclSuccess; ++i) {
             hipSetDevice(ctxs[i]->device);
-            bad = R->AllReduce(ctxs[i]->joined, ctxs[i]->joined, nn, ncclUint32, ncclSum, ctxs[i]->comm, ctxs[i]->stream);
+            bad = packed ? R->AllReduce(pk[(size_t)i], pk[(size_t)i], np, ncclUint32, ncclSum, ctxs[i]->comm, ctxs[i]->stream)
+                         : R->AllReduce(ctxs[i]->joined, ctxs[i]->joined, nn, ncclUint32, ncclSum, ctxs[i]->comm, ctxs[i]->stream);
         }
         const ncclResult_t ge = R->GroupEnd();
+        if (packed && bad == ncclSuccess && ge == ncclSuccess)
+            for (int i = 0; i < n; ++i) {
+                hipSetDevice(ctxs[i]->device);
+                hipLaunchKernelGGL(unpack16_kernel, dim3((unsigned)std::min<u64>(nblocks(np), 4096u)), dim3(TPB), 0, ctxs[i]->stream, ctxs[i]->joined, nn, (const u32 *)pk[(size_t)i]);
+                ctxs[i]->last_exchange_packed = 1;
+            }
         if (prev >= 0) hipSetDevice(prev);
         if (bad != ncclSuccess || ge != ncclSuccess) return fail(c0, MG_ERR_COMM, "ncclAllReduce x%d: %s", n, R->GetErrorString(bad != ncclSuccess ? bad : ge));
         return MG_OK;
     }
     if (c0->local_group.size() != (size_t)n) return fail(c0, MG_ERR_STATE, "mg_comm_init_all first");
-    // contexts sharing one device: context 0's stream waits for every scan, sums, and everyone waits for the sum
+    // contexts sharing one device: context 0's stream waits for every scan, sums (the packed words, where that form applies:
+    // the same pack / unpack kernels as on the wire), and everyone waits for the sum
     const DeviceGuard g(c0);
     LocalPtrs v{};
     v.n = n;
     for (int i = 0; i < n; ++i) {
-        v.p[i] = ctxs[i]->joined;
         if (i) {
             HIP_TRY(c0, hipEventRecord(ctxs[i]->ev_x, ctxs[i]->stream));
             HIP_TRY(c0, hipStreamWaitEvent(c0->stream, ctxs[i]->ev_x, 0));
         }
+        if (packed) TRY(pack_into_scratch(ctxs[i], nn, c0->stream, &v.p[i]));
+        else v.p[i] = ctxs[i]->joined;
     }
-    hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)std::min<u64>(nblocks(nn), 4096u)), dim3(TPB), 0, c0->stream, v, nn);
+    hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)std::min<u64>(nblocks(packed ? np : nn), 4096u)), dim3(TPB), 0, c0->stream, v, packed ? np : nn);
+    HIP_TRY(c0, hipGetLastError());
+    if (packed)
+        for (int i = 0; i < n; ++i) {
+            hipLaunchKernelGGL(unpack16_kernel, dim3((unsigned)std::min<u64>(nblocks(np), 4096u)), dim3(TPB), 0, c0->stream, ctxs[i]->joined, nn, (const u32 *)v.p[i]);
+            ctxs[i]->last_exchange_packed = 1;
+        }
     HIP_TRY(c0, hipGetLastError());
     HIP_TRY(c0, hipEventRecord(c0->ev_x, c0->stream));
     for (int i = 1; i < n; ++i) HIP_TRY(c0, hipStreamWaitEvent(ctxs[i]->stream, c0->ev_x, 0));

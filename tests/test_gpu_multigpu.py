@@ -96,6 +96,98 @@ def test_contexts_shard_scan_allreduce_equals_whole_table(world):
             c.close()
 
 
+def _small_counts_case(seed, n_vars=3000, n_rows=200000):
+    """partial counters small enough for the 16-bit packed form: KMC counts as they come (2..63), two table rows per signature at most"""
+    panel = synth.snp_panel(n_vars, seed)
+    hi, lo, cnt = synth.kmer_table(panel, n_rows, K, R, seed + 1)
+    return panel, hi, lo, cnt
+
+
+@pytest.mark.parametrize("world,pack", [(2, 2), (3, 2), (3, 0)])
+def test_packed_exchange_equals_whole_table(world, pack):
+    """the 16-bit packed form of the exchange (two counters per word on the wire, guarded by the ranks' largest partial counter):
+    the same pack / sum / unpack kernels whether RCCL or, on a one-GPU box, the kernel sum moves the words.  Small counts take it,
+    counts that could carry fall back to the 32-bit sum by themselves; either way every context ends with the whole table's counters."""
+    distinct = _n_devices() >= world
+    for big in (False, True):
+        panel, hi, lo, cnt = (_case(60 + world) if big else _small_counts_case(60 + world))
+        ctxs = [Context(K, R, 1 << 26, device=(r if distinct else 0)) for r in range(world)]
+        try:
+            obf = octx = omap = None
+            for c in ctxs:
+                c.set_option("exchange_pack", pack)
+                obf, octx, omap = build_index_pair(c, panel, K, R, 1 << 26)
+            ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, K, R)
+            capi.comm_init_all(ctxs)
+            for r, c in enumerate(ctxs):
+                a, b = shard_range(len(hi), r, world)
+                c.kmc_scan(hi[a:b], lo[a:b], cnt[a:b])
+            capi.counters_allreduce_all(ctxs)
+            for c in ctxs:
+                c.synchronize()
+                assert c.get_option("exchange_packed") == (1 if pack and not big else 0)
+                _assert_equals_oracle(c, obf, omap)
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+@pytest.mark.parametrize("pack", [0, 2])
+def test_exchange_on_its_own_stream_beside_the_block_cut(pack):
+    """mg_counters_allreduce_begin / _end on hardware (a one-rank communicator: the sum is the identity, the streams, events and the
+    packed form's guard, pack and unpack are real): scan -> begin -> block cut of the resident record loop -> end -> coverages and
+    likelihoods.  Counters, cuts, coverages, GT and GQ equal the oracle's."""
+    import torch
+    from malva_amd.resident import ResidentPanel
+    from test_gpu_resident import oracle_blocks
+    k, ref_k, bits = 35, 43, 1 << 28
+    panel = synth.clustered_snp_panel(40_000, seed=47, n_contigs=2)
+    args = oracle_blocks(panel, k)
+    hi, lo, cnt = synth.flat_kmer_table(panel, 400_000, k, ref_k, seed=9, max_records=6_000)
+    obf, octx, omap = ocapi.BF(bits), ocapi.BF(bits), ocapi.KMAP()
+    ocapi.index_blocks(obf, omap, panel.genome, **args, haploid=False, k=k)
+    obf.switch_mode()
+    for b, l in zip(panel.contig_base, panel.contig_len):
+        ocapi.ref_scan(obf, octx, panel.genome[int(b):int(b) + int(l)].tobytes(), k, ref_k)
+    octx.switch_mode()
+    ocapi.kmc_scan_packed(octx, obf, omap, hi, lo, cnt, k, ref_k)
+    dev = torch.device("cuda", 0)
+    d_hi, d_lo = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (hi, lo))
+    d_cnt = torch.from_numpy(cnt.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    with Context(k, ref_k, bits) as ctx:
+        ctx.set_option("exchange_pack", pack)
+        ctx.reference_upload(panel.genome)
+        rp = ResidentPanel(panel, 0, haploid=False)
+        assert rp.index(ctx).sum() == 0
+        ctx.bf_finalize(BF_ALT)
+        for b, l in zip(panel.contig_base, panel.contig_len):
+            ctx.ref_scan_resident(int(b), int(l))
+        ctx.bf_finalize(1)
+        ctx.comm_init(0, 1, capi.comm_unique_id())
+        with pytest.raises(capi.MalvaError):
+            ctx.counters_allreduce_end()                       # nothing begun
+        for _ in range(2):                                     # twice: the streams and events are reused
+            ctx.counters_reset()
+            ctx.kmc_scan_device(d_hi.data_ptr(), d_lo.data_ptr(), d_cnt.data_ptr(), len(hi))
+            ctx.counters_allreduce_begin()
+            with pytest.raises(capi.MalvaError):
+                ctx.counters_allreduce_begin()                 # one exchange at a time
+            rp.cut(ctx)                                        # needs no counters: runs beside the collective
+            ctx.counters_allreduce_end()
+            rp.cover(ctx)
+            rp.genotype(ctx)
+            got = rp.results()
+            ms, packed = ctx.exchange_stats()
+            assert ms >= 0 and packed == (1 if pack else 0)
+            want = ocapi.cover_blocks(obf, omap, panel.genome, **args, haploid=False, k=k)
+            assert np.array_equal(got["blk_var_off"], args["blk_var_off"]) and np.array_equal(got["cov"], want) and got["overflow"].sum() == 0
+            g1, g2, gq = ocapi.genotype_panel(want, panel.freq, panel.var_allele_off, 0.001, 200, False)
+            assert np.array_equal(got["g1"], g1) and np.array_equal(got["g2"], g2) and np.array_equal(got["gq"], gq)
+            assert (want > 0).sum() > 3_000
+        _assert_equals_oracle(ctx, obf, omap)
+
+
 def test_allreduce_refuses_contexts_with_different_indexes():
     a, b = Context(K, R, BITS), Context(K, R, BITS)
     try:
