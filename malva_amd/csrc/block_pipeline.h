@@ -33,6 +33,9 @@ constexpr int FW_MAXU = 12;          // unphased chain length (2^12 mixes per sa
 constexpr u32 FW_MAX_SAMPLES = 512;  // larger panels take the workgroup kernel (its 256 threads stride over the samples)
 constexpr int FW_COMBS_PER_REC = 8;  // descriptors a round's buffer holds per record of the round (average; a record may use 36)
 constexpr int FW_ITEMS_PER_REC = 32; // items likewise
+constexpr int FW_ORD_BINS = 24;      // chain lengths 0 (a reservation that did not fit) .. 21, rounded up
+constexpr int FW_ORD_HIST = 8, FW_ORD_CUR = FW_ORD_HIST + FW_ORD_BINS; // places in a round's counter block
+constexpr int FW_ROUND_COUNTERS = FW_ORD_CUR + FW_ORD_BINS;           // u64 per round
 
 struct FwSide {
     int n;
@@ -232,7 +235,9 @@ struct FlatWork {
     PickItem *slides; // items of the sliding kind (a lone allele of k bases or more): a wave each, fw_slide_kernel
     u32 slide_cap;
     u32 *retry;       // chains whose picks outgrew their share of a wave's set: taken again, a wave each (comb_cap entries)
-    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved, [2] sliding items, [3] chains to retry
+    u32 *order;       // the round's chains sorted by their number of members (fw_order_kernel), or NULL: as they were written
+    unsigned long long *counters; // this round: [0] descriptors reserved, [1] items reserved, [2] sliding items, [3] chains to retry,
+                                  // [FW_ORD_HIST ...) chains of each length, [FW_ORD_CUR ...) places taken in each length's run
     u8 *fb_flag;                  // [n_vars] the record goes to the workgroup kernel
 };
 
@@ -386,6 +391,42 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
     }
 }
 
+// The round's chains in order of their LENGTH (number of members): a counting sort by two small kernels.  The picks kernel
+// deals chains to lane groups and the eval kernel items to lanes in the order they come; every loop over a chain's members
+// then runs to the longest chain of the wave, and a wave that mixes chains of one and of six members spends most of its
+// lanes waiting (SQ_INSTS_VALU of fw_eval_kernel at C5: 2,400 per wave of 64 k-mers).  Sorted, a wave's chains are of one
+// length nearly everywhere.  Which chain of a length comes first is left to the hardware: nothing downstream depends on it.
+template <int PASS>
+__global__ void __launch_bounds__(TPB) fw_order_kernel(FlatWork W)
+{
+    __shared__ u32 sh_hist[FW_ORD_BINS], sh_base[FW_ORD_BINS];
+    const u64 n = min((unsigned long long)W.comb_cap, W.counters[0]);
+    for (u64 t0 = (u64)blockIdx.x * TPB; t0 < n; t0 += (u64)gridDim.x * TPB) { // (block-uniform bounds: barriers inside)
+        if (threadIdx.x < FW_ORD_BINS) sh_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 i = t0 + threadIdx.x;
+        u32 m = 0, rank = 0;
+        if (i < n) {
+            m = W.combs[i].m;
+            m = m < FW_ORD_BINS ? m : FW_ORD_BINS - 1;
+            rank = atomicAdd(&sh_hist[m], 1u);
+        }
+        __syncthreads();
+        if (PASS == 0) { // count
+            if (threadIdx.x < FW_ORD_BINS && sh_hist[threadIdx.x]) atomicAdd(&W.counters[FW_ORD_HIST + threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
+        } else {         // place: the length's run starts behind the shorter lengths', the tile takes its share of it
+            if (threadIdx.x < FW_ORD_BINS) {
+                unsigned long long start = 0;
+                for (int b = 0; b < (int)threadIdx.x; ++b) start += W.counters[FW_ORD_HIST + b];
+                sh_base[threadIdx.x] = sh_hist[threadIdx.x] ? (u32)(start + atomicAdd(&W.counters[FW_ORD_CUR + threadIdx.x], (unsigned long long)sh_hist[threadIdx.x])) : 0u;
+            }
+            __syncthreads();
+            if (i < n) W.order[sh_base[m] + rank] = (u32)i;
+        }
+        __syncthreads();
+    }
+}
+
 // build_alleles_combs + combine_haplotypes (var_block.hpp:709-786): the distinct picks of all panel samples along a chain.
 // A wave takes 64 / G chains at a time, G lanes each (G = the panel's sample count rounded up to a power of two, at most
 // 64: a wave per chain leaves 62 lanes idle on a two-sample panel); lanes stride over the samples.  The picks of all the
@@ -438,7 +479,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
     };
     for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + wave) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) {
         const u64 cpos = c0 + grp;                            // position in the list of chains this launch walks
-        const u64 ci = cpos < n_combs ? (RETRY ? (u64)W.retry[cpos] : cpos) : 0; // the chain's descriptor
+        const u64 ci = cpos < n_combs ? (RETRY ? (u64)W.retry[cpos] : W.order ? (u64)W.order[cpos] : cpos) : 0; // the chain's descriptor
         CombDesc d{};
         if (cpos < n_combs) d = W.combs[ci];
         const int m = d.m;
@@ -542,7 +583,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
                     chunk_at = base;
                     chunk_left = FW_CHUNK;
                 }
-                const u32 kci = RETRY ? (u32)ci : (u32)(c0 + kg); // (alone in the wave, or the kg-th of the wave's run of chains)
+                const u32 kci = (u32)__shfl((int)(u32)ci, RETRY ? 0 : kg * G, 64); // the descriptor of the key's chain (alone in the wave, or the kg-th of the wave's run of chains)
                 if (norm) W.items[chunk_at + __popcll(nm & ((1ULL << lane) - 1))] = PickItem{kci, 0u, code};
                 chunk_at += cnt;
                 chunk_left -= cnt;

@@ -80,7 +80,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[4], s_misc[8], s_blk[13], s_gt[10], s_scan;
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[4], s_misc[8], s_blk[14], s_gt[10], s_scan;
     void *h_gt_stage = nullptr;                       // pinned staging for mg_decode_gt_text's text (a pageable source is copied by the runtime in small synchronous pieces)
     size_t h_gt_stage_cap = 0;
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
@@ -106,6 +106,7 @@ struct mg_ctx {
     int blocks_round_log2 = 24;                // see blocks_setup
     int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
+    int use_chain_order = 1;                   // record loop: a round's chains sorted by their number of members before the picks and eval kernels take them (A/B)
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
@@ -734,6 +735,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_grid")) c->probe_grid = value > 0 ? (int)value : 2048;
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "use_sub")) c->use_sub = value != 0;
+    else if (!strcmp(name, "use_chain_order")) c->use_chain_order = value != 0;
     else if (!strcmp(name, "exchange_pack")) c->exchange_pack = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "exchange_pack_min_mb")) c->exchange_pack_min_mb = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "lazy_vectors")) c->lazy_vectors = value != 0;
@@ -2525,7 +2527,7 @@ struct BlocksRun {
     u8 *fb_flag;
     CombDesc *combs;
     PickItem *items, *slides;
-    u32 *retry;
+    u32 *retry, *order;
     unsigned long long *round_counters;
     u64 round, n_rounds;
     int cus;
@@ -2548,10 +2550,11 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     TRY(scratch(c, c->s_blk[2], n, &q[2]));                                                       // fb_flag
     TRY(scratch(c, c->s_blk[3], sizeof(CombDesc) * (R.round * FW_COMBS_PER_REC + 64), &q[3]));    // one round's descriptors
     TRY(scratch(c, c->s_blk[4], sizeof(PickItem) * (R.round * FW_ITEMS_PER_REC + FW_CHUNK * (u64)(1 << 14)), &q[4])); // one round's items (+ a chunk per wave)
-    TRY(scratch(c, c->s_blk[5], 32 * R.n_rounds, &q[5]));                                         // per round: descriptors, items, sliding items reserved
+    TRY(scratch(c, c->s_blk[5], 8 * FW_ROUND_COUNTERS * R.n_rounds, &q[5]));                      // per round: descriptors, items, sliding items reserved, chains per length
     TRY(scratch(c, c->s_blk[6], sizeof(PickItem) * (R.round / 4 + 4096), &q[7]));                 // one round's sliding items
-    void *q_retry;
+    void *q_retry, *q_order;
     TRY(scratch(c, c->s_blk[7], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_retry));                // one round's chains to retry
+    TRY(scratch(c, c->s_blk[13], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_order));               // one round's chains in order of their length
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
         TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
@@ -2593,6 +2596,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     R.combs = (CombDesc *)q[3]; R.items = (PickItem *)q[4]; R.round_counters = (unsigned long long *)q[5];
     R.slides = (PickItem *)q[7];
     R.retry = (u32 *)q_retry;
+    R.order = (u32 *)q_order;
     int dev = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&R.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) R.cus = 256;
@@ -2609,7 +2613,7 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         HIP_TRY(c, hipGetLastError());
         return MG_OK;
     }
-    HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 32 * R.n_rounds, c->stream));
+    HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 8 * FW_ROUND_COUNTERS * R.n_rounds, c->stream));
     for (u64 r = 0; r < R.n_rounds; ++r) {
         FlatWork W{};
         W.gen_list = R.gen_list;
@@ -2623,9 +2627,15 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         W.slides = R.slides;
         W.slide_cap = (u32)(R.round / 4 + 4096);
         W.retry = R.retry;
-        W.counters = R.round_counters + 4 * r;
+        W.counters = R.round_counters + FW_ROUND_COUNTERS * r;
+        W.order = c->use_chain_order ? R.order : nullptr;
         W.fb_flag = R.fb_flag;
         hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
+        if (W.order) { // (grids sized for the round's worst case: workgroups beyond the chains written find nothing)
+            const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 16);
+            hipLaunchKernelGGL(fw_order_kernel<0>, dim3(og), dim3(TPB), 0, c->stream, W);
+            hipLaunchKernelGGL(fw_order_kernel<1>, dim3(og), dim3(TPB), 0, c->stream, W);
+        }
         int G = 2; // lanes per chain: the samples, rounded up to a power of two
         while (G < 64 && (u32)G < R.B.n_samples) G *= 2;
         // the counting pass of `index` leaves a margin in the item buffer: the insert pass packs its chunks in another order
