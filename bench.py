@@ -373,8 +373,9 @@ class Job:
             self.ctx.kmc_scan_device(self.d_hi.data_ptr(), self.d_lo.data_ptr(), self.d_cnt.data_ptr(), n)
 
     def call(self):
-        """the record loop on this rank's records: mg_cut_blocks_device -> mg_cover_blocks_device -> mg_genotype_device"""
-        self.rp.call_step(self.ctx)
+        """the record loop on this rank's records: mg_cut_blocks_device -> mg_cover_blocks_device -> mg_genotype_device (GT and GQ, as
+        `malva-geno call` without -v prints them; the normalised likelihood lists of -v are timed apart: kernels_ms.genotype_verbose)"""
+        self.rp.call_step(self.ctx, probs=False)
 
     def call_isolated(self, n=None):
         """c3 only: the fused lone-variant entry on the first n records"""
@@ -394,7 +395,7 @@ class Job:
             self.rp.cut(self.ctx)
             self.ctx.counters_allreduce_end()
             self.rp.cover(self.ctx)
-            self.rp.genotype(self.ctx)
+            self.rp.genotype(self.ctx, probs=False)
             return
         elif self.world > 1:
             # a large vector is worth halving on the wire; for a small one the guard's extra round trip costs more
@@ -458,7 +459,7 @@ class Job:
     def kernel_times(self, reps):
         """per-kernel durations outside the timed region, same launches: HIP events on the launch stream"""
         torch, ctx = self.torch, self.ctx
-        scan_ms, call_ms, cut_ms, geno_ms, blk, iso_ms = [], [], [], [], [], []
+        scan_ms, call_ms, cut_ms, geno_ms, genov_ms, blk, iso_ms = [], [], [], [], [], [], []
         for _ in range(reps):
             ctx.counters_reset()
             self.scan(self.n_rows)
@@ -469,11 +470,15 @@ class Job:
             ev[1].record()
             self.rp.cover(ctx)
             ev[2].record()
-            self.rp.genotype(ctx)
+            self.rp.genotype(ctx, probs=False)
             ev[3].record()
-            ev[3].synchronize()
+            self.rp.genotype(ctx, probs=True)          # (-v: the normalised lists too; outside the record loop's figure)
+            ev4 = torch.cuda.Event(enable_timing=True)
+            ev4.record()
+            ev4.synchronize()
             cut_ms.append(ev[0].elapsed_time(ev[1]))
             geno_ms.append(ev[2].elapsed_time(ev[3]))
+            genov_ms.append(ev[3].elapsed_time(ev4))
             blk.append(ctx.blocks_stats())
             call_ms.append(ev[0].elapsed_time(ev[3]))
             if not self.flat:       # the fused lone-variant entry on the same counters (it ends the records' copies' validity: last)
@@ -488,7 +493,7 @@ class Job:
                "gate_open_rows": int(scan_ms[-1][3]), "bf_hit_rows": int(scan_ms[-1][4])}
         out.update({"cut_blocks": float(np.mean(cut_ms)), "tier1_lone": float(np.mean([b[0] for b in blk])),
                     "tier2_flat": float(np.mean([b[1] for b in blk])), "tier3_workgroup": float(np.mean([b[2] for b in blk])),
-                    "genotype": float(np.mean(geno_ms)), "general_records": blk[-1][3], "lone_signature_kmers": blk[-1][4],
+                    "genotype": float(np.mean(geno_ms)), "genotype_verbose": float(np.mean(genov_ms)), "general_records": blk[-1][3], "lone_signature_kmers": blk[-1][4],
                     "general_signature_kmers": blk[-1][5], "tier3_records": blk[-1][6]})
         if iso_ms:
             out["record_loop_isolated"] = float(np.mean(iso_ms))
@@ -801,10 +806,17 @@ def record(job, elapsed, steps, warmup, kt, sustained):
     if job.flat:
         n_sig = kt["lone_signature_kmers"] + kt["general_signature_kmers"]
         alg = blocks_bytes(job.n_vars, n_sig, job.n_genotypes)
+        blocks_traffic, blocks_tsrc = None, None      # counted HBM bytes of one record loop (tools/traffic_blocks.sh), when this IS that workload
+        tb = os.path.join(ROOT, "profiles", "traffic_blocks_%s.json" % job.workload)
+        if os.path.exists(tb) and world == 1:
+            t = json.load(open(tb))
+            if t.get("panel_variants") == job.n_vars_total and t.get("units_per_launch") == job.n_vars:
+                blocks_traffic, blocks_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_blocks_%s.json (rocprofv3 PMC%s)" % (
+                    job.workload, "; mean of the diploid and the haploid job's loops" if t.get("haploid_included") else "")
         loop_ms = kt["record_loop"]
         out["roofline_blocks"] = {"kernel": "cut_flags + flag_scatter + panel_lone + fw_walk + fw_picks + fw_eval + cover_blocks<0> + genotype (the record loop, main.cpp:522-579)",
                                   "bound": "hbm", "achieved": alg / (loop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                  "frac": alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": blocks_traffic, "traffic_source": blocks_tsrc, "algorithmic_bytes_per_launch": alg,
                                   "bytes_per_unit": "64 + 36 K + 8 G (SURVEY 8(d))", "units_per_launch": job.n_vars, "signature_kmers": n_sig,
                                   "genotypes": job.n_genotypes, "avg_launch_ms": loop_ms, "variants_per_s_record_loop_alone": job.n_vars / (loop_ms * 1e-3)}
         if loop_ms > scan_sum * n_groups:     # the record loop is the larger part of this workload's step

@@ -423,8 +423,8 @@ inline void load_index_hipz3(const std::string &path, IndexPayload &p, uint64_t 
     zstd_check();
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open index " + path);
-    struct stat st;
-    const uint64_t file_bytes = stat(path.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+    struct stat st; // (of the descriptor that is open, not of whatever the name points at by now; an unknown size bounds nothing)
+    const uint64_t file_bytes = fstat(fileno(f), &st) == 0 && st.st_size > 0 ? (uint64_t)st.st_size : (uint64_t)1 << 50;
     try {
         char magic[8];
         uint64_t hdr[9];

@@ -60,7 +60,13 @@ const char *USAGE =
     "  or <prefix>.txt / <prefix> holding `kmc_tools transform <db> dump` text (one `KMER<tab>count` per line).\n"
     "  index file: <variants.vcf>.c<r>.k<k>.malvax.zst, the reference's container (sdsl + zstd); `call` also reads this\n"
     "  build's compact <...>.malvax.hipz (written when MALVA_GENO_INDEX_FORMAT=hipz).\n"
-    "  extra sub-commands (no GPU needed): dump-kmers (signature k-mers of every block); index-convert <fa> <vcf> zst|hipz\n";
+    "  extra sub-commands (no GPU needed): dump-kmers (signature k-mers of every block); index-convert <fa> <vcf> zst|hipz\n"
+    "\n"
+    "  Verified inputs: the text k-mer dump and text / gzip / bgzip VCF (checked against the reference's own example).  The three\n"
+    "  BINARY formats -- a KMC database, a BCF panel, the reference's sdsl + zstd index container -- are read and written from their\n"
+    "  published layouts and checked against an independent second implementation only: no file written by KMC, bcftools or the\n"
+    "  reference binary was available to this build (formats UNPINNED).  When in doubt convert: `kmc_tools transform <db> dump`,\n"
+    "  `bcftools view -Ov`, and let this build write its own index.\n";
 
 struct Options { // argument_parser.hpp:51-66
     unsigned k = 35, ref_k = 43;

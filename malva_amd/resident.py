@@ -74,10 +74,11 @@ class ResidentPanel:
                             self.g1.data_ptr(), self.g2.data_ptr(), self.gq.data_ptr(), self.status.data_ptr(),
                             self.probs.data_ptr() if probs else None, self.t["gt_off"].data_ptr() if probs else None)
 
-    def call_step(self, ctx, error_rate=0.001, max_cov=200):
+    def call_step(self, ctx, error_rate=0.001, max_cov=200, probs=True):
+        """probs=False: GT and GQ only, what `malva-geno call` prints without -v (var_block.hpp:366-394)"""
         self.cut(ctx)
         self.cover(ctx)
-        self.genotype(ctx, error_rate, max_cov)
+        self.genotype(ctx, error_rate, max_cov, probs)
 
     def index(self, ctx):
         """cut + extract_kmers + add_kmers_to_bf (main.cpp:309-370); returns the overflow flags (host array)"""

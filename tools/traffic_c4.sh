@@ -17,4 +17,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 $BENCH
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal" -- python3 $BENCH --scan-ablate 256 > /dev/null 2> "$OUT/cal.log" || echo "calibration pass failed"
 cd - > /dev/null
 python3 tools/traffic_c4.py "$OUT" | tee "$OUT/summary.txt"
+python3 tools/traffic_blocks.py "$OUT" c4 | tee -a "$OUT/summary.txt"      # the same passes hold the record loop's kernels
 rm -rf "$OUT/fetch" "$OUT/write" "$OUT/cal"   # (hundreds of MB of per-dispatch rows: gpurun copies back at most 64 MiB)
