@@ -1006,8 +1006,14 @@ struct SubSet {
     u32 ablate;                 // timing-only diagnostic of pass one (results are wrong when non-zero): 1 = tickets not stored
 };
 
-// Pass one.  Five barriers per tile of 16,384 rows: counts complete / wave sums / places known, next counts cleared /
-// tile sorted / tile stored.  R12: the table is compact 12-byte rows (rows12), else the SoA arrays (hi, lo).
+// Pass one.  Four barriers per tile of 16,384 rows: counts complete / wave sums / places known, next counts cleared / tile
+// sorted.  The sorted tile does not leave at once: its stores are dealt out over the NEXT tile's hashing, two store
+// iterations behind every pair of rows hashed.  One workgroup per CU means nothing else covers its phases, and a wave
+// waits for its memory operations in issue order: the rows requested after a block of stores arrive, for the wave, only
+// when the last store has been acknowledged -- 0.22 ms per 2^27 rows spent behind 1.07 GB of ticket stores (0.97 ms
+// against 0.75 without them).  Spread between the pairs, the stores are younger than the loads the next pair waits for and
+// drain beside the arithmetic.  A tile one of whose segments would overflow (skewed input: rare) leaves the old way, at
+// once and through the spill list.  R12: the table is compact 12-byte rows (rows12), else the SoA arrays (hi, lo).
 template <int KC, int RC, bool R12>
 __global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ rows12, u64 n,
                                                                 int k_rt, int r_rt, BFView bf, SubSet ss)
@@ -1015,21 +1021,31 @@ __global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__rest
     __shared__ u64 sh_sorted[SB_TILE];
     __shared__ u32 sh_hist[2][SB_MAXB], sh_off[SB_MAXB], sh_pos[SB_MAXB], sh_wsum[SB_TPB / 64];
     __shared__ u32 sh_lut[256];
+    __shared__ u32 sh_slow;
     const int k = KC > 0 ? KC : k_rt, r = RC > 0 ? RC : r_rt;
     const int off = (r - k) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ascii_lut_fill(sh_lut);
     sh_hist[0][threadIdx.x] = sh_hist[1][threadIdx.x] = sh_pos[threadIdx.x] = 0; // (SB_TPB == SB_MAXB)
+    if (threadIdx.x == 0) sh_slow = 0;
     __syncthreads();
     u32 parity = 0;
     const u32 segcap = (u32)ss.segcap;
+    u32 prev_total = 0, prev_mine = 0; // the tile still waiting in sh_sorted: its tickets, and those of bin threadIdx.x among them
+    auto store_one = [&](u32 e, u32 total_) { // ticket e of the sorted tile into its bin's segment (the tile fits its segments: checked before it was left waiting)
+        if (e < total_) {
+            const u64 t = sh_sorted[e];
+            const u32 b = (u32)((t >> ss.row_bits) >> ss.bin_shift);
+            ss.tickets[((unsigned long long)b * ss.nseg + blockIdx.x) * ss.segcap + sh_pos[b] + (e - sh_off[b])] = t;
+        }
+    };
     for (u64 base = (u64)blockIdx.x * SB_TILE; base < n; base += (u64)gridDim.x * SB_TILE) {
         u64 tk[SB_ROWS];
         u32 binrank[SB_ROWS]; // bin << 16 | rank inside the bin (a tile holds 16,384 rows), ~0u = no row
         // Two adjacent rows (a "pair") per load group, hashed as they arrive -- with the loads of the pairs AHEAD already
         // requested: left to itself the compiler sinks every pair's loads to their use (fewest live registers), and a wave
         // then sits out one whole memory latency per pair, eight per tile, with three other waves on its SIMD to cover it.
-        constexpr int RAW = R12 ? 6 : 8, AHEAD = 3;
+        constexpr int RAW = R12 ? 6 : 8, AHEAD = 2;
         u32 raw[SB_ROWS / 2][RAW];
         auto request = [&](int g) { // (no predicate on a load: a pair beyond the table reads the last pair again and is dropped by its row number)
             u32 (&w)[RAW] = raw[g];
@@ -1073,8 +1089,13 @@ __global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__rest
                 const u32 bin = (u32)(idx >> ss.bin_shift);
                 binrank[2 * g + j] = i + j < n ? (bin << 16) | atomicAdd(&sh_hist[parity][bin], 1u) : ~0u;
             }
+            if (!(ss.ablate & 1)) { // two store iterations of the tile before (SB_ROWS of them in all: sixteen per thread)
+                store_one((u32)(2 * g) * SB_TPB + threadIdx.x, prev_total);
+                store_one((u32)(2 * g + 1) * SB_TPB + threadIdx.x, prev_total);
+            }
         }
-        __syncthreads(); // 1: the tile's counts are complete (and the previous tile has left the sorted array)
+        __syncthreads(); // 1: the tile's counts are complete, and the previous tile has left the sorted array
+        if (!(ss.ablate & 1)) sh_pos[threadIdx.x] = min(sh_pos[threadIdx.x] + prev_mine, segcap); // (its segments' fills: nobody reads them before barrier 3)
         const u32 mine = sh_hist[parity][threadIdx.x]; // this tile's tickets of bin threadIdx.x (bins beyond nbins stay empty)
         u32 incl = mine;
         for (int o = 1; o < 64; o <<= 1) {
@@ -1092,23 +1113,35 @@ __global__ void __launch_bounds__(SB_TPB) scan_sub_sort_kernel(const u64 *__rest
         }
         sh_off[threadIdx.x] = before + incl - mine;
         sh_hist[parity ^ 1][threadIdx.x] = 0; // the next tile's counts
+        if (sh_pos[threadIdx.x] + mine > segcap) sh_slow = 1; // a segment would overflow: this tile goes at once, through the spill list
         __syncthreads(); // 3: every bin's place in the tile is known
 #pragma unroll
         for (int j = 0; j < SB_ROWS; ++j)
             if (binrank[j] != ~0u) sh_sorted[sh_off[binrank[j] >> 16] + (binrank[j] & 0xFFFFu)] = tk[j];
         __syncthreads(); // 4: the tile is sorted
-        if (!(ss.ablate & 1))
-            for (u32 e = threadIdx.x; e < total; e += SB_TPB) { // runs of consecutive tickets, one per bin, into the workgroup's segments
-                const u64 t = sh_sorted[e];
-                const u32 b = (u32)((t >> ss.row_bits) >> ss.bin_shift);
-                const u32 at = sh_pos[b] + (e - sh_off[b]);
-                if (at < segcap) ss.tickets[((unsigned long long)b * ss.nseg + blockIdx.x) * ss.segcap + at] = t;
-                else ss.spill[atomicAdd(ss.spill_count, 1ULL)] = t; // the segment is full (skewed input): rare
-            }
-        __syncthreads(); // 5: everybody has read the segments' fills
-        if (!(ss.ablate & 1)) sh_pos[threadIdx.x] = min(sh_pos[threadIdx.x] + mine, segcap);
+        prev_total = total;
+        prev_mine = mine;
+        if (sh_slow) { // (block-uniform) runs of consecutive tickets, one per bin, into the workgroup's segments; what does not fit, to the spill list
+            if (!(ss.ablate & 1))
+                for (u32 e = threadIdx.x; e < total; e += SB_TPB) {
+                    const u64 t = sh_sorted[e];
+                    const u32 b = (u32)((t >> ss.row_bits) >> ss.bin_shift);
+                    const u32 at = sh_pos[b] + (e - sh_off[b]);
+                    if (at < segcap) ss.tickets[((unsigned long long)b * ss.nseg + blockIdx.x) * ss.segcap + at] = t;
+                    else ss.spill[atomicAdd(ss.spill_count, 1ULL)] = t;
+                }
+            __syncthreads(); // everybody has read the segments' fills
+            if (!(ss.ablate & 1)) sh_pos[threadIdx.x] = min(sh_pos[threadIdx.x] + mine, segcap);
+            if (threadIdx.x == 0) sh_slow = 0;
+            prev_total = prev_mine = 0;
+            // (the next write of sh_slow is behind the next tile's barriers 1 and 2)
+        }
         parity ^= 1;
     }
+    if (!(ss.ablate & 1)) // the last tile
+        for (u32 e = threadIdx.x; e < prev_total; e += SB_TPB) store_one(e, prev_total);
+    __syncthreads();
+    if (!(ss.ablate & 1)) sh_pos[threadIdx.x] = min(sh_pos[threadIdx.x] + prev_mine, segcap);
     __syncthreads();
     if (threadIdx.x < ss.nbins) ss.counts[threadIdx.x * ss.nseg + blockIdx.x] = sh_pos[threadIdx.x];
 }
