@@ -106,7 +106,9 @@ struct mg_ctx {
     int blocks_round_log2 = 24;                // see blocks_setup
     int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
-    int use_chain_order = 1;                   // record loop: a round's chains sorted by their number of members before the picks and eval kernels take them (A/B)
+    int use_chain_order = 0;                   // record loop: a round's chains sorted by their number of members before the picks and eval kernels take them.  Built to end the
+                                               // divergence of the per-member loops and measured: C5 record loop 2.59 -> 2.49 ms, C4 tier 2 5.8 -> 7.6 ms (the sorted order
+                                               // scatters the picks kernel's descriptor loads and the eval kernel's, which ran coalesced): off
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
