@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
         if (cpos < n_combs) d = W.combs[ci];
         const int m = d.m;
         const u32 g = d.g;
-        const bool valid = cpos < n_combs && m > 0 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit)
+        const bool valid = cpos < n_combs && m > 0 && d.rel[21] != 2 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit; rel[21] == 2: fw_snp_kernel took the chain)
         bool fail = false;  // the record goes to the workgroup kernel
         if (valid)
             for (u32 s = sub; s < B.n_samples && !fail; s += G) {
@@ -603,6 +603,122 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
         wave_sync();
     }
     for (u32 i = lane; i < chunk_left; i += 64) W.items[chunk_at + i] = PickItem{0xFFFFFFFFu, 0u, 0ULL};
+}
+
+// Chains of SNPs on a panel of few samples -- every chain of a whole-genome SNP panel -- in ONE kernel, lanes = the panel's
+// haplotypes along the chain (16 at most: 8 diploid samples), 64 / lanes chains per wave: a haplotype's k-mer is the reference
+// window around the central record with the members' bases put in; equal k-mers of one chain are told apart by comparing keys
+// across the chain's lanes, and the first of each goes on to canonical form, XXH3 and its lookup (or insert).  No set in LDS,
+// no items written and read back, no second walk over the members: what fw_picks_kernel + fw_eval_kernel do for such a chain
+// in 4.5 ms per 1.2e7 chains (C4) is one pass here.  A chain it cannot take whole -- a sample unphased along a chain of two or
+// more members (2^m mixes), a picked allele longer than one base, a window that leaves the sequence or holds a base outside
+// ACGT, more haplotypes than 16 -- is left exactly as it was for the two kernels; one it takes is marked (rel[21] = 2) and
+// skipped by them.  The decision depends on the chain and the panel alone, so `index`'s two passes agree.
+constexpr u32 FW_SNP_MAX_HAPS = 16;
+template <int MODE>
+__global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, unsigned long long *cursor, u32 row0,
+                                                     unsigned long long *n_evaluated)
+{
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G, sub = lane % G, n_grp = 64 / G;
+    const u64 gmask = (G == 64 ? ~0ULL : ((1ULL << G) - 1)) << (grp * G);
+    const u32 n_haps = B.haploid ? B.n_samples : 2 * B.n_samples;
+    const u64 n_combs = min((unsigned long long)W.comb_cap, W.counters[0]);
+    const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    const int k = B.k;
+    u32 evaluated = 0, ref_rows = 0;
+    for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + (threadIdx.x >> 6)) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) { // (whole waves: ballots inside)
+        const u64 ci = c0 + grp;
+        CombDesc d{};
+        if (ci < n_combs) d = W.combs[ci];
+        const int m = d.m, jm = d.jm;
+        const u32 g = d.g;
+        const bool chain_ok = ci < n_combs && m > 0 && d.rel[21] == 1 && !W.fb_flag[g] && k >= 17 && k <= MG_MAX_PACKED_K;
+        const bool mine = chain_ok && (u32)sub < n_haps; // this lane carries a haplotype of the chain
+        const u32 smp = B.haploid ? (u32)sub : (u32)sub >> 1, second = B.haploid ? 0u : (u32)sub & 1u;
+        bool good = true; // (of lanes that carry a haplotype) the haplotype fits the fixed geometry
+        U128 Lf{0, 0};
+        u32 mid_allele = 0;
+        unsigned long long code = 0; // the haplotype's pick as fw_picks_kernel codes it: the members' alleles, ceil(log2(alleles)) bits each
+        if (mine) {
+            const i32 ref_len = (i32)B.contig_len[d.cid];
+            int sh = 0;
+            const int w0 = B.pos[g] - k / 2;
+            good = w0 >= 0 && w0 + k <= ref_len;
+            if (good) {
+                const u64 at = B.contig_base[d.cid] + (u64)w0;
+                Lf.lo = ref_codes(B.ref2, at, k < 32 ? k : 32);
+                if (k > 32) Lf.hi = ref_codes(B.ref2, at + 32, k - 32);
+                good = !ref_bad(B.refbad, at, k < 32 ? k : 32) && (k <= 32 || !ref_bad(B.refbad, at + 32, k - 32));
+                for (int j = 0; j < m && good; ++j) {
+                    const u32 v = g + d.rel[j];
+                    const u32 gt = gt_at(B, v, smp);
+                    if (!B.haploid && m > 1 && !((gt >> 14) & 1)) good = false; // unphased along a chain: every mix of its two haplotypes is a pick
+                    const u32 a = second ? (gt >> 7) & 127 : gt & 127;
+                    const u32 s0 = B.var_allele_off[v];
+                    const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
+                    if (sh + bits > 63) good = false;
+                    code |= (unsigned long long)a << (sh & 63);
+                    sh += bits;
+                    const u32 ao = B.allele_off[s0 + a];
+                    if (B.allele_off[s0 + a + 1] - ao != 1) good = false; // (a longer ALT of a record whose shortest allele has one base)
+                    if (j == jm) mid_allele = a;
+                    const int x = B.pos[v] - w0;
+                    if (good && x >= 0 && x < k) { // the member's base at its own place in the window (a member outside it changes nothing)
+                        bool o;
+                        const u64 code = acgt_code(B.pool[ao], &o);
+                        good = o;
+                        if (x < 32) Lf.lo = (Lf.lo & ~(3ULL << (2 * x))) | code << (2 * x);
+                        else Lf.hi = (Lf.hi & ~(3ULL << (2 * (x - 32)))) | code << (2 * (x - 32));
+                    }
+                }
+            }
+        }
+        // the chain is taken here iff every one of its haplotypes fits (the group's lanes agree through the ballot)
+        const u64 bad = __ballot(mine && !good), have = __ballot(mine);
+        const bool take = chain_ok && n_haps <= FW_SNP_MAX_HAPS && !(bad & gmask) && (have & gmask);
+        // first lane of the group with each distinct PICK (what build_alleles_combs' set holds, var_block.hpp:734-786: two picks that
+        // differ only outside the window are two signatures of one k-mer, evaluated twice as the reference does)
+        bool first = take && mine;
+        for (int q = 1; q < G; ++q) {
+            const int src = grp * G + ((sub + G - q) % G); // every other lane of the group, one by one
+            const unsigned long long ocode = (unsigned long long)__shfl((long long)code, src, 64);
+            const bool omine = (have >> src) & 1;
+            if (first && omine && (src % G) < sub && ocode == code) first = false;
+        }
+        if (take && sub == 0) W.combs[ci].rel[21] = 2; // fw_picks_kernel leaves the chain alone
+        if (!first) continue;
+        ++evaluated;
+        const u32 a0 = B.var_allele_off[g];
+        const u32 mid_canon = B.canon[a0 + mid_allele];
+        const U128 mk = mask128(2 * k);
+        const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
+        const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+        const U128 key = lt128(Lf, rc) ? Lf : rc;
+        const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
+        const u64 idx = mod_size(h, bf.mod);
+        const bool is_ref = mid_canon == 0;
+        if (MODE == 0) {
+            i32 w;
+            if (is_ref) w = k == (int)map.klen ? map_value(map, key, h, idx) : 0;
+            else w = (i32)bucket_count(map, bf.counts, idx);
+            if (w > 0) atomicMax(&cov_out[a0 + mid_canon], (u32)w);
+        } else if (is_ref) {
+            if (MODE == 1) ++ref_rows;
+            else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+        } else if (MODE == 2) {
+            atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
+            gate_set(bf, idx);
+        }
+    }
+    if (MODE == 1) {
+        for (int dd = 32; dd; dd >>= 1) ref_rows += __shfl_xor(ref_rows, dd, 64);
+        if (lane == 0 && ref_rows) atomicAdd(cursor, (unsigned long long)ref_rows);
+    }
+    if (n_evaluated) {
+        for (int dd = 32; dd; dd >>= 1) evaluated += __shfl_xor(evaluated, dd, 64);
+        if (lane == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
+    }
 }
 
 // one signature k-mer: assembly in 2-bit form, canonical, XXH3, then MODE 0 lookup + max into the allele's coverage,

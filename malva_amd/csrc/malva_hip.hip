@@ -106,6 +106,7 @@ struct mg_ctx {
     int blocks_round_log2 = 24;                // see blocks_setup
     int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
+    int use_snp_kernel = 1;                    // record loop: chains of SNPs on panels of up to 8 diploid / 16 haploid samples in one kernel (fw_snp_kernel) instead of picks + eval
     int use_chain_order = 0;                   // record loop: a round's chains sorted by their number of members before the picks and eval kernels take them.  Built to end the
                                                // divergence of the per-member loops and measured: C5 record loop 2.59 -> 2.49 ms, C4 tier 2 5.8 -> 7.6 ms (the sorted order
                                                // scatters the picks kernel's descriptor loads and the eval kernel's, which ran coalesced): off
@@ -738,6 +739,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "use_sub")) c->use_sub = value != 0;
     else if (!strcmp(name, "use_chain_order")) c->use_chain_order = value != 0;
+    else if (!strcmp(name, "use_snp_kernel")) c->use_snp_kernel = value != 0;
     else if (!strcmp(name, "exchange_pack")) c->exchange_pack = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "exchange_pack_min_mb")) c->exchange_pack_min_mb = (int)std::max<int64_t>(0, value);
     else if (!strcmp(name, "lazy_vectors")) c->lazy_vectors = value != 0;
@@ -2637,6 +2639,12 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
             const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 16);
             hipLaunchKernelGGL(fw_order_kernel<0>, dim3(og), dim3(TPB), 0, c->stream, W);
             hipLaunchKernelGGL(fw_order_kernel<1>, dim3(og), dim3(TPB), 0, c->stream, W);
+        }
+        const u32 n_haps = R.B.haploid ? R.B.n_samples : 2 * R.B.n_samples;
+        if (c->use_snp_kernel && R.B.snp_chains && n_haps <= FW_SNP_MAX_HAPS) { // chains of SNPs whole, before the picks kernel sees them
+            int GH = 2;
+            while ((u32)GH < n_haps) GH *= 2;
+            hipLaunchKernelGGL(fw_snp_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, GH, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
         }
         int G = 2; // lanes per chain: the samples, rounded up to a power of two
         while (G < 64 && (u32)G < R.B.n_samples) G *= 2;

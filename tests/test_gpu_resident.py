@@ -24,7 +24,7 @@ def oracle_blocks(panel, k):
                 canon=panel.canon, gt=panel.gt, n_samples=panel.n_samples)
 
 
-def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, sparse=False):
+def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, sparse=False, options=()):
     args = oracle_blocks(panel, k)
     sizes = np.diff(args["blk_var_off"].astype(np.int64))
     assert (sizes > 1).sum() >= min_general, "the recipe drew too few general blocks: %d" % (sizes > 1).sum()
@@ -38,6 +38,8 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, spars
     with Context(k, ref_k, bits) as ctx:
         ctx.set_option("blocks_round_log2", 14)             # several rounds of tier 2 (and a round seam inside the general list) on panels this size
         ctx.set_option("use_record_counters", 2)            # the tiers' lookups read the records' own counter copies, as they do by themselves at whole-genome size
+        for name, value in options:
+            ctx.set_option(name, value)
         ctx.reference_upload(panel.genome)
         rp = ResidentPanel(panel, 0, haploid=haploid, sparse=sparse)
         ovf = rp.index(ctx)
@@ -88,6 +90,7 @@ def run_recipe(panel, k, ref_k, haploid, bits, n_rows, plant, min_general, spars
         rp.call_step(ctx)
         again = rp.results()
         assert np.array_equal(again["cov"], got["cov"]) and np.array_equal(again["gq"], got["gq"])
+        stats["device_general_kmers"] = ctx.blocks_stats()[5]
     return stats
 
 
@@ -140,3 +143,24 @@ def test_large_panel_sparse_genotypes_through_the_workgroup_tier(haploid):
     off, _, _ = sparse_genotypes(panel.gt, panel.n_samples)
     assert off[-1] < 0.06 * panel.gt.size
     run_recipe(panel, 35, 63, haploid, 1 << 26, n_rows=400_000, plant=3_000, min_general=2_000, sparse=True)
+
+
+@pytest.mark.parametrize("variant", ["diploid", "haploid", "unphased", "sparse", "eight-samples"])
+def test_snp_chains_in_one_kernel_and_through_picks_and_eval(variant):
+    """chains of SNPs take fw_snp_kernel (lanes = the panel's haplotypes along the chain) when every haplotype fits its fixed
+    geometry, and the picks + eval kernels otherwise: the C4 recipe's clustered SNPs as they come (two phased samples), haploid,
+    with a third of the genotypes unphased (chains of two or more members then need every mix: left to the picks kernel), with
+    sparse genotypes, and with eight samples (sixteen lanes per chain).  Each against the oracle with the kernel on and off; both
+    ways enumerate the same number of signature k-mers."""
+    n_samples = 8 if variant == "eight-samples" else 2
+    panel = synth.clustered_snp_panel(150_000, seed=61, n_contigs=3, n_samples=n_samples)
+    if variant == "unphased":
+        rng = np.random.default_rng(5)
+        drop = rng.random(panel.gt.shape) < 0.33
+        panel.gt[drop] &= np.uint16(~(1 << 14) & 0xFFFF)
+    counts = []
+    for on in (1, 0):
+        st = run_recipe(panel, 35, 43, variant == "haploid", 1 << 28, n_rows=600_000, plant=8_000, min_general=3_000, sparse=variant == "sparse",
+                        options=[("use_snp_kernel", on)])
+        counts.append(st["device_general_kmers"])
+    assert counts[0] == counts[1] > 10_000
