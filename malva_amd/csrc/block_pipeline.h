@@ -69,7 +69,9 @@ struct LoneClass {
     bool lone, eligible;
     u64 site, mask;
     u32 a0, A;
+    u8 cls; // REC_SNP: one base for one base, every allele; REC_PHASED: every sample's genotype phased (or the run is haploid)
 };
+constexpr u8 REC_SNP = 1, REC_PHASED = 2;
 // The loads are arranged in three LEVELS of mutually independent requests (what a thread of this kernel does is wait for
 // loads: the first form, a chain of fifteen dependent ones -- block, block ends, its sequence, the sequence's base; genotype
 // word, canonical allele, next genotype word ... -- ran at a quarter of the rate its 2.5 lines of HBM traffic per record allow):
@@ -91,6 +93,7 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
     const bool present = P.present[v] != 0;
     u64 raw = 0; // raw allele numbers some panel haplotype carries (numbers of 64 and more fold back: such a record is not lone)
     u32 e0 = 0, e1 = 0;
+    bool phased = true;
     if (P.sp_off) {
         e0 = P.sp_off[v];
         e1 = P.sp_off[v + 1];
@@ -105,6 +108,7 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
                 if (w[j] != 0xFFFFFFFFu) {
                     raw |= 1ULL << (w[j] & 63);
                     if (!haploid) raw |= 1ULL << ((w[j] >> 7) & 63);
+                    phased = phased && ((w[j] >> 14) & 1);
                 }
         }
     }
@@ -123,12 +127,21 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
             const u32 g = P.sp_gt[e];
             raw |= 1ULL << (g & 63);
             if (!haploid) raw |= 1ULL << ((g >> 7) & 63);
+            phased = phased && ((g >> 14) & 1);
         }
         if (e1 - e0 < P.n_samples) {
             raw |= 1ULL << (P.sp_default & 63);
             if (!haploid) raw |= 1ULL << ((P.sp_default >> 7) & 63);
+            phased = phased && ((P.sp_default >> 14) & 1);
         }
     }
+    // what fw_walk_kernel wants to know of a chain's members before it calls the chain one of SNPs (fw_snp_kernel takes those whole)
+    bool snp = rs == 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (a < (int)c.A) snp = snp && ao[a + 1] - ao[a] == 1;
+    for (u32 a = 4; a < c.A && snp; ++a) snp = snp && P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a] == 1;
+    c.cls = (u8)((snp ? REC_SNP : 0) | (phased || haploid ? REC_PHASED : 0));
     // a block of one variant, alleles all shorter than k (at most 64 of them: the presence mask), flanks inside the sequence
     bool lone = b1 - b0 == 1 && c.A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
     if (lone) {
@@ -169,7 +182,7 @@ template <bool SLOW>
 __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                          const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, const u8 *pool, int k,
                                                          int haploid, BFView bf, MapView map, u32 *cov_out, u32 *need_slow, u32 call_no, u32 *gen_list,
-                                                         unsigned long long *counters)
+                                                         unsigned long long *counters, u8 *rec_class)
 {
     __shared__ u32 sh_gen[LONE_TILES * TPB / 2];
     __shared__ u32 sh_n, sh_sigs;
@@ -184,8 +197,10 @@ __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars
         if (v >= n_vars) break;
         const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
         if (!SLOW && !(t & 1)) {
-            if (!c.lone) sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
-            else sigs += (u32)__popcll(c.mask);
+            if (!c.lone) {
+                sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
+                rec_class[v] = c.cls; // (every member of a chain is a record of a block of two or more: listed here)
+            } else sigs += (u32)__popcll(c.mask);
         }
         if (c.lone) iso_cover_body<SLOW>(reference, ref2, refbad, c.site, c.a0, c.A, c.eligible, c.mask, (u32)(t & 1), P.allele_off, pool, k, bf, map, cov_out, need_slow, call_no);
     }
@@ -203,7 +218,7 @@ __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars
 // index time: lone records are inserted here (REF key of record v takes insertion row row0 + v), the others listed
 __global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                                const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 row0,
-                                                               u8 *overflow, u32 *gen_list, unsigned long long *counters)
+                                                               u8 *overflow, u32 *gen_list, unsigned long long *counters, u8 *rec_class)
 {
     __shared__ u32 sh_gen[LONE_TILES * TPB];
     __shared__ u32 sh_n;
@@ -214,8 +229,10 @@ __global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 
         const u64 v = ((u64)blockIdx.x * LONE_TILES + tile) * TPB + threadIdx.x;
         if (v >= n_vars) break;
         const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
-        if (!c.lone) sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
-        else if (c.eligible && !iso_index_body(reference, c.site, c.a0, c.A, c.mask, P.allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
+        if (!c.lone) {
+            sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
+            rec_class[v] = c.cls;
+        } else if (c.eligible && !iso_index_body(reference, c.site, c.a0, c.A, c.mask, P.allele_off, pool, k, bf, map, row0 + (u32)v, row0)) overflow[v] = 1;
     }
     __syncthreads();
     if (threadIdx.x == 0) sh_base = sh_n ? atomicAdd(counters, (unsigned long long)sh_n) : 0ULL;
@@ -379,12 +396,14 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
         for (int j = 0; j < 22; ++j) d.rel[j] = 0;
         for (int j = 0; j < len_l; ++j) d.rel[j] = L.mem[cl][len_l - 1 - j];
         for (int j = 0; j < len_r; ++j) d.rel[len_l + 1 + j] = R.mem[cr][j];
-        // rel[21] (never a member: a chain has at most 21) = 1: every member replaces one base and has a one-base allele --
-        // a chain of SNPs unless a pick takes a longer ALT; fw_eval_kernel tries its fixed-geometry assembly only then
+        // rel[21] (never a member: a chain has at most 21) = 1: every member replaces one base by one base whatever the allele,
+        // and -- along a chain of two or more, diploid -- no sample is unphased at any member (tier 1 left that in rec_class):
+        // fw_snp_kernel takes such a chain whole unless its window leaves the sequence or holds a base outside ACGT
         bool snps = true;
+        const u8 need = (u8)(REC_SNP | (d.m > 1 ? REC_PHASED : 0));
         for (int j = 0; j < d.m; ++j) {
             const u32 v = g + d.rel[j];
-            snps = snps && B.ref_size[v] == 1 && B.min_size[v] == 1;
+            snps = snps && (B.rec_class[v] & need) == need;
         }
         d.rel[21] = snps ? 1 : 0;
         out[c] = d;
@@ -627,13 +646,21 @@ __global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, i
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
     const int k = B.k;
     u32 evaluated = 0, ref_rows = 0;
-    for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + (threadIdx.x >> 6)) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) { // (whole waves: ballots inside)
-        const u64 ci = c0 + grp;
+    // The wave reads 64 descriptors' marks at a time and deals the chains of SNPs among them to its lane groups: on a panel of
+    // indels and MNPs one chain in twenty is such a chain, and a wave that gave a lane group to every descriptor spent
+    // 0.19 ms per 1e6 chains finding that out (C5)
+    for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + (threadIdx.x >> 6)) * 64; c0 < n_combs; c0 += n_waves * 64) // (whole waves: ballots inside)
+      for (u64 pending = __ballot(c0 + lane < n_combs && (*(const u32 *)&W.combs[c0 + lane < n_combs ? c0 + lane : 0].rel[18] >> 24) == 1u); pending;) {
+        u64 mine_bit = pending; // the grp-th chain still to be dealt
+        for (int q = 0; q < grp; ++q) mine_bit &= mine_bit - 1;
+        const bool has = mine_bit != 0;
+        const u64 ci = c0 + (u64)(has ? __ffsll((unsigned long long)mine_bit) - 1 : 0);
+        for (int q = 0; q < n_grp && pending; ++q) pending &= pending - 1;
         CombDesc d{};
-        if (ci < n_combs) d = W.combs[ci];
+        if (has) d = W.combs[ci];
         const int m = d.m, jm = d.jm;
         const u32 g = d.g;
-        const bool chain_ok = ci < n_combs && m > 0 && d.rel[21] == 1 && !W.fb_flag[g] && k >= 17 && k <= MG_MAX_PACKED_K;
+        const bool chain_ok = has && m > 0 && d.rel[21] == 1 && !W.fb_flag[g] && k >= 17 && k <= MG_MAX_PACKED_K;
         const bool mine = chain_ok && (u32)sub < n_haps; // this lane carries a haplotype of the chain
         const u32 smp = B.haploid ? (u32)sub : (u32)sub >> 1, second = B.haploid ? 0u : (u32)sub & 1u;
         bool good = true; // (of lanes that carry a haplotype) the haplotype fits the fixed geometry

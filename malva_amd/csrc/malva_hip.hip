@@ -80,7 +80,7 @@ struct mg_ctx {
     u32 k = 0, ref_k = 0;
     BFState bf[2];
     MapState map;
-    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[4], s_misc[8], s_blk[14], s_gt[10], s_scan;
+    Scratch s_rows, s_aux, s_out, s_irr, s_open[3], s_hit[4], s_misc[8], s_blk[16], s_gt[10], s_scan;
     void *h_gt_stage = nullptr;                       // pinned staging for mg_decode_gt_text's text (a pageable source is copied by the runtime in small synchronous pieces)
     size_t h_gt_stage_cap = 0;
     u32 gt_records = 0, gt_keep = 0, gt_default = 0; // the batch mg_decode_gt_text left on the device for mg_decode_gt_entries
@@ -795,6 +795,8 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_packed_pool")) *value = c->use_packed_pool;
     else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
     else if (!strcmp(name, "use_hit_entries")) *value = c->use_hit_entries;
+    else if (!strcmp(name, "use_chain_order")) *value = c->use_chain_order;
+    else if (!strcmp(name, "use_snp_kernel")) *value = c->use_snp_kernel;
     else if (!strcmp(name, "blocks_round_log2")) *value = c->blocks_round_log2;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
     else if (!strcmp(name, "use_record_counters")) *value = c->use_record_counters;
@@ -2559,6 +2561,8 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     void *q_retry, *q_order;
     TRY(scratch(c, c->s_blk[7], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_retry));                // one round's chains to retry
     TRY(scratch(c, c->s_blk[13], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_order));               // one round's chains in order of their length
+    void *q_class;
+    TRY(scratch(c, c->s_blk[14], n, &q_class));                                                   // per listed record: REC_SNP | REC_PHASED
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
         TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
@@ -2583,6 +2587,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
     B.snp_chains = c->use_snp_chains;
+    B.rec_class = (const u8 *)q_class;
     // the alleles packed like the reference (every call: the panel is the caller's) -- unless the pool is too small to hold alleles worth
     // it (a SNP panel: two one-base alleles per record; fw_eval takes alleles of up to 4 bases from the bytes anyway)
     if (p->pool_bytes && p->pool_bytes * 2 > n * 5 && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) {
@@ -2765,10 +2770,10 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     if (++c->iso_call_no == 0) c->iso_call_no = 1;
     hipLaunchKernelGGL(panel_lone_kernel<false>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
-                       c->iso_call_no, R.gen_list, c->d_gen_count);
+                       c->iso_call_no, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
     hipLaunchKernelGGL(panel_lone_kernel<true>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
-                       c->iso_call_no, R.gen_list, c->d_gen_count);
+                       c->iso_call_no, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_b[1], c->stream));
     TRY(blocks_tier2<0>(R, (u32 *)d_cov_out, (u8 *)d_overflow_out, nullptr, 0u, c->d_gen_count + 3));
@@ -2959,7 +2964,7 @@ MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     HIP_TRY(c, hipMemsetAsync(c->d_gen_count, 0, 64, c->stream));
     // tier 1: lone and short records are inserted at once; everything else is listed
     hipLaunchKernelGGL(panel_lone_index_kernel, dim3((unsigned)((n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref, (const u8 *)p->pool,
-                       (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count);
+                       (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
     HIP_TRY(c, hipGetLastError());
     c->map.rows_total += n;
     unsigned long long *d_cursor = c->d_gen_count + 1;

@@ -349,6 +349,7 @@ struct BlockBatch {
     const uint16_t *sp_gt;     // ... and that genotype.  A panel of tens of thousands of samples is nearly all 0|0.
     u32 sp_default;            // the genotype word of every sample WITHOUT an entry (0|0 phased, or 0/0 for an unphased panel)
     int snp_chains;            // fw_eval_kernel's fixed-geometry assembly for chains of SNPs (option use_snp_chains)
+    const u8 *rec_class;       // [n_vars] per record outside tier 1: REC_SNP | REC_PHASED (written by the tier-1 kernels of the same call)
     const u64 *pool2;          // the allele pool packed like the reference (2 bits per base at the pool's own offsets) + its not-ACGT bits,
     const u32 *poolbad;        // built at the start of the call when the panel states pool_bytes; else NULL: alleles are read byte by byte
     u32 n_samples;
