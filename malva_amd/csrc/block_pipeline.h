@@ -410,37 +410,58 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
     }
 }
 
-// The round's chains in order of their LENGTH (number of members): a counting sort by two small kernels.  The picks kernel
-// deals chains to lane groups and the eval kernel items to lanes in the order they come; every loop over a chain's members
-// then runs to the longest chain of the wave, and a wave that mixes chains of one and of six members spends most of its
-// lanes waiting (SQ_INSTS_VALU of fw_eval_kernel at C5: 2,400 per wave of 64 k-mers).  Sorted, a wave's chains are of one
-// length nearly everywhere.  Which chain of a length comes first is left to the hardware: nothing downstream depends on it.
+// The round's chains still to be taken -- not the reservations that did not fit, not the chains fw_snp_kernel took -- in order
+// of their LENGTH (number of members): a counting sort by two small kernels.  The kernels that follow deal chains to lane
+// groups in the order they come; every loop over a chain's members then runs to the longest chain of the wave, and a wave
+// that mixes chains of one and of six members spends most of its lanes waiting (C5: tier 2 1.74 -> 1.58 ms with the order).
+// On a whole-genome SNP panel the list is also what keeps those kernels from walking 1.2e7 descriptors to find the few
+// fw_snp_kernel left.  A wave counts its chains of one length with one LDS atomic (a panel whose chains all have two members
+// would otherwise send 256 atomics of a tile to one address).  Which chain of a length comes first is left to the hardware:
+// nothing downstream depends on it.
+__device__ __forceinline__ u64 fw_chains_todo(const FlatWork &W)
+{
+    if (!W.order) return min((unsigned long long)W.comb_cap, W.counters[0]);
+    unsigned long long n = 0;
+    for (int b = 1; b < FW_ORD_BINS; ++b) n += W.counters[FW_ORD_HIST + b];
+    return n;
+}
 template <int PASS>
 __global__ void __launch_bounds__(TPB) fw_order_kernel(FlatWork W)
 {
     __shared__ u32 sh_hist[FW_ORD_BINS], sh_base[FW_ORD_BINS];
     const u64 n = min((unsigned long long)W.comb_cap, W.counters[0]);
+    const int lane = threadIdx.x & 63;
     for (u64 t0 = (u64)blockIdx.x * TPB; t0 < n; t0 += (u64)gridDim.x * TPB) { // (block-uniform bounds: barriers inside)
         if (threadIdx.x < FW_ORD_BINS) sh_hist[threadIdx.x] = 0;
         __syncthreads();
         const u64 i = t0 + threadIdx.x;
         u32 m = 0, rank = 0;
         if (i < n) {
-            m = W.combs[i].m;
+            const u32 mark = *(const u32 *)&W.combs[i].rel[18] >> 24;
+            m = mark == 2 ? 0u : (u32)W.combs[i].m;
             m = m < FW_ORD_BINS ? m : FW_ORD_BINS - 1;
-            rank = atomicAdd(&sh_hist[m], 1u);
+        }
+        for (u64 todo = __ballot(m != 0); todo;) { // the wave's chains of one length: one atomic
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const u32 v = (u32)__shfl((int)m, leader, 64);
+            const u64 same = __ballot(m == v);
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&sh_hist[v], (u32)__popcll(same));
+            base = (u32)__shfl((int)base, leader, 64);
+            if (m == v) rank = base + (u32)__popcll(same & ((1ULL << lane) - 1));
+            todo &= ~same;
         }
         __syncthreads();
         if (PASS == 0) { // count
             if (threadIdx.x < FW_ORD_BINS && sh_hist[threadIdx.x]) atomicAdd(&W.counters[FW_ORD_HIST + threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
         } else {         // place: the length's run starts behind the shorter lengths', the tile takes its share of it
-            if (threadIdx.x < FW_ORD_BINS) {
+            if (threadIdx.x >= 1 && threadIdx.x < FW_ORD_BINS) {
                 unsigned long long start = 0;
-                for (int b = 0; b < (int)threadIdx.x; ++b) start += W.counters[FW_ORD_HIST + b];
+                for (int b = 1; b < (int)threadIdx.x; ++b) start += W.counters[FW_ORD_HIST + b];
                 sh_base[threadIdx.x] = sh_hist[threadIdx.x] ? (u32)(start + atomicAdd(&W.counters[FW_ORD_CUR + threadIdx.x], (unsigned long long)sh_hist[threadIdx.x])) : 0u;
             }
             __syncthreads();
-            if (i < n) W.order[sh_base[m] + rank] = (u32)i;
+            if (m) W.order[sh_base[m] + rank] = (u32)i;
         }
         __syncthreads();
     }
@@ -477,7 +498,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
     if (lane < 32) sh_cnt[wave][lane] = 0;
     wave_sync();
     const u32 share = (u32)(FW_SET * 3 / 4 / n_grp); // distinct picks a chain may have here
-    const u64 n_combs = RETRY ? min((unsigned long long)W.comb_cap, W.counters[3]) : min((unsigned long long)W.comb_cap, W.counters[0]);
+    const u64 n_combs = RETRY ? min((unsigned long long)W.comb_cap, W.counters[3]) : fw_chains_todo(W);
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
     unsigned long long chunk_at = 0; // next free item of the wave's chunk
     u32 chunk_left = 0;
@@ -925,6 +946,365 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
     if (n_evaluated) {
         for (int dd = 32; dd; dd >>= 1) evaluated += __shfl_xor(evaluated, dd, 64);
         if ((threadIdx.x & 63) == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
+    }
+}
+
+// ---- tier 2: picks and evaluation of a chain in ONE kernel ----------------------------------------------------------------------
+// fw_picks_kernel writes every distinct pick out as an item and fw_eval_kernel reads it back, fetches the chain's descriptor
+// again and walks the members twice through six arrays of the panel -- 133 load instructions and 2,000 VALU instructions per
+// wave of 64 k-mers at C5, which is what the pair's 1.4 ms per 6.9e6 k-mers is made of.  Here the wave that holds the picks
+// evaluates them:
+//   staging   the lanes of a chain's group put the chain's geometry into the wave's LDS area once: per member its position,
+//             REF length, allele range and code width, and the offsets of all its alleles; they also look at every base a
+//             window of the chain can hold -- the reference from k/2 before the first member to (k+1)/2 behind the last, and
+//             every allele -- so that the assembly needs no test per piece
+//   picks     as fw_picks_kernel: the distinct haplotype picks of the wave's chains in one LDS set
+//   evaluate  the set's entries 64 at a time, a lane each: lengths and pieces from LDS, the bases from the packed reference
+//             and the packed pool, canonical form, XXH3, lookup or insert
+// A chain that does not fit its share of the staging area or of the set, or that has a base outside ACGT in reach, is listed
+// for the pair above (fw_picks_kernel<true> takes the list a chain per wave, fw_eval_kernel its items) -- what happens to it
+// there is what happened before this kernel existed, and the decision depends on the chain and the panel alone.
+constexpr int FW_POOL = 2048; // bytes of staging area per wave, shared evenly by the chains the wave holds at a time
+struct __attribute__((aligned(16))) FcHead {
+    u64 cbase;
+    i32 ref_len;
+    u32 g, a0;
+    i32 first_pos, last_end;
+    u8 m, jm;
+    u8 pad[2];
+};
+struct __attribute__((aligned(16))) FcMember {
+    i32 pos;
+    u32 rs, v;
+    unsigned short off_at; // where the member's allele offsets start in the chain's table (A + 1 of them)
+    u8 bits, A;
+};
+static_assert(sizeof(FcHead) == 32 && sizeof(FcMember) == 16, "staging layout");
+
+template <int MODE>
+__device__ __forceinline__ void fc_eval(const BlockBatch &B, const unsigned char *area, unsigned long long code, const BFView &bf, const MapView &map, u32 *cov_out,
+                                        u8 *overflow, unsigned long long *cursor, u32 row0, u32 &evaluated, u32 &ref_rows)
+{
+    const FcHead hd = *(const FcHead *)area;
+    const FcMember *mem = (const FcMember *)(area + sizeof(FcHead));
+    const int m = hd.m, jm = hd.jm, k = B.k;
+    const u32 *off = (const u32 *)(area + sizeof(FcHead) + sizeof(FcMember) * m);
+    // lengths: virtual string V = A_0 R_0 A_1 ... A_{m-1}
+    int len_v = 0, mid_pos = 0, mid_len = 0, sh = 0, prev_end = 0;
+    u32 mid_allele = 0;
+    for (int j = 0; j < m; ++j) {
+        const FcMember mj = mem[j];
+        const u32 a = (u32)(code >> sh) & ((1u << mj.bits) - 1);
+        sh += mj.bits;
+        const int al = (int)(off[mj.off_at + a + 1] - off[mj.off_at + a]);
+        if (j) len_v += mj.pos - prev_end;
+        if (j == jm) {
+            mid_pos = len_v;
+            mid_len = al;
+            mid_allele = a;
+        }
+        len_v += al;
+        prev_end = mj.pos + (int)mj.rs;
+    }
+    const int first_part = mid_pos + mid_len / 2;
+    const int mp = k / 2 - first_part;                 // missing_prefix (negative: cut)
+    const int ms = (k + 1) / 2 - (len_v - first_part); // missing_suffix
+    if (hd.first_pos - (mp > 0 ? mp : 0) < 0 || hd.last_end + (ms > 0 ? ms : 0) > hd.ref_len) {
+        if (MODE != 2) overflow[hd.g] = 1; // the reference clips or throws here: the host path's
+        return;
+    }
+    U128 Lf{0, 0};
+    auto put_codes = [&](const u64 *__restrict__ packed, int x, int xe, u64 at) { // W[x .. xe) = packed[at ..)
+        while (x < xe) {
+            const int n = xe - x < 32 ? xe - x : 32;
+            const U128 sp = shl128(U128{ref_codes(packed, at, n), 0}, 2 * x);
+            Lf.lo |= sp.lo;
+            Lf.hi |= sp.hi;
+            x += n;
+            at += n;
+        }
+    };
+    if (mp > 0) put_codes(B.ref2, 0, mp < k ? mp : k, hd.cbase + (u64)((long long)hd.first_pos - mp));
+    int vs = 0;
+    sh = 0;
+    for (int j = 0; j < m; ++j) {
+        const FcMember mj = mem[j];
+        const u32 a = (u32)(code >> sh) & ((1u << mj.bits) - 1);
+        sh += mj.bits;
+        const u32 ao = off[mj.off_at + a];
+        const int al = (int)(off[mj.off_at + a + 1] - ao);
+        {
+            const int x0 = max(0, vs + mp), xe = min(k, vs + al + mp);
+            if (x0 < xe) {
+                if (B.pool2) put_codes(B.pool2, x0, xe, (u64)ao + (u64)(x0 - mp - vs));
+                else
+                    for (int x = x0; x < xe; ++x) { // (every base was looked at when the chain was staged)
+                        bool o;
+                        const u64 c2 = acgt_code(B.pool[ao + (u32)(x - mp - vs)], &o);
+                        if (x < 32) Lf.lo |= c2 << (2 * x);
+                        else Lf.hi |= c2 << (2 * (x - 32));
+                    }
+            }
+        }
+        vs += al;
+        if (j + 1 < m) {
+            const int gs = mj.pos + (int)mj.rs;
+            const int gl = mem[j + 1].pos - gs;
+            const int x0 = max(0, vs + mp), xe = min(k, vs + gl + mp);
+            if (x0 < xe) put_codes(B.ref2, x0, xe, hd.cbase + (u64)((long long)gs + (x0 - mp - vs)));
+            vs += gl;
+        }
+        if (vs + mp >= k) break; // the window is full
+    }
+    {
+        const int x0 = max(0, len_v + mp);
+        if (x0 < k) put_codes(B.ref2, x0, k, hd.cbase + (u64)((long long)hd.last_end + (x0 - mp - len_v)));
+    }
+    ++evaluated;
+    const u32 mid_canon = B.canon[hd.a0 + mid_allele];
+    const U128 mk = mask128(2 * k);
+    const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
+    const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
+    const U128 key = lt128(Lf, rc) ? Lf : rc;
+    const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
+    const u64 idx = mod_size(h, bf.mod);
+    const bool is_ref = mid_canon == 0;
+    if (MODE == 0) {
+        i32 w;
+        if (is_ref) w = k == (int)map.klen ? map_value(map, key, h, idx) : 0;
+        else w = (i32)bucket_count(map, bf.counts, idx);
+        if (w > 0) atomicMax(&cov_out[hd.a0 + mid_canon], (u32)w);
+    } else if (is_ref) {
+        if (MODE == 1) ++ref_rows;
+        else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+    } else if (MODE == 2) {
+        atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
+        gate_set(bf, idx);
+    }
+}
+
+constexpr int FC_SET = 512; // slots of a wave's set of distinct picks in fw_chain_kernel
+template <int MODE>
+__global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, u8 *overflow, unsigned long long *cursor,
+                                                       u32 row0, unsigned long long *n_evaluated)
+{
+    __shared__ unsigned long long sh_set[FW_WAVES][FC_SET]; // key + 1, 0 = free
+    __shared__ unsigned short sh_list[FW_WAVES][FC_SET];    // slots taken, in the order they were taken
+    __shared__ u32 sh_n[FW_WAVES];
+    __shared__ u32 sh_cnt[FW_WAVES][32];                    // distinct picks per chain of the wave
+    __shared__ u32 sh_state[FW_WAVES][32];                  // per chain of the wave: 0 staged, else it goes to the list
+    __shared__ __attribute__((aligned(16))) unsigned char sh_pool[FW_WAVES][FW_POOL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / G, sub = lane % G, n_grp = 64 / G;
+    const int budget = FW_POOL / n_grp;
+    const int k = B.k;
+    unsigned long long *set = sh_set[wave];
+    unsigned short *list = sh_list[wave];
+    unsigned char *area = sh_pool[wave] + grp * budget;
+    FcHead *hd = (FcHead *)area;
+    FcMember *mem = (FcMember *)(area + sizeof(FcHead));
+    for (int i = lane; i < FC_SET; i += 64) set[i] = 0;
+    if (lane == 0) sh_n[wave] = 0;
+    if (lane < 32) sh_cnt[wave][lane] = 0;
+    wave_sync();
+    const u32 share = (u32)(FC_SET * 3 / 4 / n_grp); // distinct picks a chain may have here
+    const u64 n_combs = fw_chains_todo(W);
+    const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    volatile u32 *my_cnt = &sh_cnt[wave][grp];
+    u32 evaluated = 0, ref_rows = 0;
+    auto insert = [&](unsigned long long key) {
+        u32 at = (u32)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (FC_SET - 1);
+        for (int tries = 0; tries < FC_SET; ++tries) {
+            const unsigned long long seen = atomicCAS(&set[at], 0ULL, key + 1);
+            if (seen == 0ULL) {
+                atomicAdd(&sh_cnt[wave][grp], 1u);
+                const u32 q = atomicAdd(&sh_n[wave], 1u);
+                if (q < FC_SET) list[q] = (unsigned short)at;
+                return;
+            }
+            if (seen == key + 1) return;
+            at = (at + 1) & (FC_SET - 1);
+        }
+    };
+    for (u64 c0 = ((u64)blockIdx.x * FW_WAVES + wave) * n_grp; c0 < n_combs; c0 += n_waves * n_grp) {
+        const u64 cpos = c0 + grp;
+        const u64 ci = cpos < n_combs ? (W.order ? (u64)W.order[cpos] : cpos) : 0;
+        // (the descriptor's head and its mark; the members' offsets are read where they are used, a byte each: an array indexed
+        // by a loop counter would live in scratch memory)
+        uint4 dh{0, 0, 0, 0};
+        u32 dmark = 0;
+        if (cpos < n_combs) {
+            dh = *(const uint4 *)&W.combs[ci];
+            dmark = *(const u32 *)&W.combs[ci].rel[18] >> 24;
+        }
+        const signed char *rel = W.combs[ci].rel;
+        const int m = (int)(dh.z & 255u);
+        const u32 g = dh.x, cid = dh.y;
+        const bool valid = cpos < n_combs && m > 0 && dmark != 2 && !W.fb_flag[g]; // (m == 0: a reservation that did not fit; mark 2: fw_snp_kernel took the chain)
+        // ---- staging: members, then (one lane) where each member's allele offsets go, then the offsets and the look at every base
+        const bool room = (int)(sizeof(FcHead) + sizeof(FcMember) * m) <= budget;
+        if (sub == 0) sh_state[wave][grp] = valid && room ? 0u : 1u;
+        if (valid && room) {
+            for (int j = sub; j < m; j += G) {
+                const u32 v = g + rel[j];
+                const u32 A = B.var_allele_off[v + 1] - B.var_allele_off[v];
+                mem[j] = FcMember{B.pos[v], B.ref_size[v], v, (unsigned short)0, (u8)fw_bits(A), (u8)A};
+            }
+            if (sub == 0) {
+                FcHead h{};
+                h.cbase = B.contig_base[cid];
+                h.ref_len = (i32)B.contig_len[cid];
+                h.g = g;
+                h.a0 = B.var_allele_off[g];
+                h.m = (u8)m;
+                h.jm = (u8)((dh.z >> 8) & 255u);
+                *hd = h;
+            }
+        }
+        wave_sync();
+        if (valid && room && sub == 0) {
+            u32 acc = 0;
+            bool wide = false; // (a member of 128 alleles or more: its count does not fit the entry, its genotypes not the pick's code)
+            for (int j = 0; j < m; ++j) {
+                mem[j].off_at = (unsigned short)acc;
+                acc += (u32)mem[j].A + 1;
+                wide = wide || mem[j].bits > 7;
+            }
+            hd->first_pos = mem[0].pos;
+            hd->last_end = mem[m - 1].pos + (i32)mem[m - 1].rs;
+            if (wide || (int)(sizeof(FcHead) + sizeof(FcMember) * m + 4 * acc) > budget) sh_state[wave][grp] = 1;
+        }
+        wave_sync();
+        if (valid && sh_state[wave][grp] == 0) {
+            u32 *off = (u32 *)(area + sizeof(FcHead) + sizeof(FcMember) * m);
+            bool bad = false;
+            for (int j = 0; j < m; ++j) {
+                const FcMember mj = mem[j];
+                const u32 s0 = B.var_allele_off[mj.v];
+                for (u32 a = (u32)sub; a < mj.A; a += (u32)G) {
+                    const u32 ao = B.allele_off[s0 + a], an = B.allele_off[s0 + a + 1];
+                    off[mj.off_at + a] = ao;
+                    if (a + 1 == mj.A) off[mj.off_at + a + 1] = an;
+                    if (B.pool2)
+                        for (u32 x = ao; x < an; x += 32) bad = bad || ref_bad(B.poolbad, (u64)x, an - x < 32 ? (int)(an - x) : 32);
+                    else
+                        for (u32 x = ao; x < an; ++x) {
+                            bool o;
+                            acgt_code(B.pool[x], &o);
+                            bad = bad || !o;
+                        }
+                }
+            }
+            const i32 lo = max(0, hd->first_pos - k / 2), hi = min(hd->ref_len, hd->last_end + (k + 1) / 2);
+            for (i32 x = lo + 32 * sub; x < hi; x += 32 * G) bad = bad || ref_bad(B.refbad, hd->cbase + (u64)x, hi - x < 32 ? hi - x : 32);
+            if (bad) sh_state[wave][grp] = 1;
+        }
+        wave_sync();
+        const bool staged = valid && sh_state[wave][grp] == 0;
+        // ---- picks (build_alleles_combs + combine_haplotypes, var_block.hpp:709-786)
+        bool fail = false; // the record goes to the workgroup kernel
+        if (staged) {
+            const u32 *off = (const u32 *)(area + sizeof(FcHead) + sizeof(FcMember) * m);
+            for (u32 s = sub; s < B.n_samples && !fail; s += G) {
+                if (*my_cnt > share) break; // the chain outgrew its share of the set (all its lanes see that sooner or later)
+                bool phased = true;
+                unsigned long long c1 = 0, c2 = 0, bounds = 1; // bounds: bit set at every member's first code bit, and behind the last
+                int sh = 0;
+                for (int j = 0; j < m; ++j) {
+                    const int bits = mem[j].bits;
+                    if (sh + bits > FW_CODE_BITS) {
+                        fail = true;
+                        break;
+                    }
+                    const u32 gt = gt_at(B, mem[j].v, s);
+                    phased = phased && ((gt >> 14) & 1);
+                    c1 |= (unsigned long long)(gt & 127) << sh;
+                    c2 |= (unsigned long long)((gt >> 7) & 127) << sh;
+                    sh += bits;
+                    bounds |= 1ULL << sh;
+                }
+                if (fail) break;
+                const unsigned long long tag = (unsigned long long)grp << FW_GRP_SHIFT;
+                if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): its own kind of item
+                    const u32 l1 = off[(u32)c1 + 1] - off[(u32)c1], l2 = off[(u32)c2 + 1] - off[(u32)c2];
+                    if ((int)l1 >= k) c1 |= FW_SLIDE_IN;
+                    if ((int)l2 >= k) c2 |= FW_SLIDE_IN;
+                }
+                if (B.haploid) insert(c1 | tag);
+                else if (phased || m == 1) { // (the mixes of a chain of one are its two alleles)
+                    insert(c1 | tag);
+                    insert(c2 | tag);
+                } else if (m > FW_MAXU) fail = true;
+                else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
+                    const unsigned long long diff = c1 ^ c2;
+                    unsigned long long code = c1;
+                    insert(code | tag);
+                    for (u32 i = 1; i < (1u << m); ++i) {
+                        const int j = __ffs((int)i) - 1;
+                        unsigned long long t = bounds;
+                        for (int q = 0; q < j; ++q) t &= t - 1;
+                        const int lo = __ffsll((unsigned long long)t) - 1;
+                        t &= t - 1;
+                        const int hi = __ffsll((unsigned long long)t) - 1;
+                        const unsigned long long fm = ((1ULL << (hi - lo)) - 1) << lo;
+                        code ^= diff & fm;
+                        if (diff & fm) insert(code | tag);
+                        if (*my_cnt > share) break;
+                    }
+                }
+            }
+        }
+        wave_sync();
+        const u32 n = sh_n[wave];
+        const bool all_fail = n > FC_SET; // (cannot happen: every chain stops at its share; kept as a guard)
+        const bool grew = staged && sh_cnt[wave][grp] > share; // the chain outgrew its share of the set
+        if (valid && sub == 0 && (!staged || grew) && !fail) { // -> the list of chains fw_picks_kernel<true> takes, a wave each
+            const unsigned long long at = atomicAdd(&W.counters[3], 1ULL);
+            if (at < W.comb_cap) W.retry[at] = (u32)ci;
+            else fail = true;
+        }
+        u64 skipped = 0; // chains (by their number in the wave) whose picks are not evaluated here
+        {
+            const u64 fl = __ballot(fail || grew);
+            for (int q = 0; q < n_grp; ++q) {
+                const u64 qm = (G == 64 ? ~0ULL : ((1ULL << G) - 1)) << (q * G);
+                if (all_fail || (fl & qm)) skipped |= 1ULL << q;
+            }
+        }
+        const u64 to_wg = __ballot(fail); // lanes whose chain's record goes to the workgroup kernel
+        const u32 n_used = n < FC_SET ? n : FC_SET;
+        if (!all_fail)
+            for (u32 i0 = 0; i0 < n_used; i0 += 64) { // the set's entries, 64 at a time, a lane each
+                const u32 i = i0 + lane;
+                const unsigned long long key = i < n_used ? set[list[i]] - 1 : 0ULL;
+                const int kg = (int)(key >> FW_GRP_SHIFT) & 63;
+                const bool live = i < n_used && !((skipped >> kg) & 1);
+                const unsigned long long code = key & ((1ULL << FW_CODE_BITS) - 1);
+                const unsigned char *karea = sh_pool[wave] + kg * budget;
+                const u32 kci = (u32)__shfl((int)(u32)ci, kg * G, 64); // the descriptor of the key's chain
+                if (live && (key & FW_SLIDE_IN)) {
+                    const unsigned long long at = atomicAdd(&W.counters[2], 1ULL);
+                    if (at < W.slide_cap) W.slides[at] = PickItem{kci, 0u, code | FW_SLIDE};
+                    else W.fb_flag[((const FcHead *)karea)->g] = 1;
+                } else if (live)
+                    fc_eval<MODE>(B, karea, code, bf, map, cov_out, overflow, cursor, row0, evaluated, ref_rows);
+            }
+        if (valid && sub == 0 && (all_fail || ((to_wg >> (grp * G)) & (G == 64 ? ~0ULL : ((1ULL << G) - 1))))) W.fb_flag[g] = 1;
+        for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
+        if (lane < 32) sh_cnt[wave][lane] = 0;
+        if (n > FC_SET) // (the list lost entries: clear the whole set)
+            for (int i = lane; i < FC_SET; i += 64) set[i] = 0;
+        wave_sync();
+        if (lane == 0) sh_n[wave] = 0;
+        wave_sync();
+    }
+    if (MODE == 1) {
+        for (int dd = 32; dd; dd >>= 1) ref_rows += __shfl_xor(ref_rows, dd, 64);
+        if (lane == 0 && ref_rows) atomicAdd(cursor, (unsigned long long)ref_rows);
+    }
+    if (n_evaluated) {
+        for (int dd = 32; dd; dd >>= 1) evaluated += __shfl_xor(evaluated, dd, 64);
+        if (lane == 0 && evaluated) atomicAdd(n_evaluated, (unsigned long long)evaluated);
     }
 }
 

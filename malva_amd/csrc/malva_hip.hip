@@ -106,10 +106,11 @@ struct mg_ctx {
     int blocks_round_log2 = 24;                // see blocks_setup
     int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
+    int use_chain_kernel = 1;                  // record loop: the picks of a chain evaluated by the wave that holds them (fw_chain_kernel) instead of picks -> items -> eval
     int use_snp_kernel = 1;                    // record loop: chains of SNPs on panels of up to 8 diploid / 16 haploid samples in one kernel (fw_snp_kernel) instead of picks + eval
-    int use_chain_order = 0;                   // record loop: a round's chains sorted by their number of members before the picks and eval kernels take them.  Built to end the
-                                               // divergence of the per-member loops and measured: C5 record loop 2.59 -> 2.49 ms, C4 tier 2 5.8 -> 7.6 ms (the sorted order
-                                               // scatters the picks kernel's descriptor loads and the eval kernel's, which ran coalesced): off
+    int use_chain_order = 1;                   // record loop: what fw_snp_kernel left of a round's chains, listed in order of their number of members, before the
+                                               // chain kernel takes them (fw_order_kernel: less divergence in the per-member loops, and no walk over descriptors
+                                               // already dealt with)
     int use_packed_pool = 1;                   // record loop: signature k-mers assembled from 2-bit alleles (mg_panel_dev.pool_bytes) instead of bytes
     int map_ordered = 1;                       // records in order of the filter slot (map_home); fixed before the first key or filter entry goes in
     int map_dense = 0;                         // 1: record tables beyond 4 GB are sized at load 1/2 instead of 1/4 (measured at C4: the probe kernel got 25 % SLOWER -- longer walks, same translation cost)
@@ -739,6 +740,7 @@ MG_EXPORT int mg_set_option(mg_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "use_tickets")) c->use_tickets = value != 0;
     else if (!strcmp(name, "use_sub")) c->use_sub = value != 0;
     else if (!strcmp(name, "use_chain_order")) c->use_chain_order = value != 0;
+    else if (!strcmp(name, "use_chain_kernel")) c->use_chain_kernel = value != 0;
     else if (!strcmp(name, "use_snp_kernel")) c->use_snp_kernel = value != 0;
     else if (!strcmp(name, "exchange_pack")) c->exchange_pack = (int)std::max<int64_t>(0, std::min<int64_t>(2, value));
     else if (!strcmp(name, "exchange_pack_min_mb")) c->exchange_pack_min_mb = (int)std::max<int64_t>(0, value);
@@ -796,6 +798,7 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
     else if (!strcmp(name, "use_hit_entries")) *value = c->use_hit_entries;
     else if (!strcmp(name, "use_chain_order")) *value = c->use_chain_order;
+    else if (!strcmp(name, "use_chain_kernel")) *value = c->use_chain_kernel;
     else if (!strcmp(name, "use_snp_kernel")) *value = c->use_snp_kernel;
     else if (!strcmp(name, "blocks_round_log2")) *value = c->blocks_round_log2;
     else if (!strcmp(name, "map_ordered")) *value = c->map_ordered;
@@ -2640,26 +2643,32 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         W.order = c->use_chain_order ? R.order : nullptr;
         W.fb_flag = R.fb_flag;
         hipLaunchKernelGGL(fw_walk_kernel<MODE>, dim3(nblocks(R.round)), dim3(TPB), 0, c->stream, R.B, W, d_cov, d_overflow);
-        if (W.order) { // (grids sized for the round's worst case: workgroups beyond the chains written find nothing)
-            const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 16);
-            hipLaunchKernelGGL(fw_order_kernel<0>, dim3(og), dim3(TPB), 0, c->stream, W);
-            hipLaunchKernelGGL(fw_order_kernel<1>, dim3(og), dim3(TPB), 0, c->stream, W);
-        }
         const u32 n_haps = R.B.haploid ? R.B.n_samples : 2 * R.B.n_samples;
         if (c->use_snp_kernel && R.B.snp_chains && n_haps <= FW_SNP_MAX_HAPS) { // chains of SNPs whole, before the picks kernel sees them
             int GH = 2;
             while ((u32)GH < n_haps) GH *= 2;
             hipLaunchKernelGGL(fw_snp_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, GH, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
         }
+        if (W.order) { // what is left, by length (grids sized for the round's worst case: workgroups beyond the chains written find nothing)
+            const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 16);
+            hipLaunchKernelGGL(fw_order_kernel<0>, dim3(og), dim3(TPB), 0, c->stream, W);
+            hipLaunchKernelGGL(fw_order_kernel<1>, dim3(og), dim3(TPB), 0, c->stream, W);
+        }
         int G = 2; // lanes per chain: the samples, rounded up to a power of two
         while (G < 64 && (u32)G < R.B.n_samples) G *= 2;
         // the counting pass of `index` leaves a margin in the item buffer: the insert pass packs its chunks in another order
         const u32 cap_eff = MODE == 1 ? W.item_cap / 8 * 7 : W.item_cap;
-        hipLaunchKernelGGL(fw_picks_kernel<false>, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G, cap_eff);
-        if (G < 64) hipLaunchKernelGGL(fw_picks_kernel<true>, dim3(R.cus * 4), dim3(TPB), 0, c->stream, R.B, W, 64, cap_eff);
+        if (c->use_chain_kernel && c->k >= 17 && c->k <= MG_MAX_PACKED_K) { // picks and evaluation in one kernel; what it lists, the pair below takes
+            hipLaunchKernelGGL(fw_chain_kernel<MODE>, dim3(R.cus * 5), dim3(TPB), 0, c->stream, R.B, W, G, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
+                               d_evaluated);
+            hipLaunchKernelGGL(fw_picks_kernel<true>, dim3(R.cus * 4), dim3(TPB), 0, c->stream, R.B, W, 64, cap_eff);
+        } else {
+            hipLaunchKernelGGL(fw_picks_kernel<false>, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G, cap_eff);
+            if (G < 64) hipLaunchKernelGGL(fw_picks_kernel<true>, dim3(R.cus * 4), dim3(TPB), 0, c->stream, R.B, W, 64, cap_eff);
+        }
         hipLaunchKernelGGL(fw_eval_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
                            d_evaluated);
-        hipLaunchKernelGGL(fw_slide_kernel<MODE>, dim3(R.cus * 2), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
+        hipLaunchKernelGGL(fw_slide_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
         HIP_TRY(c, hipGetLastError());
     }
     return MG_OK;

@@ -164,3 +164,67 @@ def test_snp_chains_in_one_kernel_and_through_picks_and_eval(variant):
                         options=[("use_snp_kernel", on)])
         counts.append(st["device_general_kmers"])
     assert counts[0] == counts[1] > 10_000
+
+
+@pytest.mark.parametrize("variant", ["eight-samples", "haploid", "two-samples", "forty-samples"])
+def test_picks_evaluated_by_the_chain_kernel_and_through_items(variant):
+    """tier 2's picks of a chain are evaluated by the wave that holds them (fw_chain_kernel: geometry staged in LDS, chains in
+    order of their length) or written out as items for fw_eval_kernel (use_chain_kernel = 0), with and without the ordering
+    pass.  C5's indel / MNP clusters on panels of 8 samples (eight chains per wave), 2 samples (thirty-two chains per wave: the
+    staging area's share per chain is small, chains of many alleles take the item path) and 40 samples (a wave per chain).
+    Each way against the oracle; all ways enumerate the same number of signature k-mers."""
+    n_samples = {"two-samples": 2, "forty-samples": 40}.get(variant, 8)
+    panel = synth.indel_panel(12_000, seed=83, n_samples=n_samples)
+    counts = []
+    for chain, order in ((1, 1), (1, 0), (0, 1)):
+        st = run_recipe(panel, 35, 63, variant == "haploid", 1 << 27, n_rows=500_000, plant=5_000, min_general=5_000,
+                        options=[("use_chain_kernel", chain), ("use_chain_order", order)])
+        counts.append(st["device_general_kmers"])
+    assert counts[0] == counts[1] == counts[2] > 50_000
+
+
+@pytest.mark.parametrize("haploid", [False, True])
+def test_chains_with_bases_outside_acgt_in_reach(haploid):
+    """a base outside ACGT near or inside a cluster: fw_chain_kernel looks at every base a window of the chain can hold when it
+    stages the chain, and a chain with such a base takes the item path, where -- as before -- the record goes on to the workgroup
+    kernel if one of its windows holds the base (that kernel assembles byte by byte and leaves the k-mer out, as the reference
+    does).  Index from the oracle with made-up weights; coverages of every record the device kept equal the oracle's, and
+    coverages and flags are the same whichever way tier 2 runs."""
+    k, ref_k, bits = 35, 63, 1 << 26
+    panel = synth.indel_panel(12_000, seed=84)
+    rng = np.random.default_rng(9)
+    gpos = panel.gpos()
+    for v in rng.choice(panel.n, size=1_500, replace=False):
+        panel.genome[int(gpos[v]) + int(rng.integers(-30, 31))] = ord("N")
+    args = oracle_blocks(panel, k)
+    obf, omap = ocapi.BF(bits), ocapi.KMAP()
+    ocapi.index_blocks(obf, omap, panel.genome, **args, haploid=haploid, k=k)
+    obf.switch_mode()
+    cnts = obf.counts()
+    cnts[:] = (1 + (np.arange(cnts.size, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(97)).astype(np.uint16)
+    acgt = set(b"ACGT")
+    for key, _ in list(omap.items()):
+        if set(key) <= acgt:       # (a KMC table holds 2-bit k-mers: no scan can count a key with another letter in it)
+            omap.increment(key, 1 + ocapi.xxh3_64(key) % 97)
+    want_cov = ocapi.cover_blocks(obf, omap, panel.genome, **args, haploid=haploid, k=k)
+    items = [(k_, v_) for k_, v_ in omap.items() if set(k_) <= acgt]
+    seen = []
+    for chain, order in ((1, 1), (1, 0), (0, 1)):
+        with Context(k, ref_k, bits) as ctx:
+            ctx.set_option("use_chain_kernel", chain)
+            ctx.set_option("use_chain_order", order)
+            ctx.bf_import_sparse(BF_ALT, 1, bits, obf.set_positions(), obf.counts())
+            ctx.bf_import_sparse(BF_CTX, 1, bits, np.zeros(0, np.uint64), np.zeros(0, np.uint16))
+            ctx.map_import([k_ for k_, _ in items], np.array([v for _, v in items], dtype=np.int32))
+            ctx.reference_upload(panel.genome)
+            rp = ResidentPanel(panel, 0, haploid=haploid)
+            rp.call_step(ctx)
+            got = rp.results()
+            general_kmers, tier3_records = ctx.blocks_stats()[5:7]
+        kept = np.repeat(got["overflow"] == 0, np.diff(panel.var_allele_off.astype(np.int64)))
+        assert (got["overflow"] != 0).mean() < 0.08 and 100 < tier3_records < 0.2 * panel.n
+        assert np.array_equal(got["cov"][kept], want_cov[kept])
+        assert (want_cov[kept] > 0).sum() > 20_000
+        seen.append((got["overflow"].copy(), got["cov"].copy(), general_kmers))
+    for other in seen[1:]:
+        assert np.array_equal(other[0], seen[0][0]) and np.array_equal(other[1], seen[0][1])

@@ -8,6 +8,8 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="$PWD/bench.py --cpu-sample 0 --sustained-s 0 $*"
+# PMC_SCRIPT=tools/c5_blocks_bench.py: another python command of this repository instead of bench.py (its arguments follow the tag)
+if [ -n "$PMC_SCRIPT" ]; then BENCH="$PWD/$PMC_SCRIPT $*"; fi
 GROUPS_=(
  "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum"
  "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_PENDING_STALL_CYCLES_sum"
