@@ -560,19 +560,32 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
                     insert(c2 | tag);
                 } else if (m > FW_MAXU) fail = true;
                 else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
+                    // (only the members at which the two haplotypes differ: 2^h codes for h of them, not 2^m steps of which most change nothing)
                     const unsigned long long diff = c1 ^ c2;
+                    u32 het = 0;
+                    {
+                        unsigned long long t = bounds;
+                        for (int j = 0; j < m; ++j) {
+                            const int lo = __ffsll((unsigned long long)t) - 1;
+                            t &= t - 1;
+                            const int hi = __ffsll((unsigned long long)t) - 1;
+                            if (diff & (((1ULL << (hi - lo)) - 1) << lo)) het |= 1u << j;
+                        }
+                    }
+                    const int n_het = __popc(het);
                     unsigned long long code = c1;
                     insert(code | tag);
-                    for (u32 i = 1; i < (1u << m); ++i) {
-                        const int j = __ffs((int)i) - 1;
+                    for (u32 i = 1; i < (1u << n_het); ++i) {
+                        u32 hm = het; // the member this step flips: the (number of trailing zeros of i)-th of the differing ones
+                        for (int q = __ffs((int)i) - 1; q > 0; --q) hm &= hm - 1;
+                        const int j = __ffs((int)hm) - 1;
                         unsigned long long t = bounds;
                         for (int q = 0; q < j; ++q) t &= t - 1;
                         const int lo = __ffsll((unsigned long long)t) - 1;
                         t &= t - 1;
                         const int hi = __ffsll((unsigned long long)t) - 1;
-                        const unsigned long long fm = ((1ULL << (hi - lo)) - 1) << lo;
-                        code ^= diff & fm;
-                        if (diff & fm) insert(code | tag);
+                        code ^= diff & (((1ULL << (hi - lo)) - 1) << lo);
+                        insert(code | tag);
                         if (*my_cnt > share) break;
                     }
                 }
@@ -1236,19 +1249,32 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
                     insert(c2 | tag);
                 } else if (m > FW_MAXU) fail = true;
                 else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
+                    // (only the members at which the two haplotypes differ: 2^h codes for h of them, not 2^m steps of which most change nothing)
                     const unsigned long long diff = c1 ^ c2;
+                    u32 het = 0;
+                    {
+                        unsigned long long t = bounds;
+                        for (int j = 0; j < m; ++j) {
+                            const int lo = __ffsll((unsigned long long)t) - 1;
+                            t &= t - 1;
+                            const int hi = __ffsll((unsigned long long)t) - 1;
+                            if (diff & (((1ULL << (hi - lo)) - 1) << lo)) het |= 1u << j;
+                        }
+                    }
+                    const int n_het = __popc(het);
                     unsigned long long code = c1;
                     insert(code | tag);
-                    for (u32 i = 1; i < (1u << m); ++i) {
-                        const int j = __ffs((int)i) - 1;
+                    for (u32 i = 1; i < (1u << n_het); ++i) {
+                        u32 hm = het; // the member this step flips: the (number of trailing zeros of i)-th of the differing ones
+                        for (int q = __ffs((int)i) - 1; q > 0; --q) hm &= hm - 1;
+                        const int j = __ffs((int)hm) - 1;
                         unsigned long long t = bounds;
                         for (int q = 0; q < j; ++q) t &= t - 1;
                         const int lo = __ffsll((unsigned long long)t) - 1;
                         t &= t - 1;
                         const int hi = __ffsll((unsigned long long)t) - 1;
-                        const unsigned long long fm = ((1ULL << (hi - lo)) - 1) << lo;
-                        code ^= diff & fm;
-                        if (diff & fm) insert(code | tag);
+                        code ^= diff & (((1ULL << (hi - lo)) - 1) << lo);
+                        insert(code | tag);
                         if (*my_cnt > share) break;
                     }
                 }
