@@ -61,6 +61,17 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// One insertion row for every lane that calls (any subset of the wave, together): one returning atomic per wave.  A lane each
+// on ONE counter serialises at ~3 ns a row -- 14 ms of `index`'s insert pass per 4.4e6 REF k-mers (C5).
+__device__ __forceinline__ u32 wave_take(unsigned long long *cursor)
+{
+    const u64 callers = __ballot(true);
+    const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)callers) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(callers));
+    base = __shfl(base, leader, 64);
+    return (u32)base + (u32)__popcll(callers & ((1ULL << lane) - 1));
+}
 __device__ __forceinline__ int fw_bits(u32 n_alleles) { return n_alleles <= 2 ? 1 : 32 - __clz((int)n_alleles - 1); }
 
 // ---- tier 1 ------------------------------------------------------------------------------------------------------------------
@@ -766,7 +777,7 @@ __global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, i
             if (w > 0) atomicMax(&cov_out[a0 + mid_canon], (u32)w);
         } else if (is_ref) {
             if (MODE == 1) ++ref_rows;
-            else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+            else map_insert_key(map, bf, key, h, row0 + wave_take(cursor), row0);
         } else if (MODE == 2) {
             atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
             gate_set(bf, idx);
@@ -946,7 +957,7 @@ __global__ void __launch_bounds__(TPB) fw_eval_kernel(BlockBatch B, FlatWork W, 
             if (w > 0) atomicMax(&cov_out[a0 + mid_canon], (u32)w);
         } else if (is_ref) {
             if (MODE == 1) ++ref_rows;
-            else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+            else map_insert_key(map, bf, key, h, row0 + wave_take(cursor), row0);
         } else if (MODE == 2) {
             atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
             gate_set(bf, idx);
@@ -1089,7 +1100,7 @@ __device__ __forceinline__ void fc_eval(const BlockBatch &B, const unsigned char
         if (w > 0) atomicMax(&cov_out[hd.a0 + mid_canon], (u32)w);
     } else if (is_ref) {
         if (MODE == 1) ++ref_rows;
-        else map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+        else map_insert_key(map, bf, key, h, row0 + wave_take(cursor), row0);
     } else if (MODE == 2) {
         atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63)); // BF::add_key, bloom_filter.hpp:81-85
         gate_set(bf, idx);
@@ -1335,48 +1346,59 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
 }
 
 // Sliding signatures (var_block.hpp:130-144): the chain is the variant alone and the allele has k bases or more -- every k-mer of
-// the allele, coverage = truncating running mean over those with a weight, in order (main.cpp:162-176).  One WAVE per item:
-// the lanes take the k-mers (assembly, hash, lookup or insert), lane 0 folds their weights in order.
+// the allele, coverage = truncating running mean over those with a weight, in order (main.cpp:162-176).  SIXTEEN LANES per item,
+// four items per wave: the lanes take the k-mers (assembly, hash, lookup or insert) sixteen at a time, the group's first lane
+// folds their weights in order.  (An insertion of 35 to 60 bases at k = 35 has 1 to 26 k-mers, 13 on average: a whole wave
+// per item left four lanes in five idle.)
+constexpr int FW_SLIDE_G = 16;
 template <int MODE>
 __global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W, BFView bf, MapView map, u32 *cov_out, unsigned long long *cursor, u32 row0,
                                                        unsigned long long *n_evaluated)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int G = FW_SLIDE_G, N_GRP = 64 / G;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / G, sub = lane % G;
     const u64 n_items = min((unsigned long long)W.slide_cap, W.counters[2]);
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
+    const u64 gmask = ((1ULL << G) - 1) << (grp * G);
     const int k = B.k;
-    for (u64 it = (u64)blockIdx.x * FW_WAVES + wave; it < n_items; it += n_waves) {
-        const PickItem item = W.slides[it];
-        const u32 g = W.combs[item.comb].g;
-        if (__shfl((int)W.fb_flag[g], 0, 64)) continue;
-        const u32 a0 = B.var_allele_off[g];
+    for (u64 i0 = ((u64)blockIdx.x * FW_WAVES + wave) * N_GRP; i0 < n_items; i0 += n_waves * N_GRP) { // (whole waves: ballots and shuffles inside)
+        const u64 it = i0 + grp;
+        const bool have = it < n_items;
+        PickItem item{0u, 0u, 0ULL};
+        if (have) item = W.slides[it];
+        const u32 g = have ? W.combs[item.comb].g : 0u;
+        bool live = have && !W.fb_flag[g];
+        const u32 a0 = live ? B.var_allele_off[g] : 0u;
         const u32 a = (u32)(item.code & 127);
-        const u32 canon = B.canon[a0 + a];
-        const u32 ao = B.allele_off[a0 + a];
+        const u32 canon = live ? (u32)B.canon[a0 + a] : 0u;
+        const u32 ao = live ? B.allele_off[a0 + a] : 0u;
         const u8 *ap = B.pool + ao;
-        const int al = (int)(B.allele_off[a0 + a + 1] - ao);
+        const int al = live ? (int)(B.allele_off[a0 + a + 1] - ao) : 0;
         const bool is_ref = canon == 0;
-        const int n_kmers = al - k + 1;
+        const int n_kmers = live ? al - k + 1 : 0;
         // first: is every base ACGT?  (nothing is counted or inserted for a record the workgroup kernel will redo)
         bool good = k >= 17 && k <= MG_MAX_PACKED_K;
         if (B.pool2) {
-            for (int x = 32 * lane; x < al; x += 32 * 64) good = good && !ref_bad(B.poolbad, (u64)ao + (u64)x, al - x < 32 ? al - x : 32);
+            for (int x = 32 * sub; x < al; x += 32 * G) good = good && !ref_bad(B.poolbad, (u64)ao + (u64)x, al - x < 32 ? al - x : 32);
         } else
-            for (int x = lane; x < al; x += 64) {
+            for (int x = sub; x < al; x += G) {
                 bool o;
                 acgt_code(ap[x], &o);
                 good = good && o;
             }
-        if (!__all(good)) {
-            if (lane == 0) W.fb_flag[g] = 1;
-            continue;
+        const bool group_bad = (__ballot(live && !good) & gmask) != 0;
+        if (live && group_bad) {
+            if (sub == 0) W.fb_flag[g] = 1;
+            live = false;
         }
         u32 curr = 0;
         i32 nn = 0;
-        for (int p0 = 0; p0 < n_kmers; p0 += 64) {
-            const int p = p0 + lane;
+        int longest = live ? n_kmers : 0; // (the wave walks to its longest item)
+        for (int d = 32; d; d >>= 1) longest = max(longest, __shfl_xor(longest, d, 64));
+        for (int p0 = 0; p0 < longest; p0 += G) {
+            const int p = p0 + sub;
             i32 w = 0;
-            if (p < n_kmers) {
+            if (live && p < n_kmers) {
                 U128 Lf{0, 0};
                 if (B.pool2) { // the window out of the packed pool
                     Lf.lo = ref_codes(B.pool2, (u64)ao + (u64)p, k < 32 ? k : 32);
@@ -1392,31 +1414,29 @@ __global__ void __launch_bounds__(TPB) fw_slide_kernel(BlockBatch B, FlatWork W,
                 const U128 mform = shr128(U128{pairrev64(Lf.hi), pairrev64(Lf.lo)}, 2 * (64 - k));
                 const U128 rc{~mform.lo & mk.lo, ~mform.hi & mk.hi};
                 const U128 key = lt128(Lf, rc) ? Lf : rc;
-                const u64 h = xxh3_packed(key, k);
+                const u64 h = k == 35 ? xxh3_packed_fixed<35>(key.lo, key.hi) : xxh3_packed(key, k);
                 const u64 idx = mod_size(h, bf.mod);
                 if (MODE == 0) {
                     if (is_ref) w = k == (int)map.klen ? map_value(map, key, h, idx) : 0;
                     else w = (i32)bucket_count(map, bf.counts, idx);
                 } else if (MODE == 2) {
-                    if (is_ref) map_insert_key(map, bf, key, h, row0 + (u32)atomicAdd(cursor, 1ULL), row0);
+                    if (is_ref) map_insert_key(map, bf, key, h, row0 + wave_take(cursor), row0);
                     else {
                         atomicOr((unsigned long long *)&bf.words[idx >> 6], 1ULL << (idx & 63));
                         gate_set(bf, idx);
                     }
                 }
             }
-            if (MODE == 0) {
-                const int cnt = min(64, n_kmers - p0);
-                for (int j = 0; j < cnt; ++j) { // in order: the mean truncates at every step
-                    const i32 wj = __shfl(w, j, 64);
-                    if (wj > 0) {
+            if (MODE == 0)
+                for (int j = 0; j < G; ++j) { // in order: the mean truncates at every step (every group's first lane folds its own)
+                    const i32 wj = __shfl(w, grp * G + j, 64);
+                    if (sub == 0 && wj > 0) {
                         curr = (curr * (u32)nn + (u32)wj) / (u32)(nn + 1);
                         ++nn;
                     }
                 }
-            }
         }
-        if (lane == 0) {
+        if (live && sub == 0) {
             if (MODE == 0 && curr) atomicMax(&cov_out[a0 + canon], curr);
             if (MODE == 1 && is_ref) atomicAdd(cursor, (unsigned long long)n_kmers);
             if (n_evaluated) atomicAdd(n_evaluated, (unsigned long long)n_kmers);
