@@ -814,7 +814,7 @@ def record(job, elapsed, steps, warmup, kt, sustained):
                 blocks_traffic, blocks_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_blocks_%s.json (rocprofv3 PMC%s)" % (
                     job.workload, "; mean of the diploid and the haploid job's loops" if t.get("haploid_included") else "")
         loop_ms = kt["record_loop"]
-        out["roofline_blocks"] = {"kernel": "cut_flags + flag_scatter + panel_lone + fw_walk + fw_picks + fw_eval + cover_blocks<0> + genotype (the record loop, main.cpp:522-579)",
+        out["roofline_blocks"] = {"kernel": "cut_flags + flag_scatter + panel_lone + fw_walk + fw_snp + fw_order + fw_chain (+ fw_picks<true> / fw_eval for what it lists) + fw_slide + cover_blocks<0> + genotype (the record loop, main.cpp:522-579)",
                                   "bound": "hbm", "achieved": alg / (loop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": blocks_traffic, "traffic_source": blocks_tsrc, "algorithmic_bytes_per_launch": alg,
                                   "bytes_per_unit": "64 + 36 K + 8 G (SURVEY 8(d))", "units_per_launch": job.n_vars, "signature_kmers": n_sig,

@@ -80,9 +80,11 @@ struct LoneClass {
     bool lone, eligible;
     u64 site, mask;
     u32 a0, A;
-    u8 cls; // REC_SNP: one base for one base, every allele; REC_PHASED: every sample's genotype phased (or the run is haploid)
+    unsigned short cls; // what fw_walk_kernel and fw_snp_kernel want to know of a record outside tier 1, see REC_*
 };
-constexpr u8 REC_SNP = 1, REC_PHASED = 2;
+// REC_SNP: one base for one base, every allele; REC_PHASED: every sample's genotype phased (or the run is haploid); REC_CODES: at
+// most four alleles, all of them A, C, G or T, and their 2-bit codes in the high byte (allele a at bits 8 + 2a)
+constexpr unsigned short REC_SNP = 1, REC_PHASED = 2, REC_CODES = 4;
 // The loads are arranged in three LEVELS of mutually independent requests (what a thread of this kernel does is wait for
 // loads: the first form, a chain of fifteen dependent ones -- block, block ends, its sequence, the sequence's base; genotype
 // word, canonical allele, next genotype word ... -- ran at a quarter of the rate its 2.5 lines of HBM traffic per record allow):
@@ -91,7 +93,7 @@ constexpr u8 REC_SNP = 1, REC_PHASED = 2;
 //   3  the flanks and allele bytes (iso_cover_body), then the records
 // The genotype words give a mask of RAW allele numbers; the canonical numbers (variant.hpp:228-240) are applied to the mask
 // afterwards, so their loads wait for nothing but the allele range.
-__device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32 *blk_var_off, const u32 *var_block, u64 v, int k, int haploid)
+__device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32 *blk_var_off, const u32 *var_block, u64 v, int k, int haploid, const u8 *pool)
 {
     LoneClass c{};
     // level 1
@@ -152,7 +154,7 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
     for (int a = 0; a < 4; ++a)
         if (a < (int)c.A) snp = snp && ao[a + 1] - ao[a] == 1;
     for (u32 a = 4; a < c.A && snp; ++a) snp = snp && P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a] == 1;
-    c.cls = (u8)((snp ? REC_SNP : 0) | (phased || haploid ? REC_PHASED : 0));
+    c.cls = (unsigned short)((snp ? REC_SNP : 0) | (phased || haploid ? REC_PHASED : 0));
     // a block of one variant, alleles all shorter than k (at most 64 of them: the presence mask), flanks inside the sequence
     bool lone = b1 - b0 == 1 && c.A <= 64 && p >= k / 2 && (long long)p + rs + (k + 1) / 2 <= (long long)clen;
     if (lone) {
@@ -162,7 +164,22 @@ __device__ __forceinline__ LoneClass classify_lone(const PanelView &P, const u32
         for (u32 a = 4; a < c.A; ++a) lone = lone && (int)(P.allele_off[c.a0 + a + 1] - P.allele_off[c.a0 + a]) < k;
     }
     c.lone = lone;
-    if (!lone) return c;
+    if (!lone) {
+        if (snp && c.A <= 4) { // the alleles' bases as codes, for fw_snp_kernel (which then reads one byte per member instead of
+                               // allele range -> allele offset -> base)
+            u32 codes = 0;
+            bool acgt = true;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < (int)c.A) {
+                    bool o;
+                    codes |= acgt_code(pool[ao[a]], &o) << (2 * a);
+                    acgt = acgt && o;
+                }
+            if (acgt) c.cls = (unsigned short)(c.cls | REC_CODES | (codes << 8));
+        }
+        return c;
+    }
     c.eligible = present && p >= k && (long long)p <= (long long)clen - k; // var_block.hpp:104
     u64 mask = 0;
     if (c.eligible) { // build_alleles_combs on a chain of one (var_block.hpp:734-786): the alleles some panel haplotype carries
@@ -190,10 +207,10 @@ __device__ __forceinline__ void list_append(bool take, u32 value, u32 *list, uns
 constexpr int LONE_TILES = 8; // tiles of TPB / 2 records a workgroup of panel_lone_kernel takes (one list reservation per workgroup:
                               // a returning atomic per wave on ONE counter serialises at ~10 ns each -- 3 ms per 5e6 records)
 template <bool SLOW>
-__global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
+__global__ void __launch_bounds__(TPB, SLOW ? 1 : 8) panel_lone_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                          const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, const u8 *pool, int k,
                                                          int haploid, BFView bf, MapView map, u32 *cov_out, u32 *need_slow, u32 call_no, u32 *gen_list,
-                                                         unsigned long long *counters, u8 *rec_class)
+                                                         unsigned long long *counters, unsigned short *rec_class)
 {
     __shared__ u32 sh_gen[LONE_TILES * TPB / 2];
     __shared__ u32 sh_n, sh_sigs;
@@ -206,7 +223,7 @@ __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars
         const u64 t = ((u64)blockIdx.x * LONE_TILES + tile) * TPB + threadIdx.x;
         const u64 v = t >> 1;
         if (v >= n_vars) break;
-        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid, pool);
         if (!SLOW && !(t & 1)) {
             if (!c.lone) {
                 sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
@@ -227,9 +244,9 @@ __global__ void __launch_bounds__(TPB) panel_lone_kernel(PanelView P, u64 n_vars
     for (u32 i = threadIdx.x; i < sh_n; i += TPB) gen_list[sh_base + i] = sh_gen[i];
 }
 // index time: lone records are inserted here (REF key of record v takes insertion row row0 + v), the others listed
-__global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
+__global__ void __launch_bounds__(TPB, 8) panel_lone_index_kernel(PanelView P, u64 n_vars, const u32 *__restrict__ blk_var_off, const u32 *__restrict__ var_block,
                                                                const u8 *reference, const u8 *pool, int k, int haploid, BFView bf, MapView map, u32 row0,
-                                                               u8 *overflow, u32 *gen_list, unsigned long long *counters, u8 *rec_class)
+                                                               u8 *overflow, u32 *gen_list, unsigned long long *counters, unsigned short *rec_class)
 {
     __shared__ u32 sh_gen[LONE_TILES * TPB];
     __shared__ u32 sh_n;
@@ -239,7 +256,7 @@ __global__ void __launch_bounds__(TPB) panel_lone_index_kernel(PanelView P, u64 
     for (int tile = 0; tile < LONE_TILES; ++tile) {
         const u64 v = ((u64)blockIdx.x * LONE_TILES + tile) * TPB + threadIdx.x;
         if (v >= n_vars) break;
-        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid);
+        const LoneClass c = classify_lone(P, blk_var_off, var_block, v, k, haploid, pool);
         if (!c.lone) {
             sh_gen[atomicAdd(&sh_n, 1u)] = (u32)v;
             rec_class[v] = c.cls;
@@ -411,7 +428,7 @@ __global__ void __launch_bounds__(TPB) fw_walk_kernel(BlockBatch B, FlatWork W, 
         // and -- along a chain of two or more, diploid -- no sample is unphased at any member (tier 1 left that in rec_class):
         // fw_snp_kernel takes such a chain whole unless its window leaves the sequence or holds a base outside ACGT
         bool snps = true;
-        const u8 need = (u8)(REC_SNP | (d.m > 1 ? REC_PHASED : 0));
+        const unsigned short need = (unsigned short)(REC_SNP | REC_CODES | (d.m > 1 ? REC_PHASED : 0));
         for (int j = 0; j < d.m; ++j) {
             const u32 v = g + d.rel[j];
             snps = snps && (B.rec_class[v] & need) == need;
@@ -680,7 +697,7 @@ __global__ void __launch_bounds__(TPB) fw_picks_kernel(BlockBatch B, FlatWork W,
 // skipped by them.  The decision depends on the chain and the panel alone, so `index`'s two passes agree.
 constexpr u32 FW_SNP_MAX_HAPS = 16;
 template <int MODE>
-__global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, unsigned long long *cursor, u32 row0,
+__global__ void __launch_bounds__(TPB, 8) fw_snp_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, unsigned long long *cursor, u32 row0,
                                                      unsigned long long *n_evaluated)
 {
     const int lane = threadIdx.x & 63;
@@ -714,7 +731,6 @@ __global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, i
         unsigned long long code = 0; // the haplotype's pick as fw_picks_kernel codes it: the members' alleles, ceil(log2(alleles)) bits each
         if (mine) {
             const i32 ref_len = (i32)B.contig_len[d.cid];
-            int sh = 0;
             const int w0 = B.pos[g] - k / 2;
             good = w0 >= 0 && w0 + k <= ref_len;
             if (good) {
@@ -722,26 +738,20 @@ __global__ void __launch_bounds__(TPB) fw_snp_kernel(BlockBatch B, FlatWork W, i
                 Lf.lo = ref_codes(B.ref2, at, k < 32 ? k : 32);
                 if (k > 32) Lf.hi = ref_codes(B.ref2, at + 32, k - 32);
                 good = !ref_bad(B.refbad, at, k < 32 ? k : 32) && (k <= 32 || !ref_bad(B.refbad, at + 32, k - 32));
-                for (int j = 0; j < m && good; ++j) {
+                for (int j = 0; j < m && good; ++j) { // (a marked chain: every member one base for one base, at most four alleles, all
+                                                      // ACGT, phased wherever that matters -- fw_walk_kernel saw to it, from tier 1's class words)
                     const u32 v = g + d.rel[j];
                     const u32 gt = gt_at(B, v, smp);
-                    if (!B.haploid && m > 1 && !((gt >> 14) & 1)) good = false; // unphased along a chain: every mix of its two haplotypes is a pick
                     const u32 a = second ? (gt >> 7) & 127 : gt & 127;
-                    const u32 s0 = B.var_allele_off[v];
-                    const int bits = fw_bits(B.var_allele_off[v + 1] - s0);
-                    if (sh + bits > 63) good = false;
-                    code |= (unsigned long long)a << (sh & 63);
-                    sh += bits;
-                    const u32 ao = B.allele_off[s0 + a];
-                    if (B.allele_off[s0 + a + 1] - ao != 1) good = false; // (a longer ALT of a record whose shortest allele has one base)
+                    const u32 codes = (u32)B.rec_class[v] >> 8;
+                    if (a > 3) good = false; // (a genotype beyond the record's alleles: left to the picks kernel's reading of it)
+                    code |= (unsigned long long)(a & 3) << (2 * j);
                     if (j == jm) mid_allele = a;
                     const int x = B.pos[v] - w0;
                     if (good && x >= 0 && x < k) { // the member's base at its own place in the window (a member outside it changes nothing)
-                        bool o;
-                        const u64 code = acgt_code(B.pool[ao], &o);
-                        good = o;
-                        if (x < 32) Lf.lo = (Lf.lo & ~(3ULL << (2 * x))) | code << (2 * x);
-                        else Lf.hi = (Lf.hi & ~(3ULL << (2 * (x - 32)))) | code << (2 * (x - 32));
+                        const u64 c2 = (codes >> (2 * a)) & 3;
+                        if (x < 32) Lf.lo = (Lf.lo & ~(3ULL << (2 * x))) | c2 << (2 * x);
+                        else Lf.hi = (Lf.hi & ~(3ULL << (2 * (x - 32)))) | c2 << (2 * (x - 32));
                     }
                 }
             }

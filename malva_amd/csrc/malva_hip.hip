@@ -2565,7 +2565,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     TRY(scratch(c, c->s_blk[7], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_retry));                // one round's chains to retry
     TRY(scratch(c, c->s_blk[13], 4 * (R.round * FW_COMBS_PER_REC + 64), &q_order));               // one round's chains in order of their length
     void *q_class;
-    TRY(scratch(c, c->s_blk[14], n, &q_class));                                                   // per listed record: REC_SNP | REC_PHASED
+    TRY(scratch(c, c->s_blk[14], 2 * n, &q_class));                                               // per listed record: REC_* and the alleles' codes
     if (!d_var_block) { // derive it from the cut: heads -> scan
         void *fl, *ts;
         TRY(scratch(c, c->s_blk[8], 4 * n, &q[6]));
@@ -2590,7 +2590,7 @@ int blocks_setup(mg_ctx *c, const mg_panel_dev *p, const u32 *d_blk_var_off, con
     B.n_samples = p->n_samples; B.haploid = haploid; B.k = (int)c->k;
     B.set_limit = c->blocks_set_limit;
     B.snp_chains = c->use_snp_chains;
-    B.rec_class = (const u8 *)q_class;
+    B.rec_class = (const unsigned short *)q_class;
     // the alleles packed like the reference (every call: the panel is the caller's) -- unless the pool is too small to hold alleles worth
     // it (a SNP panel: two one-base alleles per record; fw_eval takes alleles of up to 4 bases from the bytes anyway)
     if (p->pool_bytes && p->pool_bytes * 2 > n * 5 && ((uintptr_t)p->pool & 3) == 0 && c->use_packed_pool) {
@@ -2779,10 +2779,10 @@ MG_EXPORT int mg_cover_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     if (++c->iso_call_no == 0) c->iso_call_no = 1;
     hipLaunchKernelGGL(panel_lone_kernel<false>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
-                       c->iso_call_no, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
+                       c->iso_call_no, R.gen_list, c->d_gen_count, (unsigned short *)R.B.rec_class);
     hipLaunchKernelGGL(panel_lone_kernel<true>, dim3((unsigned)((2 * n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref,
                        (const u64 *)c->d_ref2, (const u32 *)c->d_refbad, (const u8 *)p->pool, (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32 *)d_cov_out, need_slow,
-                       c->iso_call_no, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
+                       c->iso_call_no, R.gen_list, c->d_gen_count, (unsigned short *)R.B.rec_class);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_b[1], c->stream));
     TRY(blocks_tier2<0>(R, (u32 *)d_cov_out, (u8 *)d_overflow_out, nullptr, 0u, c->d_gen_count + 3));
@@ -2973,7 +2973,7 @@ MG_EXPORT int mg_index_blocks_device(mg_ctx *c, const mg_panel_dev *p, const voi
     HIP_TRY(c, hipMemsetAsync(c->d_gen_count, 0, 64, c->stream));
     // tier 1: lone and short records are inserted at once; everything else is listed
     hipLaunchKernelGGL(panel_lone_index_kernel, dim3((unsigned)((n + (u64)LONE_TILES * TPB - 1) / ((u64)LONE_TILES * TPB))), dim3(TPB), 0, c->stream, R.P, n, R.B.blk_var_off, R.B.var_block, (const u8 *)c->d_ref, (const u8 *)p->pool,
-                       (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count, (u8 *)R.B.rec_class);
+                       (int)c->k, haploid, view(c, MG_BF_ALT), view(c), (u32)c->map.rows_total, (u8 *)d_overflow_out, R.gen_list, c->d_gen_count, (unsigned short *)R.B.rec_class);
     HIP_TRY(c, hipGetLastError());
     c->map.rows_total += n;
     unsigned long long *d_cursor = c->d_gen_count + 1;

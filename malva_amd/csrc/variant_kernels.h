@@ -211,7 +211,7 @@ __device__ __forceinline__ void iso_cover_body(const u8 *reference, const u64 *_
     }
 }
 template <bool SLOW>
-__global__ void __launch_bounds__(TPB) iso_cover_kernel(const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, u64 n_vars, const u64 *pos,
+__global__ void __launch_bounds__(TPB, SLOW ? 1 : 8) iso_cover_kernel(const u8 *reference, const u64 *__restrict__ ref2, const u32 *__restrict__ refbad, u64 n_vars, const u64 *pos,
                                                         const u32 *var_allele_off, const u32 *allele_off, const u8 *pool, const u64 *present_mask,
                                                         const u8 *flags, int k, BFView bf, MapView map, u32 *cov_out, u32 *need_slow,
                                                         u32 call_no)
@@ -349,7 +349,7 @@ struct BlockBatch {
     const uint16_t *sp_gt;     // ... and that genotype.  A panel of tens of thousands of samples is nearly all 0|0.
     u32 sp_default;            // the genotype word of every sample WITHOUT an entry (0|0 phased, or 0/0 for an unphased panel)
     int snp_chains;            // fw_eval_kernel's fixed-geometry assembly for chains of SNPs (option use_snp_chains)
-    const u8 *rec_class;       // [n_vars] per record outside tier 1: REC_SNP | REC_PHASED (written by the tier-1 kernels of the same call)
+    const unsigned short *rec_class; // [n_vars] per record outside tier 1: REC_* flags and the alleles' codes (written by the tier-1 kernels of the same call)
     const u64 *pool2;          // the allele pool packed like the reference (2 bits per base at the pool's own offsets) + its not-ACGT bits,
     const u32 *poolbad;        // built at the start of the call when the panel states pool_bytes; else NULL: alleles are read byte by byte
     u32 n_samples;

@@ -1459,6 +1459,7 @@ int call_main(const Options &o)
 
     auto prefix_of = [&](Variant &v) { return std::move(v.text_prefix); }; // (made by the thread that decoded the record)
 
+    const bool iso_path = getenv("MALVA_GENO_ISO_PATH") && atoi(getenv("MALVA_GENO_ISO_PATH")) != 0;
     std::string base_name;
     bool base_known = false, base_found = false;
     uint64_t base_value = 0;
@@ -1474,8 +1475,12 @@ int call_main(const Options &o)
             base_name = seq_name;
             base_known = true;
         }
+        // Every block takes the resident record loop (mg_cover_blocks: the panel batch goes up once, then tier 1 for the lone
+        // records -- classification and the panel's genotypes gathered on the device --, tiers 2 and 3 for the others: the
+        // kernels bench.py times).  MALVA_GENO_ISO_PATH=1 keeps the older split, where a lone record goes through the fused
+        // mg_call_isolated with a presence mask made here (tests run both: same bytes).
         // (k beyond the packed forms: exact-map keys live in the context's host-side list, which only the ASCII batch lookups reach)
-        const bool lone = o.k <= MG_MAX_PACKED_K && vb.is_lone_short() && base_found &&
+        const bool lone = iso_path && o.k <= MG_MAX_PACKED_K && vb.is_lone_short() && base_found &&
                           (long)vb.vars[0].ref_pos + vb.vars[0].ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
         if (lone) {
             Variant &v = vb.vars[0];

@@ -40,6 +40,8 @@ def test_haploid_example_byte_identical(tmp_path, golden_dir):
     run_cli(["index"] + common)
     out = run_cli(["call"] + common)
     assert out == open(os.path.join(golden_dir, "haploid.malva.vcf")).read()
+    # every block through the resident record loop (the default), or lone records through the fused mg_call_isolated: same bytes
+    assert run_cli(["call"] + common, env=dict(os.environ, MALVA_GENO_ISO_PATH="1")) == out
 
 
 @pytest.mark.parametrize("seed,haploid,verbose,k,ref_k", [(11, False, True, 35, 43), (12, True, True, 35, 43), (13, False, False, 31, 45),
@@ -57,6 +59,7 @@ def test_clustered_panel_matches_oracle(tmp_path, seed, haploid, verbose, k, ref
     args += [prefix + ".fa", prefix + ".vcf", table]
     run_cli(["index"] + args)
     got = run_cli(["call"] + args)
+    assert run_cli(["call"] + args, env=dict(os.environ, MALVA_GENO_ISO_PATH="1")) == got    # (lone records through the fused entry instead of tier 1)
     assert got.count("\n") == want.count("\n")
     strip = lambda s: re.sub(r";GTS=[^\t]*", "", s)         # (the likelihood list only: COVS before it and GT:GQ behind it stay)
     assert strip(got) == strip(want)                 # header, records, COVS, GT, GQ: identical
