@@ -17,7 +17,7 @@ from collections import defaultdict
 
 out, wl = sys.argv[1], sys.argv[2]
 CUT = ("cut_flags_kernel", "tile_reduce_kernel", "part_scan_kernel", "tile_rescan_kernel", "flag_scatter_kernel")
-LOOP = ("panel_lone_kernel", "fw_walk_kernel", "fw_snp_kernel", "fw_order_kernel", "fw_picks_kernel", "fw_eval_kernel", "fw_slide_kernel", "fb_compact_kernel",
+LOOP = ("panel_lone_kernel", "fw_walk_kernel", "fw_snp_kernel", "fw_order_kernel", "fw_chain_kernel", "fw_picks_kernel", "fw_eval_kernel", "fw_slide_kernel", "fb_compact_kernel",
         "cover_blocks_kernel", "fw_finish_kernel", "ref_pack_kernel")
 
 
