@@ -470,45 +470,46 @@ struct PanelGenotypes {
     uint16_t sp_default = (uint16_t)(1u << 14);
     size_t bytes() const { return sparse ? 4 * sp_off.size() + 6 * sp_sample.size() : 2 * gt.size(); }
 };
-inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_vars, uint32_t n_samples, bool haploid)
+// one sample's genotype as the device takes it: a1 | a2 << 7 | phased << 14
+inline uint16_t genotype_word(const Variant &v, size_t s_, bool haploid)
+{
+    const auto &p2 = v.genotypes[s_];
+    if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
+        throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
+                                 " (the reference reads out of bounds here)");
+    if (haploid) return (uint16_t)(p2.first | (1u << 14));
+    return (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
+}
+inline PanelGenotypes pack_genotypes(const std::vector<const Variant *> &vars, size_t n_vars, uint32_t n_samples, bool haploid)
 {
     PanelGenotypes g;
     g.sparse = n_samples > SPARSE_GT_SAMPLES;
-    for (const Block &b : blocks) // (records decoded on the device arrive in the sparse form whatever the panel's size)
-        for (const Variant &v : b.vars) g.sparse = g.sparse || v.gt_deferred;
+    for (const Variant *vp : vars) g.sparse = g.sparse || vp->gt_deferred; // (records decoded on the device arrive in the sparse form whatever the panel's size)
     if (!g.sparse) g.gt.assign(n_vars * n_samples, 0);
     // haploid mode reads the first allele only (var_block.hpp:751): the word is reduced to it, so that a ploidy-1 panel --
     // whose second "allele" is whatever htslib's layout puts behind the first -- is as sparse as it looks
-    auto word = [&](const Variant &v, size_t s_) -> uint16_t {
-        const auto &p2 = v.genotypes[s_];
-        if (p2.first >= v.n_alleles() || p2.second >= v.n_alleles())
-            throw std::runtime_error("GT allele beyond the kept ALT list at " + v.seq_name + ":" + std::to_string(v.ref_pos + 1) +
-                                     " (the reference reads out of bounds here)");
-        if (haploid) return (uint16_t)(p2.first | (1u << 14));
-        return (uint16_t)(p2.first | (p2.second << 7) | ((v.phasing[s_] ? 1 : 0) << 14));
-    };
+    auto word = [&](const Variant &v, size_t s_) -> uint16_t { return genotype_word(v, s_, haploid); };
     if (g.sparse) { // the default word: 0|0 phased or 0/0 unphased, whichever the batch holds more of (a sample of it decides)
         size_t phased0 = 0, unphased0 = 0, seen = 0;
-        for (const Block &b : blocks) {
-            for (const Variant &v : b.vars) {
-                if (v.gt_deferred) { // decoded on the device: its batch's default stands for its samples
-                    (v.sp_default ? phased0 : unphased0) += 64;
-                    seen += 64;
-                    continue;
-                }
+        for (const Variant *vp : vars) {
+            const Variant &v = *vp;
+            if (v.gt_deferred) { // decoded on the device: its batch's default stands for its samples
+                (v.sp_default ? phased0 : unphased0) += 64;
+                seen += 64;
+            } else
                 for (size_t s_ = 0; s_ < v.genotypes.size() && seen < 200000; s_ += 7, ++seen) {
                     const uint16_t w = word(v, s_);
                     phased0 += w == (1u << 14);
                     unphased0 += w == 0;
                 }
-            }
             if (seen >= 200000) break;
         }
         g.sp_default = unphased0 > phased0 ? 0 : (uint16_t)(1u << 14);
     }
     size_t row = 0;
-    for (const Block &b : blocks)
-        for (const Variant &v : b.vars) {
+    for (const Variant *vp : vars)
+        {
+            const Variant &v = *vp;
             if (v.gt_deferred) { // already the sparse layout (mg_decode_gt_text), against its own batch's default
                 if (!g.sparse) throw std::runtime_error("internal: deferred genotypes on a panel of few samples");
                 if (v.max_allele >= (uint32_t)v.n_alleles())
@@ -544,6 +545,22 @@ inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_
             ++row;
         }
     return g;
+}
+
+inline PanelGenotypes pack_genotypes(const std::vector<Block> &blocks, size_t n_vars, uint32_t n_samples, bool haploid)
+{
+    std::vector<const Variant *> vars;
+    vars.reserve(n_vars);
+    for (const Block &b : blocks)
+        for (const Variant &v : b.vars) vars.push_back(&v);
+    return pack_genotypes(vars, n_vars, n_samples, haploid);
+}
+inline PanelGenotypes pack_genotypes(const std::vector<Variant> &records, size_t n_vars, uint32_t n_samples, bool haploid)
+{
+    std::vector<const Variant *> vars;
+    vars.reserve(records.size());
+    for (const Variant &v : records) vars.push_back(&v);
+    return pack_genotypes(vars, n_vars, n_samples, haploid);
 }
 
 // ---- index file (index_file.hpp): payload out of / into the contexts ---------------------------------------------------
@@ -1178,9 +1195,13 @@ struct Batch { // inputs of mg_call_isolated (isolated) or mg_lookup_cover + mg_
     Rows rows;
     std::vector<uint8_t> is_ref;
     std::vector<uint64_t> sig_kmer_off{0}, allele_sig_off{0}, var_gt_off{0};
-    // general blocks, enumerated on the device (mg_cover_blocks); the Block objects are kept until the batch has
-    // run, for the variants the device hands back (overflow) and for the panel genotypes
-    std::vector<Block> blocks;
+    // general blocks, enumerated on the device (mg_cover_blocks); the records are kept until the batch has run, for the
+    // panel genotypes and for the blocks the device hands back (a Block is rebuilt for those alone: one vector per block
+    // kept alive cost a malloc per lone record once every block came this way)
+    std::vector<Variant> vars;
+    std::vector<int32_t> var_slot;  // record -> its place in `vars`, or -1: a lone record the device cannot hand back, not kept
+    std::vector<uint16_t> gt_dense; // a panel of few samples: the genotype words, made as the records are batched (else packed from `vars` by the worker)
+    bool dense_gt = false, wide_alleles = false;
     std::vector<const std::string *> block_ref;
     std::vector<uint64_t> blk_base;
     std::vector<uint32_t> blk_len, blk_var_off{0}, ref_size, min_size;
@@ -1294,6 +1315,10 @@ int call_main(const Options &o)
     const size_t batch_records = getenv("MALVA_GENO_BATCH") ? (size_t)std::max(1L, atol(getenv("MALVA_GENO_BATCH"))) : 200000;
     std::vector<Rec> recs;
     Batch iso, gen;
+    // few samples and every record's genotypes decoded on the host: the words are made while batching
+    const size_t n_samples_kept = vcf.keep.size();
+    const bool dense_gt = n_samples_kept <= SPARSE_GT_SAMPLES && !vcf.defer_genotypes;
+    gen.dense_gt = dense_gt;
     std::atomic<size_t> gt_bytes_uploaded{0}; // panel genotypes handed to mg_cover_blocks[_sparse], all batches
     const std::string best_default = o.haploid ? "0" : "0/0";
     auto n_gt = [&](uint64_t A) { return o.haploid ? A : A * (A + 1) / 2; };
@@ -1329,19 +1354,20 @@ int call_main(const Options &o)
             const uint32_t n_samples = (uint32_t)vcf.keep.size();
             std::vector<uint8_t> overflow(n, 0);
             bool device_ok = o.k <= MG_MAX_PACKED_K && !getenv("MALVA_GENO_HOST_ENUM"); // the variable forces the host enumerator (tests)
-            for (const Block &b : gen.blocks)
-                for (const Variant &v : b.vars)
-                    if (v.n_alleles() > 127) device_ok = false;
-            const PanelGenotypes pg = pack_genotypes(gen.blocks, n, n_samples, o.haploid);
+            if (gen.wide_alleles) device_ok = false;
+            const size_t n_blocks = gen.blk_var_off.size() - 1;
+            PanelGenotypes pg;
+            if (gen.dense_gt) pg.gt = std::move(gen.gt_dense);
+            else pg = pack_genotypes(gen.vars, n, n_samples, o.haploid); // (every record of such a batch is kept)
             gt_bytes_uploaded += pg.bytes();
             if (device_ok && pg.sparse)
-                dev.check(mg_cover_blocks_sparse(dev.ctx, gen.blocks.size(), gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
+                dev.check(mg_cover_blocks_sparse(dev.ctx, n_blocks, gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
                                                  gen.ref_size.data(), gen.min_size.data(), gen.is_present.data(), gen.var_allele_off.data(),
                                                  gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), pg.sp_off.data(), pg.sp_sample.data(),
                                                  pg.sp_gt.data(), pg.sp_default, n_samples, o.haploid, gen.cov.data(), overflow.data()),
                           "mg_cover_blocks_sparse"); // extract_kmers + set_coverages, main.cpp:556-557
             else if (device_ok)
-                dev.check(mg_cover_blocks(dev.ctx, gen.blocks.size(), gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
+                dev.check(mg_cover_blocks(dev.ctx, n_blocks, gen.blk_base.data(), gen.blk_len.data(), gen.blk_var_off.data(), n, gen.ipos.data(),
                                           gen.ref_size.data(), gen.min_size.data(), gen.is_present.data(), gen.var_allele_off.data(),
                                           gen.allele_off.data(), gen.pool.data(), gen.pool.size(), gen.canon.data(), pg.gt.data(), n_samples, o.haploid,
                                           gen.cov.data(), overflow.data()),
@@ -1351,12 +1377,16 @@ int call_main(const Options &o)
             // blocks the device handed back (a capacity was exceeded, or a window was clipped by a contig end):
             // host enumerator + mg_lookup_cover for exactly those blocks
             size_t n_fallback = 0;
-            for (size_t b = 0; b < gen.blocks.size(); ++b) {
+            for (size_t b = 0; b < n_blocks; ++b) {
                 bool redo = false;
                 for (uint32_t v = gen.blk_var_off[b]; v < gen.blk_var_off[b + 1]; ++v) redo = redo || overflow[v];
                 if (!redo) continue;
                 ++n_fallback;
-                Block &blk = gen.blocks[b];
+                Block blk((int)o.k); // (rebuilt from the batch's records: nothing reads them after this)
+                for (uint32_t v = gen.blk_var_off[b]; v < gen.blk_var_off[b + 1]; ++v) {
+                    if (gen.var_slot[v] < 0) throw std::runtime_error("internal: the device handed back a record tier 1 should have taken");
+                    blk.add(std::move(gen.vars[(size_t)gen.var_slot[v]]));
+                }
                 genotypes_from_entries(blk);
                 const auto sigs = blk.extract(*gen.block_ref[b], o.haploid);
                 Rows rows;
@@ -1443,6 +1473,15 @@ int call_main(const Options &o)
             if (fwrite(text.data(), 1, text.size(), stdout) != text.size()) throw std::runtime_error("cannot write the output");
         }
     };
+    auto reserve_general = [&](Batch &b) { // (a batch's vectors at their final size at once: fifteen of them grew by doubling, record by record)
+        const size_t n = batch_records + 64;
+        for (auto *v32 : {&b.blk_len, &b.blk_var_off, &b.ref_size, &b.min_size, &b.var_allele_off}) v32->reserve(n + 1);
+        b.allele_off.reserve(2 * n + 1);
+        b.blk_base.reserve(n); b.ipos.reserve(n); b.is_present.reserve(n); b.canon.reserve(2 * n); b.freq.reserve(2 * n); b.pool.reserve(4 * n);
+        b.var_gt_off.reserve(n + 1); b.var_slot.reserve(n); b.block_ref.reserve(n);
+        if (b.dense_gt) b.gt_dense.reserve(n * n_samples_kept);
+    };
+    reserve_general(gen);
     auto run_and_print = [&]() {
         drain(devs.size() - 1);
         auto job = std::make_shared<Job>();
@@ -1453,6 +1492,8 @@ int call_main(const Options &o)
         recs.clear();
         iso = Batch();
         gen = Batch();
+        gen.dense_gt = dense_gt;
+        reserve_general(gen);
         recs.reserve(batch_records + 64);
         in_flight.push_back(std::async(std::launch::async, [&process, job]() { return process(*job); }));
     };
@@ -1503,8 +1544,13 @@ int call_main(const Options &o)
             // main.cpp:556-557: extract_kmers + set_coverages happen on the device for the whole batch of blocks
             gen.blk_base.push_back(base_value);
             gen.blk_len.push_back((uint32_t)reference.size());
+            // a record tier 1 is sure to take (the device's own test, block_pipeline.h: classify_lone) can never be handed back:
+            // with its genotype words made here, nothing of it needs keeping
+            const bool sure_lone = gen.dense_gt && o.k <= MG_MAX_PACKED_K && vb.is_lone_short() && base_found && vb.vars[0].ref_pos >= (int)o.k / 2 &&
+                                   (long)vb.vars[0].ref_pos + vb.vars[0].ref_size + (long)(o.k + 1) / 2 <= (long)reference.size();
             for (Variant &v : vb.vars) {
                 const uint32_t A = (uint32_t)v.n_alleles();
+                if (A > 127) gen.wide_alleles = true;
                 recs.push_back({prefix_of(v), A, false, gen.n(), gen.var_allele_off.back(), gen.var_gt_off.back()});
                 gen.ipos.push_back(v.ref_pos);
                 gen.ref_size.push_back((uint32_t)v.ref_size);
@@ -1520,11 +1566,19 @@ int call_main(const Options &o)
                 gen.var_allele_off.push_back(gen.var_allele_off.back() + A);
                 gen.var_gt_off.push_back(gen.var_gt_off.back() + n_gt(A));
                 gen.genotype_cells += v.n_genotypes();
+                if (gen.dense_gt) { // one row of n_samples words per record (a record whose genotypes were not read -- it carries nothing -- keeps a row of zeros)
+                    const size_t have = std::min(v.genotypes.size(), n_samples_kept);
+                    for (size_t s_ = 0; s_ < have; ++s_) gen.gt_dense.push_back(genotype_word(v, s_, o.haploid));
+                    gen.gt_dense.resize(gen.gt_dense.size() + (n_samples_kept - have), 0);
+                }
+                if (sure_lone) gen.var_slot.push_back(-1);
+                else {
+                    gen.var_slot.push_back((int32_t)gen.vars.size());
+                    gen.vars.push_back(std::move(v)); // (the caller clears the block: its vector is used again)
+                }
             }
             gen.blk_var_off.push_back((uint32_t)gen.n());
             gen.block_ref.push_back(&reference);
-            gen.blocks.push_back(std::move(vb));
-            vb = Block((int)o.k);
         }
         if (gen.genotype_cells >= (200u << 20)) run_and_print(); // bound the panel genotypes held in memory
         if (recs.size() >= batch_records) run_and_print();
