@@ -1118,11 +1118,16 @@ __device__ __forceinline__ void fc_eval(const BlockBatch &B, const unsigned char
 }
 
 constexpr int FC_SET = 512; // slots of a wave's set of distinct picks in fw_chain_kernel
+// A set entry is 32 bits: the pick's code (at most FC_CODE_BITS wide: six members of up to sixteen alleles; a wider chain takes the
+// list), the sliding mark, the chain's number in the wave -- half the LDS of 64-bit entries, one more workgroup per CU
+constexpr int FC_CODE_BITS = 24;
+constexpr u32 FC_SLIDE_IN = 1u << FC_CODE_BITS;
+constexpr int FC_GRP_SHIFT = FC_CODE_BITS + 1;
 template <int MODE>
-__global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, u8 *overflow, unsigned long long *cursor,
+__global__ void __launch_bounds__(TPB, 6) fw_chain_kernel(BlockBatch B, FlatWork W, int G, BFView bf, MapView map, u32 *cov_out, u8 *overflow, unsigned long long *cursor,
                                                        u32 row0, unsigned long long *n_evaluated)
 {
-    __shared__ unsigned long long sh_set[FW_WAVES][FC_SET]; // key + 1, 0 = free
+    __shared__ u32 sh_set[FW_WAVES][FC_SET];                // key + 1, 0 = free
     __shared__ unsigned short sh_list[FW_WAVES][FC_SET];    // slots taken, in the order they were taken
     __shared__ u32 sh_n[FW_WAVES];
     __shared__ u32 sh_cnt[FW_WAVES][32];                    // distinct picks per chain of the wave
@@ -1132,7 +1137,7 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
     const int grp = lane / G, sub = lane % G, n_grp = 64 / G;
     const int budget = FW_POOL / n_grp;
     const int k = B.k;
-    unsigned long long *set = sh_set[wave];
+    u32 *set = sh_set[wave];
     unsigned short *list = sh_list[wave];
     unsigned char *area = sh_pool[wave] + grp * budget;
     FcHead *hd = (FcHead *)area;
@@ -1146,11 +1151,11 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
     const u64 n_waves = (u64)gridDim.x * FW_WAVES;
     volatile u32 *my_cnt = &sh_cnt[wave][grp];
     u32 evaluated = 0, ref_rows = 0;
-    auto insert = [&](unsigned long long key) {
-        u32 at = (u32)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (FC_SET - 1);
+    auto insert = [&](u32 key) {
+        u32 at = ((key * 0x9E3779B9u) >> 20) & (FC_SET - 1);
         for (int tries = 0; tries < FC_SET; ++tries) {
-            const unsigned long long seen = atomicCAS(&set[at], 0ULL, key + 1);
-            if (seen == 0ULL) {
+            const u32 seen = atomicCAS(&set[at], 0u, key + 1);
+            if (seen == 0u) {
                 atomicAdd(&sh_cnt[wave][grp], 1u);
                 const u32 q = atomicAdd(&sh_n[wave], 1u);
                 if (q < FC_SET) list[q] = (unsigned short)at;
@@ -1197,16 +1202,17 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
         }
         wave_sync();
         if (valid && room && sub == 0) {
-            u32 acc = 0;
+            u32 acc = 0, bit_at = 0;
             bool wide = false; // (a member of 128 alleles or more: its count does not fit the entry, its genotypes not the pick's code)
             for (int j = 0; j < m; ++j) {
                 mem[j].off_at = (unsigned short)acc;
                 acc += (u32)mem[j].A + 1;
                 wide = wide || mem[j].bits > 7;
+                bit_at += mem[j].bits;
             }
             hd->first_pos = mem[0].pos;
             hd->last_end = mem[m - 1].pos + (i32)mem[m - 1].rs;
-            if (wide || (int)(sizeof(FcHead) + sizeof(FcMember) * m + 4 * acc) > budget) sh_state[wave][grp] = 1;
+            if (wide || bit_at > (u32)FC_CODE_BITS || (int)(sizeof(FcHead) + sizeof(FcMember) * m + 4 * acc) > budget) sh_state[wave][grp] = 1;
         }
         wave_sync();
         if (valid && sh_state[wave][grp] == 0) {
@@ -1258,16 +1264,16 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
                     bounds |= 1ULL << sh;
                 }
                 if (fail) break;
-                const unsigned long long tag = (unsigned long long)grp << FW_GRP_SHIFT;
+                const u32 tag = (u32)grp << FC_GRP_SHIFT;
                 if (m == 1) { // an allele of k bases or more on its own is a SLIDING signature (var_block.hpp:130-144): its own kind of item
                     const u32 l1 = off[(u32)c1 + 1] - off[(u32)c1], l2 = off[(u32)c2 + 1] - off[(u32)c2];
-                    if ((int)l1 >= k) c1 |= FW_SLIDE_IN;
-                    if ((int)l2 >= k) c2 |= FW_SLIDE_IN;
+                    if ((int)l1 >= k) c1 |= FC_SLIDE_IN;
+                    if ((int)l2 >= k) c2 |= FC_SLIDE_IN;
                 }
-                if (B.haploid) insert(c1 | tag);
+                if (B.haploid) insert((u32)c1 | tag);
                 else if (phased || m == 1) { // (the mixes of a chain of one are its two alleles)
-                    insert(c1 | tag);
-                    insert(c2 | tag);
+                    insert((u32)c1 | tag);
+                    insert((u32)c2 | tag);
                 } else if (m > FW_MAXU) fail = true;
                 else { // every mix of the two haplotypes (combine_haplotypes): Gray-code walk, one member's field flipped per step
                     // (only the members at which the two haplotypes differ: 2^h codes for h of them, not 2^m steps of which most change nothing)
@@ -1284,7 +1290,7 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
                     }
                     const int n_het = __popc(het);
                     unsigned long long code = c1;
-                    insert(code | tag);
+                    insert((u32)code | tag);
                     for (u32 i = 1; i < (1u << n_het); ++i) {
                         u32 hm = het; // the member this step flips: the (number of trailing zeros of i)-th of the differing ones
                         for (int q = __ffs((int)i) - 1; q > 0; --q) hm &= hm - 1;
@@ -1295,7 +1301,7 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
                         t &= t - 1;
                         const int hi = __ffsll((unsigned long long)t) - 1;
                         code ^= diff & (((1ULL << (hi - lo)) - 1) << lo);
-                        insert(code | tag);
+                        insert((u32)code | tag);
                         if (*my_cnt > share) break;
                     }
                 }
@@ -1319,24 +1325,24 @@ __global__ void __launch_bounds__(TPB, 5) fw_chain_kernel(BlockBatch B, FlatWork
             }
         }
         const u64 to_wg = __ballot(fail); // lanes whose chain's record goes to the workgroup kernel
+        if (valid && sub == 0 && (all_fail || ((to_wg >> (grp * G)) & (G == 64 ? ~0ULL : ((1ULL << G) - 1))))) W.fb_flag[g] = 1;
         const u32 n_used = n < FC_SET ? n : FC_SET;
         if (!all_fail)
             for (u32 i0 = 0; i0 < n_used; i0 += 64) { // the set's entries, 64 at a time, a lane each
                 const u32 i = i0 + lane;
-                const unsigned long long key = i < n_used ? set[list[i]] - 1 : 0ULL;
-                const int kg = (int)(key >> FW_GRP_SHIFT) & 63;
+                const u32 key = i < n_used ? set[list[i]] - 1 : 0u;
+                const int kg = (int)(key >> FC_GRP_SHIFT) & 31;
                 const bool live = i < n_used && !((skipped >> kg) & 1);
-                const unsigned long long code = key & ((1ULL << FW_CODE_BITS) - 1);
+                const unsigned long long code = key & (FC_SLIDE_IN - 1);
                 const unsigned char *karea = sh_pool[wave] + kg * budget;
                 const u32 kci = (u32)__shfl((int)(u32)ci, kg * G, 64); // the descriptor of the key's chain
-                if (live && (key & FW_SLIDE_IN)) {
+                if (live && (key & FC_SLIDE_IN)) {
                     const unsigned long long at = atomicAdd(&W.counters[2], 1ULL);
                     if (at < W.slide_cap) W.slides[at] = PickItem{kci, 0u, code | FW_SLIDE};
                     else W.fb_flag[((const FcHead *)karea)->g] = 1;
                 } else if (live)
                     fc_eval<MODE>(B, karea, code, bf, map, cov_out, overflow, cursor, row0, evaluated, ref_rows);
             }
-        if (valid && sub == 0 && (all_fail || ((to_wg >> (grp * G)) & (G == 64 ? ~0ULL : ((1ULL << G) - 1))))) W.fb_flag[g] = 1;
         for (u32 i = lane; i < n_used; i += 64) set[list[i]] = 0;
         if (lane < 32) sh_cnt[wave][lane] = 0;
         if (n > FC_SET) // (the list lost entries: clear the whole set)

@@ -2659,7 +2659,7 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         // the counting pass of `index` leaves a margin in the item buffer: the insert pass packs its chunks in another order
         const u32 cap_eff = MODE == 1 ? W.item_cap / 8 * 7 : W.item_cap;
         if (c->use_chain_kernel && c->k >= 17 && c->k <= MG_MAX_PACKED_K) { // picks and evaluation in one kernel; what it lists, the pair below takes
-            hipLaunchKernelGGL(fw_chain_kernel<MODE>, dim3(R.cus * 5), dim3(TPB), 0, c->stream, R.B, W, G, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
+            hipLaunchKernelGGL(fw_chain_kernel<MODE>, dim3(R.cus * 6), dim3(TPB), 0, c->stream, R.B, W, G, view(c, MG_BF_ALT), view(c), d_cov, d_overflow, d_cursor, row0,
                                d_evaluated);
             hipLaunchKernelGGL(fw_picks_kernel<true>, dim3(R.cus * 4), dim3(TPB), 0, c->stream, R.B, W, 64, cap_eff);
         } else {
