@@ -106,6 +106,7 @@ struct mg_ctx {
     int blocks_round_log2 = 24;                // see blocks_setup
     int use_hit_entries = 1;                   // scan: the probe kernel hands the hit kernel each row's filter entry (counter index, record) with the row
     int use_snp_chains = 1;                    // record loop: chains of SNPs assembled as the reference window with the members' bases put in
+    u64 last_rounds = 0;                       // rounds of tier 2 in the most recent record loop (blocks_listed_chains)
     int use_chain_kernel = 1;                  // record loop: the picks of a chain evaluated by the wave that holds them (fw_chain_kernel) instead of picks -> items -> eval
     int use_snp_kernel = 1;                    // record loop: chains of SNPs on panels of up to 8 diploid / 16 haploid samples in one kernel (fw_snp_kernel) instead of picks + eval
     int use_chain_order = 1;                   // record loop: what fw_snp_kernel left of a round's chains, listed in order of their number of members, before the
@@ -798,6 +799,16 @@ MG_EXPORT int mg_get_option(mg_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "use_snp_chains")) *value = c->use_snp_chains;
     else if (!strcmp(name, "use_hit_entries")) *value = c->use_hit_entries;
     else if (!strcmp(name, "use_chain_order")) *value = c->use_chain_order;
+    else if (!strcmp(name, "blocks_listed_chains")) { // diagnostic: chains fw_chain_kernel handed to the list path in the most recent record loop (waits for it)
+        unsigned long long total = 0;
+        if (c->last_rounds && c->s_blk[5].p) {
+            std::vector<unsigned long long> h((size_t)FW_ROUND_COUNTERS * c->last_rounds);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(h.data(), c->s_blk[5].p, 8 * h.size(), hipMemcpyDeviceToHost));
+            for (u64 r = 0; r < c->last_rounds; ++r) total += h[(size_t)FW_ROUND_COUNTERS * r + 3];
+        }
+        *value = (int64_t)total;
+    }
     else if (!strcmp(name, "use_chain_kernel")) *value = c->use_chain_kernel;
     else if (!strcmp(name, "use_snp_kernel")) *value = c->use_snp_kernel;
     else if (!strcmp(name, "blocks_round_log2")) *value = c->blocks_round_log2;
@@ -2626,6 +2637,7 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
         return MG_OK;
     }
     HIP_TRY(c, hipMemsetAsync(R.round_counters, 0, 8 * FW_ROUND_COUNTERS * R.n_rounds, c->stream));
+    c->last_rounds = R.n_rounds;
     for (u64 r = 0; r < R.n_rounds; ++r) {
         FlatWork W{};
         W.gen_list = R.gen_list;
@@ -2650,7 +2662,7 @@ template <int MODE> int blocks_tier2(BlocksRun &R, u32 *d_cov, u8 *d_overflow, u
             hipLaunchKernelGGL(fw_snp_kernel<MODE>, dim3(R.cus * 8), dim3(TPB), 0, c->stream, R.B, W, GH, view(c, MG_BF_ALT), view(c), d_cov, d_cursor, row0, d_evaluated);
         }
         if (W.order) { // what is left, by length (grids sized for the round's worst case: workgroups beyond the chains written find nothing)
-            const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 16);
+            const unsigned og = (unsigned)std::min<u64>(nblocks((u64)W.comb_cap), (u64)R.cus * 4);
             hipLaunchKernelGGL(fw_order_kernel<0>, dim3(og), dim3(TPB), 0, c->stream, W);
             hipLaunchKernelGGL(fw_order_kernel<1>, dim3(og), dim3(TPB), 0, c->stream, W);
         }

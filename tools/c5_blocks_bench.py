@@ -59,8 +59,9 @@ def main():
             if key in res:
                 crc = zlib.crc32(np.ascontiguousarray(res[key]).tobytes(), crc)
         first = crc if first is None else first
-        print("%-44s tier1 %.3f tier2 %.3f tier3 %.3f loop %.3f ms  general %d kmers %d tier3 %d  crc %08x%s"
-              % (cfg, np.mean(t1), np.mean(t2), np.mean(t3), np.mean(wall), st[3], st[5], st[6], crc, "" if crc == first else "  DIFFERS"), flush=True)
+        print("%-44s tier1 %.3f tier2 %.3f tier3 %.3f loop %.3f ms  general %d kmers %d tier3 %d listed chains %d  crc %08x%s"
+              % (cfg, np.mean(t1), np.mean(t2), np.mean(t3), np.mean(wall), st[3], st[5], st[6], ctx.get_option("blocks_listed_chains"), crc,
+                 "" if crc == first else "  DIFFERS"), flush=True)
         for name, value in old.items():
             ctx.set_option(name, int(value))
     job.close()
