@@ -314,6 +314,25 @@ const char MAGIC[8] = {'M', 'G', 'H', 'I', 'P', 'X', '2', '\n'};
 // Version 2 files are still read.
 namespace hipz {
 const char MAGIC3[8] = {'M', 'G', 'H', 'I', 'P', 'X', '3', '\n'};
+// version 4 = version 3 + two header words tying the index to the panel it was built from: the VCF's size and its modification time
+// (ns).  `call` takes a compact index whose tie does not match the VCF it is given for stale (a file copied or restored beside a
+// reference container rebuilt for another panel carries a fresh mtime and the same -k/-r/-b) and reads the reference's container.
+const char MAGIC4[8] = {'M', 'G', 'H', 'I', 'P', 'X', '4', '\n'};
+struct PanelTie {
+    uint64_t size = 0, mtime_ns = 0; // 0, 0: unknown (an index of version 3, or one converted from the reference's container)
+    bool known() const { return size || mtime_ns; }
+    bool operator==(const PanelTie &o) const { return size == o.size && mtime_ns == o.mtime_ns; }
+};
+inline PanelTie panel_tie_of(const std::string &vcf_path)
+{
+    struct stat st;
+    PanelTie t;
+    if (stat(vcf_path.c_str(), &st) == 0) {
+        t.size = (uint64_t)st.st_size;
+        t.mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ULL + (uint64_t)st.st_mtim.tv_nsec;
+    }
+    return t;
+}
 constexpr size_t CHUNK = 8u << 20;
 template <class F> void parallel_for(size_t n, F f)
 {
@@ -386,7 +405,7 @@ inline void get_section(FILE *f, void *data, size_t bytes, uint64_t file_bytes, 
 }
 } // namespace hipz
 
-inline void save_index_hipz(const std::string &path, const IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits)
+inline void save_index_hipz(const std::string &path, const IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits, hipz::PanelTie tie = hipz::PanelTie())
 {
     using namespace hipz;
     zstd_check();
@@ -398,7 +417,8 @@ inline void save_index_hipz(const std::string &path, const IndexPayload &p, uint
         for (uint64_t i = 0; i < nkeys; ++i) key_bytes = std::max<uint64_t>(key_bytes, strnlen(&p.rows[i * p.stride], p.stride) + 1);
         key_bytes = std::min<uint64_t>(key_bytes, p.stride);
         const uint64_t hdr[9] = {k, ref_k, bf_bits, p.filt[0].mode, p.filt[0].pos.size(), p.filt[1].mode, p.filt[1].pos.size(), nkeys, key_bytes};
-        if (fwrite(MAGIC3, 1, 8, f) != 8 || fwrite(hdr, 8, 9, f) != 9) throw std::runtime_error("index file: write failed");
+        const uint64_t tie_words[2] = {tie.size, tie.mtime_ns};
+        if (fwrite(MAGIC4, 1, 8, f) != 8 || fwrite(hdr, 8, 9, f) != 9 || fwrite(tie_words, 8, 2, f) != 2) throw std::runtime_error("index file: write failed");
         for (int i = 0; i < 2; ++i) {
             put_section(f, p.filt[i].pos.data(), p.filt[i].pos.size() * 8);
             put_section(f, p.filt[i].cnt.data(), p.filt[i].cnt.size() * 2);
@@ -427,9 +447,11 @@ inline void load_index_hipz3(const std::string &path, IndexPayload &p, uint64_t 
     const uint64_t file_bytes = fstat(fileno(f), &st) == 0 && st.st_size > 0 ? (uint64_t)st.st_size : (uint64_t)1 << 50;
     try {
         char magic[8];
-        uint64_t hdr[9];
+        uint64_t hdr[9], tie_words[2];
         if (fread(magic, 1, 8, f) != 8 || fread(hdr, 8, 9, f) != 9) throw std::runtime_error("index file: truncated");
-        if (memcmp(magic, MAGIC3, 8) != 0 || hdr[0] != k || hdr[1] != ref_k || hdr[2] != bf_bits)
+        const bool v4 = memcmp(magic, MAGIC4, 8) == 0;
+        if (v4 && fread(tie_words, 8, 2, f) != 2) throw std::runtime_error("index file: truncated");
+        if ((!v4 && memcmp(magic, MAGIC3, 8) != 0) || hdr[0] != k || hdr[1] != ref_k || hdr[2] != bf_bits)
             throw std::runtime_error("index " + path + " was built with other -k/-r/-b");
         // a corrupt length must not turn into a huge allocation: a filter holds fewer than 2^32 set bits (mg_bf_finalize), and no
         // field can promise more bytes than zstd can have packed into the file
@@ -465,13 +487,30 @@ inline void load_index_hipz3(const std::string &path, IndexPayload &p, uint64_t 
     fclose(f);
 }
 
+// the panel tie in a compact index's header (unknown for older versions or an unreadable file)
+inline hipz::PanelTie index_hipz_tie(const std::string &path)
+{
+    using namespace hipz;
+    PanelTie t;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return t;
+    char magic[8];
+    uint64_t hdr[11];
+    if (fread(magic, 1, 8, f) == 8 && memcmp(magic, MAGIC4, 8) == 0 && fread(hdr, 8, 11, f) == 11) {
+        t.size = hdr[9];
+        t.mtime_ns = hdr[10];
+    }
+    fclose(f);
+    return t;
+}
+
 inline void load_index_hipz(const std::string &path, IndexPayload &p, uint64_t k, uint64_t ref_k, uint64_t bf_bits, size_t stride)
 {
     using namespace hipz;
     {
         char magic[8] = {0};
         FILE *probe = fopen(path.c_str(), "rb");
-        const bool v3 = probe && fread(magic, 1, 8, probe) == 8 && memcmp(magic, MAGIC3, 8) == 0;
+        const bool v3 = probe && fread(magic, 1, 8, probe) == 8 && (memcmp(magic, MAGIC3, 8) == 0 || memcmp(magic, MAGIC4, 8) == 0);
         if (probe) fclose(probe);
         if (v3) return load_index_hipz3(path, p, k, ref_k, bf_bits, stride);
     }

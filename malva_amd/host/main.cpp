@@ -600,7 +600,7 @@ void save_index(Device &dev, const Options &o)
         const std::string tmp_path = final_path + ".tmp." + std::to_string((long)getpid());
         try {
             Timed t(hipz ? "index file: .hipz" : "index file: .zst");
-            if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size);
+            if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size, hipz::panel_tie_of(o.vcf_path));
             else save_index_zst(tmp_path, p, o.bf_size);
         } catch (...) {
             unlink(tmp_path.c_str());
@@ -620,7 +620,7 @@ void save_index(Device &dev, const Options &o)
     else {
         try {
             Timed t("index file: .hipz");
-            save_index_hipz(hipz_tmp, p, o.k, o.ref_k, o.bf_size);
+            save_index_hipz(hipz_tmp, p, o.k, o.ref_k, o.bf_size, hipz::panel_tie_of(o.vcf_path));
         } catch (...) {
             unlink(hipz_tmp.c_str());
             hipz_err = std::current_exception();
@@ -672,8 +672,16 @@ void read_index(const Options &o, IndexPayload &p)
     auto newer = [](const struct stat &a, const struct stat &b) { // a strictly newer than b
         return a.st_mtim.tv_sec != b.st_mtim.tv_sec ? a.st_mtim.tv_sec > b.st_mtim.tv_sec : a.st_mtim.tv_nsec > b.st_mtim.tv_nsec;
     };
-    // the sparse container unless the reference's one is newer (an index brought over from the reference's binary)
-    if (has_hipz && !(has_zst && newer(sz, sh))) load_index_hipz(hipz, p, o.k, o.ref_k, o.bf_size, STRIDE);
+    // the sparse container unless the reference's one is newer (an index brought over from the reference's binary) -- or unless the
+    // sparse one says it was built from another panel than the VCF given here (its header holds that VCF's size and modification
+    // time: file dates alone do not survive a copy or a restore) while the reference's container is there to be read instead
+    bool stale = false;
+    if (has_hipz && has_zst) {
+        const hipz::PanelTie tie = index_hipz_tie(hipz);
+        stale = tie.known() && !(tie == hipz::panel_tie_of(o.vcf_path));
+        if (stale) std::cerr << "[malva-geno] " << hipz << " was built from another version of " << o.vcf_path << ": reading " << zst << std::endl;
+    }
+    if (has_hipz && !stale && !(has_zst && newer(sz, sh))) load_index_hipz(hipz, p, o.k, o.ref_k, o.bf_size, STRIDE);
     else if (has_zst) load_index_zst(zst, p, o.bf_size, STRIDE);
     else throw std::runtime_error("cannot open index " + index_path(o, ".zst") + " (run `malva-geno index` with the same -k -r -b first)");
 }

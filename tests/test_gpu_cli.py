@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 import subprocess
+import time
 
 import pytest
 
@@ -258,6 +259,12 @@ def test_index_file_is_the_references_container_and_interchanges_with_the_oracle
     os.utime(hipz, (1, 1))
     index_file.write_index(zst, idx.context_bf, idx.bf, idx.ref_bf)
     assert run_cli(["call"] + args) == from_own
+    # ... and the same stale sparse file with a FRESH date (copied or restored without its times): its header names the size and
+    # modification time of the VCF it was built from, which is not this one -- the reference's container is read
+    now = time.time() + 5
+    os.utime(hipz, (now, now))
+    r = subprocess.run([BIN, "call"] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout == from_own and "another version of" in r.stderr
     assert sum(1 for l in from_own.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 20
 
 

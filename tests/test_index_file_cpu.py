@@ -74,8 +74,9 @@ def test_wrong_size_and_truncation_are_refused(tmp_path):
 
 
 def test_compact_container_versions_and_corruption(tmp_path):
-    """the compact container, version 3 (sections of independently compressed chunks): a flipped byte or a cut file is an error,
-    never a crash or a silent index; a version 2 file (one gzip stream, what earlier builds wrote) is still read"""
+    """the compact container, versions 3 and 4 (sections of independently compressed chunks; 4 adds the tie to the panel): a flipped
+    byte or a cut file is an error, never a crash or a silent index; a version 2 file (one gzip stream, what earlier builds wrote) is
+    still read"""
     import gzip
     import struct
     bits = 1 << 22
@@ -87,7 +88,11 @@ def test_compact_container_versions_and_corruption(tmp_path):
     run = lambda fmt: subprocess.run([BIN, "index-convert", "-k", "35", "-r", "43", "x.fa", vcf, fmt], env=env, capture_output=True, text=True, timeout=600)
     assert run("hipz").returncode == 0
     good = open(hipz, "rb").read()
-    assert good[:8] == b"MGHIPX3\n"
+    assert good[:8] == b"MGHIPX4\n"                                   # version 4 = version 3 + the panel's size and modification time behind the header
+    os.remove(zst)
+    open(hipz, "wb").write(b"MGHIPX3\n" + good[8:80] + good[96:])      # the same index as version 3 (no tie): still read
+    assert run("zst").returncode == 0
+    assert index_file.read_index(zst)[1] == dict(kmap.items())
     os.remove(zst)
     for at in (len(good) // 3, len(good) - 9, 40):                    # inside a chunk, near the end, inside the header
         bad = bytearray(good)
