@@ -591,17 +591,16 @@ void save_index(Device &dev, const Options &o)
     const char *fmt = getenv("MALVA_GENO_INDEX_FORMAT");
     const std::string want = fmt ? fmt : "both";
     if (want != "both" && want != "zst" && want != "hipz") throw std::runtime_error("MALVA_GENO_INDEX_FORMAT: zst, hipz or both");
-    auto write_one = [&](bool hipz) {
-        const std::string final_path = index_path(o, hipz ? ".hipz" : ".zst");
-        if (want != "both" && (want == "hipz") != hipz) {
+    auto write_zst = [&]() {
+        const std::string final_path = index_path(o, ".zst");
+        if (want == "hipz") {
             unlink(final_path.c_str()); // no stale index of the other kind beside the new one
             return;
         }
         const std::string tmp_path = final_path + ".tmp." + std::to_string((long)getpid());
         try {
-            Timed t(hipz ? "index file: .hipz" : "index file: .zst");
-            if (hipz) save_index_hipz(tmp_path, p, o.k, o.ref_k, o.bf_size, hipz::panel_tie_of(o.vcf_path));
-            else save_index_zst(tmp_path, p, o.bf_size);
+            Timed t("index file: .zst");
+            save_index_zst(tmp_path, p, o.bf_size);
         } catch (...) {
             unlink(tmp_path.c_str());
             throw;
@@ -613,7 +612,7 @@ void save_index(Device &dev, const Options &o)
     };
     // side by side (the .zst takes seconds, single-threaded inside libzstd); the .hipz is renamed into place after the .zst,
     // so it is the newer file of the two
-    auto zst_job = std::async(std::launch::async, [&]() { write_one(false); });
+    auto zst_job = std::async(std::launch::async, write_zst);
     std::exception_ptr hipz_err;
     const std::string hipz_final = index_path(o, ".hipz"), hipz_tmp = hipz_final + ".tmp." + std::to_string((long)getpid());
     if (want == "zst") unlink(hipz_final.c_str());
