@@ -91,6 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--strong-c4-kmers", type=float, default=3e9)
     ap.add_argument("--strong-c4-variants", type=float, default=8e7)
     ap.add_argument("--no-summary", action="store_true", help="A/B: disable the cache-resident gate")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1, c3: launch every step kernel by kernel instead of replaying one captured step")
     ap.add_argument("--grow-panel", action="store_true", help="c3: panel of N x --variants SNPs instead of a fixed one")
     ap.add_argument("--pack16-min-mb", type=float, default=32.0,
                     help="torch exchange: counter vectors of at least this size try the 16-bit packed all-reduce")
@@ -409,19 +410,71 @@ class Job:
         if self.world > 1:
             self.dist.barrier()
 
+    def capture_step(self):
+        """one step captured into a HIP graph (every launch of a step goes to the context's stream; after the warm-up steps the library
+        allocates nothing): the C3 step is three dozen launches of which two dozen are the record loop's, a few microseconds apart.
+        Returns the replay callable, or None where capture is not on (N > 1: the exchange's second stream and RCCL stay outside graphs;
+        the whole-genome and C5 steps are milliseconds of kernels, not of launches) or fails."""
+        torch = self.torch
+        self.launch = "stream"
+        if self.world > 1 or self.workload != "c3" or self.args.no_graph:
+            return None
+        if self.ctx.get_option("record_counters_live"):     # (a replay repeats its kernels' arguments, the counter copies' epoch among them: only where the vectors are the counters)
+            return None
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(self.stream)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                self.ctx.set_stream(side.cuda_stream)
+                self.step()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    self.step()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001 -- reported; the steps are then launched one by one as before
+            log(self.rank, "step not captured into a graph (%s): plain launches" % (repr(e)[:200]))
+            self.ctx.set_stream(self.stream.cuda_stream)
+            torch.cuda.synchronize()
+            return None
+        self.ctx.set_stream(self.stream.cuda_stream)     # (what follows the timed region launches on the usual stream again)
+        self._graph, self._graph_stream = graph, side    # kept alive as long as the job
+        self.launch = "hipGraph replay of one captured step"
+        return graph.replay
+
     def timed(self, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks"""
         torch = self.torch
         for _ in range(warmup):
             self.step()
+        run = self.capture_step() or self.step
         torch.cuda.synchronize()
         self.barrier()
         t_start = time.perf_counter()
         for _ in range(steps):
-            self.step()
+            run()
         torch.cuda.synchronize()
         self.barrier()
         elapsed = time.perf_counter() - t_start
+        self.stream_ms = None
+        if run != self.step:        # the same K steps launched one by one: for the record, and as the check that a replayed step leaves what a launched one does
+            def state():
+                r = self.rp.results()
+                return [r[k].copy() for k in ("cov", "g1", "g2", "gq", "overflow")]
+            after_replay = state()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            stream_elapsed = time.perf_counter() - t0
+            self.stream_ms = 1e3 * stream_elapsed / steps
+            self.replay_equals_launched = all(np.array_equal(a, b) for a, b in zip(after_replay, state()))
+            if not self.replay_equals_launched:      # never seen; the replayed timing is then not a measurement of this step
+                log(self.rank, "a replayed step left other results than a launched one: the plain launches are the timing")
+                self.launch = "stream (graph replay discarded: results differed)"
+                elapsed = stream_elapsed
         if self.world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.args.rehearse_on_one_gpu else self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -778,6 +831,9 @@ def record(job, elapsed, steps, warmup, kt, sustained):
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
+        "launch": getattr(job, "launch", "stream"),                      # how the timed steps were issued: kernel by kernel, or one captured step replayed
+        "ms_per_step_stream": getattr(job, "stream_ms", None),           # (graph replay only) the same steps launched kernel by kernel
+        "replay_equals_launched": getattr(job, "replay_equals_launched", None),   # ... and whether both left the same coverages, GT, GQ
         "higher_is_better": True,
         "scaling": "strong" if job.strong else "weak",
         "vs_baseline": None,
