@@ -863,12 +863,13 @@ def record(job, elapsed, steps, warmup, kt, sustained):
         n_sig = kt["lone_signature_kmers"] + kt["general_signature_kmers"]
         alg = blocks_bytes(job.n_vars, n_sig, job.n_genotypes)
         blocks_traffic, blocks_tsrc = None, None      # counted HBM bytes of one record loop (tools/traffic_blocks.sh), when this IS that workload
-        tb = os.path.join(ROOT, "profiles", "traffic_blocks_%s.json" % job.workload)
-        if os.path.exists(tb) and world == 1:
-            t = json.load(open(tb))
-            if t.get("panel_variants") == job.n_vars_total and t.get("units_per_launch") == job.n_vars:
-                blocks_traffic, blocks_tsrc = t["hbm_bytes_per_launch"], "profiles/traffic_blocks_%s.json (rocprofv3 PMC%s)" % (
-                    job.workload, "; mean of the diploid and the haploid job's loops" if t.get("haploid_included") else "")
+        for tname in ("traffic_blocks_%s.json" % job.workload, "traffic_blocks_%s_leg.json" % job.workload):   # (the workload at its full size; at the size of the default line's leg)
+            tb = os.path.join(ROOT, "profiles", tname)
+            if blocks_traffic is None and os.path.exists(tb) and world == 1:
+                t = json.load(open(tb))
+                if t.get("panel_variants") == job.n_vars_total and t.get("units_per_launch") == job.n_vars:
+                    blocks_traffic, blocks_tsrc = t["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 PMC%s)" % (
+                        tname, "; mean of the diploid and the haploid job's loops" if t.get("haploid_included") else "")
         loop_ms = kt["record_loop"]
         out["roofline_blocks"] = {"kernel": "cut_flags + flag_scatter + panel_lone + fw_walk + fw_snp + fw_order + fw_chain (+ fw_picks<true> / fw_eval for what it lists) + fw_slide + cover_blocks<0> + genotype (the record loop, main.cpp:522-579)",
                                   "bound": "hbm", "achieved": alg / (loop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
