@@ -262,3 +262,27 @@ def test_c5_indel_mnp_panel_r63_b8(tmp_path, haploid):
     got = run_cli(["call"] + args, env=env)
     assert got == want and got.count("\n") > 1500
     assert sum(1 for l in got.split("\n") if l and not l.startswith("#") and not l.endswith(":0")) > 200
+
+
+def test_bench_one_gpu_line_replays_a_captured_step():
+    """`python bench.py` on one GPU at a reduced C3: ONE JSON line; its timed steps are replays of one step captured into a HIP graph
+    (after the warm-up steps a step allocates nothing and launches on one stream), the same steps launched kernel by kernel leave the
+    same coverages, GT and GQ, the CPU oracle's sample agrees, and --no-graph gives the plain launches"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = [sys.executable, os.path.join(root, "bench.py"), "--kmers", "4e6", "--variants", "5e4", "--steps", "3", "--warmup", "2", "--no-c4-leg", "--no-c5-leg",
+              "--sustained-s", "0", "--cpu-sample", "2e5", "--cpu-variants", "2e4"]
+    for extra, launch in (([], "hipGraph"), (["--no-graph"], "stream")):
+        r = subprocess.run(common + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.split("\n") if l.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["launch"].startswith(launch), d["launch"]
+        assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["overflow_records"] == 0
+        assert all(v is True for k, v in d["parity_sample"].items() if k.endswith("_equal")), d["parity_sample"]
+        if launch == "hipGraph":
+            assert d["replay_equals_launched"] is True and d["ms_per_step_stream"] > 0
