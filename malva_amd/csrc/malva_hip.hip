@@ -143,7 +143,9 @@ struct mg_ctx {
     int use_pregate = 1;
     bool pre_skip = false; // the coarse gate is saturated at this index size (decided at finalize): scans go straight to the fine gate
     int pregate_log2 = 25; // coarse gate size: 4 MiB, what stays resident in an XCD's L2 next to the table stream
-    int use_partition = 1; // bin the coarse gate's survivors by fine-gate slice (large indexes)
+    int use_partition = 0; // bin the coarse gate's survivors by fine-gate slice (SoA tables, fine gates of 4..64 MiB).  Off: since the ticket and sub-slice forms took the
+                           // gates of 32 MiB and more, what is left to this form is where the plain filter kernel beats it (C5, 16 MiB gate: 0.84 against 1.03 ms per
+                           // 1e8 rows; C3-shaped indexes of 4e6 and 8e6 entries: 0.82 / 1.09 against 0.96 / 1.23)
     int probe_grid = 2048, hits_grid = 1024; // workgroups of the two list kernels (swept)
     int use_tickets = 1;      // gates of 2^ticket_min_log2 bits and more: 8-byte tickets filed by 2 MiB gate slice, the slices then walked out of L2
                               // (scan_ticket_sort_kernel + scan_ticket_gate_kernel) instead of one random HBM sector per table row

@@ -176,6 +176,8 @@ def test_c4_one_gpu_share_3p75e8_rows_b16(n_vars, expect):
             ctx.set_option("use_sub", 0)
         if expect != "tickets":
             ctx.set_option("use_tickets", 0)
+        if expect == "two-level":
+            ctx.set_option("use_partition", 1)
         build_device_index(ctx, panel, K)
         counters, n_bf, n_map = counters_tensor(ctx)
         assert n_map == n_vars

@@ -58,14 +58,15 @@ def test_scan_without_summaries_is_identical():
 @pytest.mark.parametrize("k,ref_k,bits,n_bins,bin_cap", [(35, 43, 1 << 33, 32, 0), (35, 43, 1 << 17, 4, 0), (31, 41, (1 << 18) + 77, 9, 0),
                                                          (35, 43, 1 << 33, 32, 4), (35, 43, 1 << 17, 4, 1)])
 def test_scan_partitioned_second_level(k, ref_k, bits, n_bins, bin_cap):
-    """whole-genome-sized indexes bin the coarse gate's survivors by fine-gate slice; forced here with a 2^10-bit
+    """the partition form (option use_partition; off by default since the ticket and sub-slice forms took the index sizes it was built
+    for: on what is left to it the plain filter kernel is faster): the coarse gate's survivors binned by fine-gate slice; forced here with a 2^10-bit
     coarse gate in front of a fine one of up to 2^14 bits (slices of 2^9 bits).  bin_cap > 0 shrinks the bin segments so that most
     rows overflow them and take the spill list."""
     def check(ctx):
         assert ctx.get_option("pregate_k") > 0 and ctx.get_option("scan_bins") == n_bins
         assert (ctx.get_option("scan_spilled") > 0) == (bin_cap > 0)
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=check,
-               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap)])
+               options=[("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("scan_bin_cap", bin_cap), ("use_partition", 1)])
     def direct(ctx):
         assert ctx.get_option("scan_bins") == 0
     _scan_case(k, ref_k, bits, 3000, 150000, 31, after=direct,
@@ -130,7 +131,7 @@ def test_scan_hit_list_with_and_without_the_filter_entries(form, hit_entries):
     if form == "tickets":
         options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 1), ("ticket_min_log2", 11)]
     if form == "partition":
-        options += [("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14)]
+        options += [("use_pregate", 2), ("pregate_log2", 10), ("gate_log2", 14), ("use_partition", 1)]
 
     def check(ctx):
         assert ctx.get_option("use_hit_entries") == hit_entries
@@ -332,7 +333,7 @@ def test_scan_in_many_chunks(form, chunk_log2):
     if "tickets" in form:
         options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 1), ("ticket_min_log2", 11)]
     if form == "partition":
-        options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 0)]
+        options += [("pregate_log2", 10), ("gate_log2", 14), ("use_tickets", 0), ("use_partition", 1)]
     if "subs" in form:
         options += [("gate_log2", 14), ("use_sub", 1), ("sub_min_log2", 11), ("sub_words_log2", 3)]
     panel = synth.snp_panel(3000, 201)
